@@ -1,0 +1,271 @@
+/*
+ * oracle/nlo.c -- TEST INFRASTRUCTURE ONLY.  CPU restatement (plain C, scalar, one thread) of the
+ * reference hot path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call it;
+ * the product (nonlocal-monte-carlo_amd/) never imports, links or executes anything under oracle/.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks every function below against golden vectors
+ * captured by running the reference itself in the build container (tools/make_golden.py -> tests/golden/).
+ *
+ * Reference lines restated here (paths relative to the reference checkout):
+ *   nlo_sweeps_stream   NMC/nmc.py:28-91  (== NPT/npt.py:47-110, NPT/apt_ICM.py:52-93,
+ *                       NPT/apt_preprocessor.py:33-74): random-permutation sequential heat-bath sweeps.
+ *                       The field uses scipy's csr_matvec order (third-party, scipy==1.11.2 pinned in
+ *                       requirements.txt:14; algorithm: y_i = 0; for jj in row i ascending: y_i += A_jj*x_col),
+ *                       then `+ h`  (NMC/nmc.py:86); update rule NMC/nmc.py:87.
+ *   nlo_energy          NMC/nmc.py:386 / NPT/npt.py:31-45:  E = -(m^T J m / 2 + m^T h).
+ *   nlo_clusters        NPT/apt_ICM.py:116-143: connected components of the disagreement sub-graph,
+ *                       ordered by ascending smallest member.
+ *   nlo_sweeps_philox   NOT a reference function: the sequential *specification* of the product's throughput
+ *                       mode (Philox4x32-10 order keys + uniforms, fp32/fp64 field, base-2 logistic test).
+ *                       The HIP kernels run a level-parallel schedule that must reproduce it bit for bit.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------ */
+/* a-1  heat-bath sweeps consuming an externally drawn legacy stream (perm + uniforms per sweep)      */
+/* ------------------------------------------------------------------------------------------------ */
+/* perm[t*n + i]  : i-th spin visited in sweep t            (np.random.permutation(N), NMC/nmc.py:71)
+ * u[t*n + i]     : the i-th np.random.rand() of sweep t     (NMC/nmc.py:87)
+ * beta_run[t]    : inverse temperature of sweep t           (NMC/nmc.py:56-69, built by the caller)
+ * m              : in: start state (+-1, may hold 0), out: final state, as double like the reference
+ * M_out[t*n + k] : state after sweep t (int8), nullable
+ */
+int nlo_sweeps_stream(int n, const int32_t *rowptr, const int32_t *col, const double *val, const double *h,
+                      int num_sweeps, const int32_t *perm, const double *u, const double *beta_run,
+                      double *m, int8_t *M_out)
+{
+    for (int t = 0; t < num_sweeps; ++t) {
+        const int32_t *p = perm + (size_t)t * n;
+        const double *ut = u + (size_t)t * n;
+        const double b = beta_run[t];
+        for (int i = 0; i < n; ++i) {
+            const int k = p[i];
+            double x = 0.0;
+            for (int e = rowptr[k]; e < rowptr[k + 1]; ++e) x += val[e] * m[col[e]];
+            x = x + h[k];
+            const double v = tanh(b * x) - 2.0 * ut[i] + 1.0; /* left-to-right like the Python expression */
+            m[k] = (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : 0.0); /* np.sign */
+        }
+        if (M_out) {
+            int8_t *o = M_out + (size_t)t * n;
+            for (int k = 0; k < n; ++k) o[k] = (int8_t)m[k];
+        }
+    }
+    return 0;
+}
+
+/* a-3  E = -(m^T J m / 2 + m^T h), J in CSR with both triangles stored */
+double nlo_energy(int n, const int32_t *rowptr, const int32_t *col, const double *val, const double *h,
+                  const int8_t *m)
+{
+    double q = 0.0, l = 0.0;
+    for (int k = 0; k < n; ++k) {
+        double x = 0.0;
+        for (int e = rowptr[k]; e < rowptr[k + 1]; ++e) x += val[e] * (double)m[col[e]];
+        q += (double)m[k] * x;
+        l += (double)m[k] * h[k];
+    }
+    return -(q / 2.0 + l);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* a-9  disagreement clusters                                                                        */
+/* ------------------------------------------------------------------------------------------------ */
+/* label_out[k] = index (0-based, in the reference's list order) of the cluster holding k, or -1.
+ * returns the number of clusters. */
+int nlo_clusters(int n, const int32_t *rowptr, const int32_t *col, const double *val, const int8_t *s1,
+                 const int8_t *s2, int32_t *label_out)
+{
+    int32_t *queue = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    int nc = 0;
+    for (int k = 0; k < n; ++k) label_out[k] = -1;
+    for (int s = 0; s < n; ++s) {
+        if ((int)s1[s] * (int)s2[s] != -1 || label_out[s] >= 0) continue;
+        int head = 0, tail = 0;
+        queue[tail++] = s;
+        label_out[s] = nc;
+        while (head < tail) {
+            const int c = queue[head++];
+            for (int e = rowptr[c]; e < rowptr[c + 1]; ++e) {
+                const int j = col[e];
+                if (val[e] == 0.0) continue; /* `val != 0` test, NPT/apt_ICM.py:129 */
+                if ((int)s1[j] * (int)s2[j] != -1 || label_out[j] >= 0) continue;
+                label_out[j] = nc;
+                queue[tail++] = j;
+            }
+        }
+        ++nc;
+    }
+    free(queue);
+    return nc;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Philox4x32-10 (Salmon et al., SC'11) -- public algorithm, restated                                */
+/* ------------------------------------------------------------------------------------------------ */
+static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                 uint32_t out[4])
+{
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void nlo_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *out)
+{
+    philox4x32_10(c0, c1, c2, c3, k0, k1, out);
+}
+
+/* Stream tags (counter word 3).  Must match nonlocal-monte-carlo_amd/csrc/nlmc_device.h */
+#define NLMC_TAG_UNIFORM 1u
+#define NLMC_TAG_ORDER 2u
+#define NLMC_TAG_SWAP 3u
+#define NLMC_TAG_PAIR 4u
+#define NLMC_TAG_ICM 5u
+
+/* 2^z for |z| <= 100 from IEEE basic operations only (identical bits on CPU and GPU). */
+static inline float exp2_spec_f32(float z)
+{
+    if (z > 100.0f) z = 100.0f;
+    if (z < -100.0f) z = -100.0f;
+    const float nf = rintf(z);
+    const float f = z - nf; /* exact, |f| <= 0.5 */
+    float p = 1.540352969e-04f;     /* ln2^6/6! ; degree-6 Taylor of 2^f, rel. err ~1e-7 */
+    p = fmaf(p, f, 1.333355787e-03f);
+    p = fmaf(p, f, 9.618128650e-03f);
+    p = fmaf(p, f, 5.550410971e-02f);
+    p = fmaf(p, f, 2.402265072e-01f);
+    p = fmaf(p, f, 6.931471825e-01f);
+    p = fmaf(p, f, 1.0f);
+    union { float f; uint32_t u; } v;
+    v.f = p;
+    v.u += ((uint32_t)(int32_t)nf) << 23;
+    return v.f;
+}
+
+static inline double exp2_spec_f64(double z)
+{
+    if (z > 1000.0) z = 1000.0;
+    if (z < -1000.0) z = -1000.0;
+    const double nf = rint(z);
+    const double f = z - nf; /* exact, |f| <= 0.5 */
+    double p = 1.36914888539041241e-12;     /* ln2^13/13! ; degree-13 Taylor, rel. err < 1e-16 */
+    p = fma(p, f, 2.56784359934881958e-11);
+    p = fma(p, f, 4.44553827187081007e-10);
+    p = fma(p, f, 7.05491162080112088e-09);
+    p = fma(p, f, 1.01780860092396960e-07);
+    p = fma(p, f, 1.32154867901443053e-06);
+    p = fma(p, f, 1.52527338040598377e-05);
+    p = fma(p, f, 1.54035303933816061e-04);
+    p = fma(p, f, 1.33335581464284411e-03);
+    p = fma(p, f, 9.61812910762847688e-03);
+    p = fma(p, f, 5.55041086648215762e-02);
+    p = fma(p, f, 2.40226506959100694e-01);
+    p = fma(p, f, 6.93147180559945286e-01);
+    p = fma(p, f, 1.0);
+    union { double f; uint64_t u; } v;
+    v.f = p;
+    v.u += ((uint64_t)(int64_t)nf) << 52;
+    return v.f;
+}
+
+float nlo_exp2_f32(float z) { return exp2_spec_f32(z); }
+double nlo_exp2_f64(double z) { return exp2_spec_f64(z); }
+
+typedef struct { uint32_t key; int32_t idx; } keyed_t;
+static int keyed_cmp(const void *a, const void *b)
+{
+    const keyed_t *x = (const keyed_t *)a, *y = (const keyed_t *)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+
+/* Sequential specification of the product's throughput mode, one chain.
+ *   order of sweep t   : spins sorted by (philox(k, t, order_group, ORDER)[0], k)
+ *   uniform of (t, k)  : philox(k, t, chain_id, UNIFORM) -> 24-bit (f32) or 53-bit (f64) uniform in [0,1)
+ *   field              : x = ((0 + J_e0 s_c0) + J_e1 s_c1 ...) + h_k     in precision T
+ *   test               : z = cb * x ; e = exp2_spec(z) ; s' = (fma(u, e, u) < 1) ? +1 : -1
+ *                        cb = (T)(-2 log2(e) beta), beta = flags==1 ? beta_scaled : beta  (rounded by the caller)
+ *   flags[k]           : 0 normal, 1 scaled (cluster spin at beta/temp_x), 2/3 frozen (never updated)
+ *   energy             : fixed point, E_fix += llrint(-(s'-s) * x * 2^escale) on every flip
+ * val/h are given in double and rounded to T here (the product rounds the same way at upload).
+ */
+int nlo_sweeps_philox(int n, const int32_t *rowptr, const int32_t *col, const double *val, const double *h,
+                      int use_f64, int num_sweeps, uint32_t sweep0, const double *cb_run /*[num_sweeps][2]*/,
+                      uint32_t seed_lo, uint32_t seed_hi, uint32_t chain_id, uint32_t order_group,
+                      const uint8_t *flags /*nullable*/, int escale, int8_t *s, int64_t *efix_io,
+                      int8_t *M_out /*nullable [num_sweeps][n]*/, int64_t *efix_trace /*nullable [num_sweeps]*/)
+{
+    keyed_t *ord = (keyed_t *)malloc(sizeof(keyed_t) * (size_t)(n > 0 ? n : 1));
+    float *valf = NULL, *hf = NULL;
+    const int64_t nnz = rowptr[n];
+    if (!use_f64) {
+        valf = (float *)malloc(sizeof(float) * (size_t)(nnz > 0 ? nnz : 1));
+        hf = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+        for (int64_t e = 0; e < nnz; ++e) valf[e] = (float)val[e];
+        for (int k = 0; k < n; ++k) hf[k] = (float)h[k];
+    }
+    int64_t efix = efix_io ? *efix_io : 0;
+    const double esc = ldexp(1.0, escale);
+    for (int t = 0; t < num_sweeps; ++t) {
+        const uint32_t tt = sweep0 + (uint32_t)t;
+        uint32_t r[4];
+        for (int k = 0; k < n; ++k) {
+            philox4x32_10((uint32_t)k, tt, order_group, NLMC_TAG_ORDER, seed_lo, seed_hi, r);
+            ord[k].key = r[0];
+            ord[k].idx = k;
+        }
+        qsort(ord, (size_t)n, sizeof(keyed_t), keyed_cmp);
+        for (int i = 0; i < n; ++i) {
+            const int k = ord[i].idx;
+            const unsigned fl = flags ? flags[k] : 0u;
+            if (fl >= 2u) continue;
+            philox4x32_10((uint32_t)k, tt, chain_id, NLMC_TAG_UNIFORM, seed_lo, seed_hi, r);
+            int accept;
+            double xd;
+            if (use_f64) {
+                double x = 0.0;
+                for (int e = rowptr[k]; e < rowptr[k + 1]; ++e) x += val[e] * (double)s[col[e]];
+                x = x + h[k];
+                const double u = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) / 9007199254740992.0;
+                const double z = cb_run[2 * t + (fl == 1u)] * x;
+                const double ee = exp2_spec_f64(z);
+                accept = fma(u, ee, u) < 1.0;
+                xd = x;
+            } else {
+                float x = 0.0f;
+                for (int e = rowptr[k]; e < rowptr[k + 1]; ++e) x += valf[e] * (float)s[col[e]];
+                x = x + hf[k];
+                const float u = (float)(r[0] >> 8) * 5.9604644775390625e-08f;
+                const float z = (float)cb_run[2 * t + (fl == 1u)] * x;
+                const float ee = exp2_spec_f32(z);
+                accept = fmaf(u, ee, u) < 1.0f;
+                xd = (double)x;
+            }
+            const int8_t sn = accept ? 1 : -1;
+            if (sn != s[k]) {
+                efix += llrint(-(double)(sn - s[k]) * xd * esc);
+                s[k] = sn;
+            }
+        }
+        if (M_out) memcpy(M_out + (size_t)t * n, s, (size_t)n);
+        if (efix_trace) efix_trace[t] = efix;
+    }
+    if (efix_io) *efix_io = efix;
+    free(ord);
+    free(valf);
+    free(hf);
+    return 0;
+}

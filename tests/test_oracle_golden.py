@@ -1,0 +1,159 @@
+"""Pin the oracle (oracle/nlo.c + oracle/refport.py) to golden vectors captured from the reference itself.
+
+Spin configurations: bit-exact.  Energies: |dE| <= 1e-10 * max(1,|E|) (dense BLAS vs CSR summation order).
+"""
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import refport
+from conftest import golden, golden_names
+
+E_RTOL = 1e-10
+
+
+def csr_of(g):
+    return oracle.Csr.from_parts(int(g["N"]), g["indptr"], g["indices"], g["data"])
+
+
+def assert_energy(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    assert a.shape == b.shape
+    assert np.all(np.abs(a - b) <= E_RTOL * np.maximum(1.0, np.abs(b)))
+
+
+@pytest.mark.parametrize("name", golden_names("mcmc_fixed_") + golden_names("mcmc_icmvariant_"))
+def test_mcmc_fixed_beta(name):
+    g = golden(name)
+    csr = csr_of(g)
+    np.random.seed(int(g["seed"]))
+    m0 = np.sign(2 * np.random.rand(csr.n) - 1)
+    assert np.array_equal(m0.astype(np.int8), g["m_start"])
+    M = refport.mcmc(int(g["num_sweeps"]), m0, float(g["beta"]), csr, g["h"])
+    assert np.array_equal(M.T.astype(np.int8), g["M"])
+    E = [oracle.energy(csr, g["h"], M[:, i]) for i in range(M.shape[1])]
+    assert_energy(E, g["energies"])
+
+
+@pytest.mark.parametrize("name", golden_names("mcmc_anneal_"))
+def test_mcmc_anneal(name):
+    g = golden(name)
+    csr = csr_of(g)
+    np.random.seed(int(g["seed"]))
+    m0 = np.sign(2 * np.random.rand(csr.n) - 1)
+    M = refport.mcmc(int(g["num_sweeps"]), m0, float(g["beta"]), csr, g["h"], anneal=True,
+                     sweeps_per_beta=int(g["sweeps_per_beta"]), initial_beta=float(g["initial_beta"]))
+    assert np.array_equal(M.T.astype(np.int8), g["M"])
+
+
+@pytest.mark.parametrize("name", golden_names("nmc_subroutine_"))
+def test_nmc_subroutine(name):
+    g = golden(name)
+    J = csr_of(g).toarray()
+    variant = "npt" if "_npt_" in name else "nmc"
+    np.random.seed(int(g["seed"]))
+    m_star = np.sign(2 * np.random.rand(J.shape[0]) - 1)
+    Mo, Eo, Emin, cl = refport.nmc_subroutine(J, g["h"].copy(), variant, m_star, int(g["num_cycles"]),
+                                              int(g["num_sweeps_per_NMC_phase"]), int(g["full_update_frequency"]),
+                                              int(g["M_skip"]), float(g["global_beta"]), float(g["temp_x"]), 3, 0.01,
+                                              0.9, 0.9999999, 0.999999, 10, np.finfo(float).eps,
+                                              all_clusters=g["clusters"].copy())
+    assert np.array_equal(Mo.T.astype(np.int8), g["M_overall"])
+    assert_energy(Eo, g["energy_overall"])
+    assert_energy(Emin, g["min_energy"])
+
+
+@pytest.mark.parametrize("name", golden_names("lbp_"))
+def test_lbp(name):
+    g = golden(name)
+    J = csr_of(g).toarray()
+    h = g["h"]
+    eps = np.abs(h) + np.sum(np.abs(J), axis=1)
+    cl, marg = refport.lbp_convexified(J, h, float(g["lambda_start"]), float(g["lambda_end"]),
+                                       float(g["lambda_reduction_factor"]), g["m_star"].astype(float), eps,
+                                       np.finfo(float).eps, int(g["max_iterations"]), float(g["threshold_initial"]),
+                                       float(g["threshold_cutoff"]), float(g["global_beta"]), want_marginals=True)
+    lam = np.array(sorted(marg.keys(), reverse=True))
+    assert np.allclose(lam, g["lambdas"], rtol=0, atol=0)
+    assert np.allclose(np.array([marg[l] for l in lam]), g["marginals"], rtol=0, atol=1e-12)
+    assert np.array_equal(np.array([len(c) for c in cl]), g["cluster_sizes"])
+    got = np.concatenate(cl).astype(np.int64) if cl else np.zeros(0, np.int64)
+    assert np.array_equal(got, g["clusters_concat"])
+
+
+@pytest.mark.parametrize("name", golden_names("nmc_run_"))
+def test_nmc_run(name):
+    g = golden(name)
+    J = csr_of(g).toarray()
+    np.random.seed(int(g["seed"]))
+    obj = refport.RefNMC(J, g["h"].copy())
+    Mo, Eo, Emin = obj.run(int(g["num_sweeps_initial"]), int(g["num_sweeps_per_NMC_phase"]), int(g["num_NMC_cycles"]),
+                           int(g["full_update_frequency"]), int(g["M_skip"]), float(g["temp_x"]),
+                           float(g["global_beta"]), float(g["lambda_start"]), float(g["lambda_end"]),
+                           float(g["lambda_reduction_factor"]), float(g["threshold_initial"]),
+                           float(g["threshold_cutoff"]), int(g["max_iterations"]), np.finfo(float).eps)
+    assert np.array_equal(Mo.T.astype(np.int8), g["M_overall"])
+    assert_energy(Eo, g["energy_overall"])
+    assert_energy(Emin, g["min_energy"])
+
+
+@pytest.mark.parametrize("name", golden_names("npt_run_"))
+def test_npt_run(name):
+    g = golden(name)
+    J = csr_of(g).toarray()
+    np.random.seed(int(g["seed"]))
+    random.seed(int(g["seed"]))
+    obj = refport.RefNPT(J, g["h"].copy())
+    M, Energy = obj.run(g["beta_list"], int(g["num_replicas"]), [bool(v) for v in g["doNMC"]],
+                        int(g["num_sweeps_MCMC"]), int(g["num_sweeps_read"]), int(g["num_swap_attempts"]),
+                        int(g["num_swapping_pairs"]), int(g["num_cycles"]), 1, 1, 20, float(g["global_beta"]), 3, 0.01,
+                        0.9, 0.9999999, 0.999999, int(g["max_iterations"]), np.finfo(float).eps)
+    assert np.array_equal(obj.swap_pairs, g["swap_pairs"])
+    assert np.array_equal(obj.swap_accepted, g["swap_accepted"])
+    assert np.array_equal(M.astype(np.int8), g["M"])
+    assert_energy(Energy, g["Energy"])
+
+
+def test_disagreement_clusters():
+    g = golden("icm_clusters_pmj24")
+    csr = csr_of(g)
+    so, mo = 0, 0
+    for t in range(g["s1"].shape[0]):
+        cl = oracle.clusters(csr, g["s1"][t], g["s2"][t])
+        nc = int(g["n_clusters"][t])
+        assert len(cl) == nc
+        sizes = g["sizes"][so:so + nc]
+        so += nc
+        assert np.array_equal(np.array([len(c) for c in cl]), sizes)
+        mem = g["members"][mo:mo + int(sizes.sum())]
+        mo += int(sizes.sum())
+        assert np.array_equal(np.concatenate(cl) if cl else np.zeros(0, np.int64), mem)
+
+
+@pytest.mark.parametrize("name", golden_names("apt_icm_run_"))
+def test_apt_icm_run(name):
+    g = golden(name)
+    J = csr_of(g).toarray()
+    np.random.seed(int(g["seed"]))
+    random.seed(int(g["seed"]))
+    obj = refport.RefAPT_ICM(J, g["h"].copy())
+    M, Energy = obj.run(g["beta_list"], int(g["num_replicas"]), int(g["num_sweeps_MCMC"]), int(g["num_sweeps_read"]),
+                        int(g["num_swap_attempts"]), int(g["num_swapping_pairs"]))
+    assert np.array_equal(obj.swap_pairs, g["swap_pairs"])
+    assert np.array_equal(obj.swap_accepted, g["swap_accepted"])
+    assert np.array_equal(M.astype(np.int8), g["M"])
+    assert_energy(Energy, g["Energy"])
+
+
+def test_apt_preprocessor():
+    g = golden("apt_preprocessor_pmj16")
+    import scipy.sparse as sp
+    J = sp.csr_matrix(csr_of(g).toarray())
+    np.random.seed(int(g["seed"]))
+    obj = refport.RefAPTPreprocessor(J, g["h"].reshape(-1, 1).copy())
+    beta, sigma = obj.run(int(g["num_sweeps_MCMC"]), int(g["num_sweeps_read"]), int(g["num_rng"]),
+                          float(g["beta_start"]), float(g["alpha"]), float(g["sigma_E_val"]), float(g["beta_max"]))
+    assert np.allclose(beta, g["beta"], rtol=1e-12, atol=0)
+    assert np.allclose(sigma, g["sigma"], rtol=1e-10, atol=1e-12)
