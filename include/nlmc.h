@@ -1,0 +1,141 @@
+/*
+ * nlmc.h -- C-ABI of the MI355X-native heat-bath sweep + replica-exchange engine (libnlmc_hip.so).
+ *
+ * The reference (usra-riacs/Nonlocal-Monte-Carlo) is pure Python/NumPy and has NO FFI boundary of its own;
+ * its boundary is the Python class surface NMC(J,h).run / NPT(J,h).run / APT_ICM(J,h).run.  The entry points
+ * below are what a ctypes binding inside those classes needs to replace the reference's inner loops.  Each
+ * one names the reference lines it replaces (paths relative to the reference checkout).  Plain pointers and
+ * sizes only; no torch types.  All calls are blocking with respect to their host-pointer outputs and are
+ * stream-ordered on the HIP stream given at creation.  One context per host thread.
+ *
+ * Ownership: the caller owns every host buffer for the duration of the call only; the library owns all
+ * device memory until nlmc_destroy.  Errors: 0 = ok, negative = failure (text via nlmc_last_error).
+ * There is NO CPU fallback: without a HIP device every compute entry point fails with NLMC_ERR_HIP.
+ */
+#ifndef NLMC_H
+#define NLMC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nlmc_ctx nlmc_ctx;
+
+enum {
+    NLMC_OK = 0,
+    NLMC_ERR_ARG = -1,         /* bad argument (ValueError on the Python side) */
+    NLMC_ERR_HIP = -2,         /* HIP runtime failure / no device (RuntimeError) */
+    NLMC_ERR_UNSUPPORTED = -3, /* size outside what this build handles */
+    NLMC_ERR_STATE = -4        /* call order violated (e.g. PT call before nlmc_pt_init) */
+};
+
+enum { NLMC_F32 = 0, NLMC_F64 = 1 };                 /* arithmetic of the local field in philox mode */
+enum { NLMC_ORDER_SHARED = 0, NLMC_ORDER_PER_CHAIN = 1 }; /* one permutation per sweep for all chains | per chain */
+
+/* phase flags, one byte per (chain, spin): caller contract of NMC/nmc.py:377-381,398-401 */
+enum { NLMC_SPIN_NORMAL = 0, NLMC_SPIN_SCALED = 1, NLMC_SPIN_FROZEN_UP = 2, NLMC_SPIN_FROZEN_DOWN = 3 };
+
+#define NLMC_MAX_N 24576 /* spins per chain this build keeps in LDS */
+
+int nlmc_abi_version(void);
+int nlmc_device_count(void);
+
+/* Build a context: uploads J (CSR, both triangles, sorted columns -- what scipy.sparse.csr_matrix(J) holds at
+ * NMC/nmc.py:53) and h, allocates n_chains replicas.  chain_base / n_chains_global describe this rank's shard of
+ * a replica set spread over several GPUs (single GPU: 0 / n_chains).  hip_stream may be NULL (default stream).
+ * Replaces: the per-call `csr_matrix(J)` + process-pool pickling of self (NMC/nmc.py:53, NPT/npt.py:616-640). */
+int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz, const int32_t *rowptr,
+                const int32_t *colidx, const double *vals, const double *h, int n_chains, int chain_base,
+                int n_chains_global);
+void nlmc_destroy(nlmc_ctx *ctx);
+const char *nlmc_last_error(const nlmc_ctx *ctx); /* ctx may be NULL: error of the last failed nlmc_create */
+
+/* Replica state, int8 +-1 (0 allowed), layout [n_chains][n].  Replaces m_start / M[:, -1] hand-offs
+ * (NMC/nmc.py:50, NPT/npt.py:612,647). */
+int nlmc_set_spins(nlmc_ctx *ctx, const int8_t *spins);
+int nlmc_get_spins(nlmc_ctx *ctx, int8_t *spins);
+
+/* Phase parameterisation (NMC/nmc.py:377-381,398-401; NPT/npt.py:406-414,425,441): flags [n_chains][n] or NULL
+ * to clear.  SCALED spins see (J_k,: , h_k)/temp_x, FROZEN_UP/DOWN spins see h_k = +-10000. */
+int nlmc_set_flags(nlmc_ctx *ctx, const uint8_t *flags, double temp_x);
+
+/* E = -(m^T J m/2 + m^T h) of the current state of every local chain, fp64 (NMC/nmc.py:386, NPT/npt.py:31-45,
+ * 657-658).  Also re-synchronises the engine's incremental fixed-point energies. */
+int nlmc_energy(nlmc_ctx *ctx, double *out /*[n_chains]*/);
+/* Same, result left in device memory (for an RCCL all-gather issued by the caller). */
+int nlmc_energy_dev(nlmc_ctx *ctx, double *dev_out /*[n_chains], device pointer*/);
+
+/* log2 of the fixed-point scale of the incrementally tracked energies (E_tracked = integer * 2^-scale). */
+int nlmc_energy_scale(const nlmc_ctx *ctx);
+
+/* Energies of an arbitrary batch of configurations (trace read-out, NPT/npt.py:685-692). */
+int nlmc_energy_of(nlmc_ctx *ctx, const int8_t *spins /*[count][n]*/, int64_t count, double *out /*[count]*/);
+
+/* Outputs shared by both sweep entry points (every pointer nullable):
+ *   out_spins  [n_chains][ceil(n_sweeps/record_stride)][n]  state after sweeps 0, record_stride, 2*record_stride, ...
+ *                                                     (M[:, ::M_skip], NMC/nmc.py:89,390)
+ *   out_energy [n_chains][n_sweeps]                   energy after every sweep (NMC/nmc.py:386-387)
+ *   out_min_energy [n_chains], out_argmin [n_chains]  min / first argmin over this call's sweeps (NMC/nmc.py:394)
+ *   out_argmin_state [n_chains][n]                    the argmin column (NMC/nmc.py:395)
+ */
+
+/* STREAM mode: random-permutation sequential heat-bath sweeps consuming a pre-drawn legacy stream
+ * (np.random.permutation(N) + N x np.random.rand() per sweep, NMC/nmc.py:71,87), fp64, update rule
+ * m_k = sign(tanh(beta x_k) - 2u + 1).  Replaces MCMC(): NMC/nmc.py:28-91 == NPT/npt.py:47-110,
+ * NPT/apt_ICM.py:52-93, NPT/apt_preprocessor.py:33-74.
+ *   perm, u   : [n_chains][n_sweeps][n]  (i-th visited spin, i-th uniform)
+ *   beta      : table of inverse temperatures, element (c, t) at beta[c*chain_stride + t*sweep_stride] */
+int nlmc_sweep_stream(nlmc_ctx *ctx, int n_sweeps, const int32_t *perm, const double *u, const double *beta,
+                      int chain_stride, int sweep_stride, int record_stride, int8_t *out_spins, double *out_energy,
+                      double *out_min_energy, int32_t *out_argmin, int8_t *out_argmin_state);
+
+/* PHILOX mode (throughput): same Markov kernel, counter-based RNG generated on the device.  Sweep t of the run
+ * (global index sweep0 + t) visits spins in ascending order of philox(k, t, group, ORDER) and spin k of chain c
+ * draws philox(k, t, c, UNIFORM); results are a pure function of (seed, global chain id, sweep index, spin) and
+ * therefore independent of how chains are sharded over GPUs.
+ *   beta : as above, or NULL to take each chain's beta from the PT ladder (nlmc_pt_init). */
+int nlmc_sweep_philox(nlmc_ctx *ctx, int precision, int order_mode, int n_sweeps, uint32_t sweep0, uint64_t seed,
+                      const double *beta, int chain_stride, int sweep_stride, int record_stride, int8_t *out_spins,
+                      double *out_energy, double *out_min_energy, int32_t *out_argmin, int8_t *out_argmin_state);
+
+/* Optional: build and cache the level schedules of sweeps [sweep0, sweep0+n_sweeps) ahead of time (shared-order
+ * philox mode).  Later nlmc_sweep_philox calls inside that range with the same seed skip their schedule pass. */
+int nlmc_plan_philox(nlmc_ctx *ctx, int order_mode, uint32_t sweep0, int n_sweeps, uint64_t seed);
+
+/* Replica exchange (NPT/npt.py:602-683).  Chains are grouped into ladders of ladder_len consecutive global
+ * chain ids; slot r of a ladder runs at beta_list[r].  Accepted swaps exchange the beta slots of two chains
+ * (label exchange) -- equivalent to the reference's exchange of the two N-blocks of m_start (NPT/npt.py:677-678). */
+int nlmc_pt_init(nlmc_ctx *ctx, int ladder_len, const double *beta_list /*[ladder_len]*/);
+int nlmc_pt_get_slots(nlmc_ctx *ctx, int32_t *slot_of_chain /*[n_chains_global]*/);
+int nlmc_pt_set_slots(nlmc_ctx *ctx, const int32_t *slot_of_chain /*[n_chains_global]*/);
+/* Host-decided swaps (numpy-stream mode: select_non_overlapping_pairs + np.random.rand() stay in Python,
+ * NPT/npt.py:514-533,668-671): exchange slots a and b (0-based) of ladder `ladder`. */
+int nlmc_pt_apply_swap(nlmc_ctx *ctx, int ladder, int slot_a, int slot_b);
+/* Device-decided round: pair selection with the law of NPT/npt.py:514-533 and Metropolis acceptance
+ * u < min(1, exp(dBeta*dE)) (NPT/npt.py:668-671), Philox-keyed by (seed, round, ladder).
+ *   energies_all_dev: device pointer [n_chains_global] (after the caller's all-gather) or NULL = this context's
+ *   own current energies (single GPU).  out_pairs [n_ladders][n_pairs][2] slots, out_accepted [n_ladders][n_pairs]. */
+int nlmc_pt_swap_philox(nlmc_ctx *ctx, uint32_t round, uint64_t seed, int n_pairs, const double *energies_all_dev,
+                        int32_t *out_pairs, uint8_t *out_accepted);
+
+/* Houdayer iso-cluster move (NPT/apt_ICM.py:116-143, 215-246) between the current states of local chains a and
+ * b: connected components of the disagreement sub-graph, pick component number `pick_index mod n_components`
+ * (list ordered by ascending smallest member); if its size > n/2 and katzgraber: state a := -state a, else
+ * exchange the component between the two states.  out_info = {n_components, picked size}. */
+int nlmc_icm_components(nlmc_ctx *ctx, int chain_a, int chain_b, int32_t *out_n_components);
+int nlmc_icm_move(nlmc_ctx *ctx, int chain_a, int chain_b, int64_t pick_index, int katzgraber, int32_t *out_info);
+/* Device-decided batch: pairs [n_pairs][2] local chain ids, pick = philox(pair, round, ., ICM) */
+int nlmc_icm_round_philox(nlmc_ctx *ctx, const int32_t *pairs, int n_pairs, uint32_t round, uint64_t seed,
+                          int katzgraber, int32_t *out_info /*[n_pairs][2] nullable*/);
+
+/* Timing of the most recent sweep call, measured with HIP events on the context's stream. */
+int nlmc_last_timing(nlmc_ctx *ctx, float *ms_levelize, float *ms_sweep, int32_t *launches_sweep);
+/* Level-schedule statistics of the most recent sweep call: total levels and total spins over its orders. */
+int nlmc_last_schedule_stats(nlmc_ctx *ctx, int64_t *n_orders, int64_t *n_levels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NLMC_H */

@@ -1,0 +1,880 @@
+// nlmc.hip -- context management, kernel launchers and the C-ABI of include/nlmc.h (gfx950 only).
+#include "../../include/nlmc.h"
+#include "nlmc_kernels.h"
+#include "nlmc_pt_icm.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr double LOG2E = 1.4426950408889634;
+std::string g_create_error;
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;   // elements
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct nlmc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n = 0, n_pad = 0;
+    int64_t nnz = 0;
+    int n_chains = 0, chain_base = 0, n_chains_global = 0;
+    int escale = 32;
+    double temp_x = 1.0;
+    bool has_flags = false;
+
+    DevBuf<int32_t> rowptr, col;
+    DevBuf<double> val64, h64;
+    DevBuf<EdgeF> edge32;
+    DevBuf<float> h32;
+    DevBuf<int8_t> spins, best;
+    DevBuf<uint8_t> flags;
+    DevBuf<long long> efix, emin, etrace;
+    DevBuf<int32_t> argmin;
+    DevBuf<double> energy, tab, ustream, etrace_d;
+    DevBuf<uint32_t> keys;
+    DevBuf<int8_t> strace, cfg;
+    // schedule scratch (per call) and plan cache (persistent)
+    DevBuf<int32_t> order, lvl_off, nlev;
+    DevBuf<int32_t> p_order, p_lvl_off, p_nlev;
+    bool plan_valid = false;
+    int plan_mode = 0;
+    uint32_t plan_sweep0 = 0;
+    int plan_count = 0;
+    uint64_t plan_seed = 0;
+    // PT
+    int ladder_len = 0;
+    std::vector<double> beta_list;
+    DevBuf<double> pt_tab, pt_beta;
+    DevBuf<int32_t> slot_of_chain, chain_of_slot, pt_pairs, pt_status;
+    DevBuf<uint8_t> pt_acc;
+    // ICM
+    DevBuf<int32_t> icm_label, icm_info, icm_pairs;
+    // timing / stats
+    std::vector<hipEvent_t> events;
+    size_t ev_used = 0;
+    int launches_sweep = 0;
+    int64_t stat_orders = 0, stat_levels = 0;
+    bool stats_pending = false;
+    const int32_t *stats_nlev_ptr = nullptr;
+    int64_t stats_nlev_count = 0;
+
+    std::string err;
+    CsrDev g{};
+};
+
+namespace {
+
+int fail(nlmc_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                                   \
+    do {                                                                                                   \
+        hipError_t e__ = (expr);                                                                           \
+        if (e__ != hipSuccess)                                                                             \
+            return fail((c), NLMC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));            \
+    } while (0)
+
+hipEvent_t next_event(nlmc_ctx *c)
+{
+    if (c->ev_used == c->events.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->events.push_back(e);
+    }
+    return c->events[c->ev_used++];
+}
+
+int sweep_block(int n)
+{
+    if (const char *s = getenv("NLMC_SWEEP_NT")) {
+        int v = atoi(s);
+        if (v >= 64 && v <= 1024 && v % 64 == 0) return v;
+    }
+    int nt = ((n + 7) / 8 + 63) / 64 * 64;
+    return std::min(1024, std::max(64, nt));
+}
+
+int level_block(int n)
+{
+    int nt = ((n + 3) / 4 + 63) / 64 * 64;
+    return std::min(1024, std::max(64, nt));
+}
+
+// energies of the context's own chains -> efix (+ optional double output on device)
+int launch_energy_self(nlmc_ctx *c, double *dev_out)
+{
+    EnergyArgs a{};
+    a.g = c->g;
+    a.spins = c->spins.p;
+    a.stride = c->n_pad;
+    a.out = dev_out;
+    a.efix = c->efix.p;
+    a.escale = c->escale;
+    if (c->n_chains > 0)
+        hipLaunchKernelGGL(k_energy, dim3(c->n_chains), dim3(256), (size_t)c->n_pad, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    return NLMC_OK;
+}
+
+int run_levelize(nlmc_ctx *c, int n_orders, const uint32_t *keys_in, int per_chain, int n_sweeps, uint32_t sweep0,
+                 uint64_t seed, int32_t *order, int32_t *lvl_off, int32_t *nlev)
+{
+    if (n_orders <= 0) return NLMC_OK;
+    LevelizeArgs a{};
+    a.g = c->g;
+    a.n_orders = n_orders;
+    a.keys_in = keys_in;
+    a.seed_lo = (uint32_t)seed;
+    a.seed_hi = (uint32_t)(seed >> 32);
+    a.sweep0 = sweep0;
+    a.per_chain = per_chain;
+    a.n_sweeps = n_sweeps;
+    a.chain_base = c->chain_base;
+    a.order = order;
+    a.lvl_off = lvl_off;
+    a.nlev = nlev;
+    const size_t lds = (size_t)(c->n + 2) * 4 + (size_t)c->n * 2 + 16;
+    hipLaunchKernelGGL(k_levelize, dim3(n_orders), dim3(level_block(c->n)), lds, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    return NLMC_OK;
+}
+
+struct SweepOut {
+    int record_stride;
+    int8_t *out_spins;
+    double *out_energy;
+    double *out_min_energy;
+    int32_t *out_argmin;
+    int8_t *out_argmin_state;
+};
+
+// Shared driver: windows of sweeps -> (levelize) -> k_sweep.  `stream_mode` selects the kernel flavour.
+int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int n_sweeps, uint32_t sweep0,
+               uint64_t seed, const double *tab_dev, int tab_cs, int tab_ss, bool use_slots, const uint32_t *keys_dev,
+               const double *ustream_dev, const SweepOut &o)
+{
+    const int R = c->n_chains, n = c->n;
+    c->ev_used = 0;
+    c->launches_sweep = 0;
+    c->stat_orders = 0;
+    c->stat_levels = 0;
+    c->stats_pending = false;
+    if (R == 0 || n_sweeps == 0) return NLMC_OK;
+    const bool want_min = o.out_min_energy || o.out_argmin || o.out_argmin_state;
+    const int rec = o.out_spins ? std::max(1, o.record_stride) : 0;
+    const int n_rec = rec ? (n_sweeps + rec - 1) / rec : 0;
+    if (o.out_energy) HIP_TRY(c, c->etrace.reserve((size_t)R * n_sweeps));
+    if (rec) HIP_TRY(c, c->strace.reserve((size_t)R * n_rec * n));
+    if (want_min) {
+        std::vector<long long> init((size_t)R, LLONG_MAX);
+        HIP_TRY(c, hipMemcpyAsync(c->emin.p, init.data(), sizeof(long long) * R, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->argmin.p, 0, sizeof(int32_t) * R, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));   // `init` is a stack-lifetime host buffer
+    }
+
+    const int per_chain = (stream_mode || order_mode == NLMC_ORDER_PER_CHAIN) ? 1 : 0;
+    // plan cache hit?
+    const bool cached = !stream_mode && c->plan_valid && c->plan_mode == order_mode && c->plan_seed == seed &&
+                        !per_chain && sweep0 >= c->plan_sweep0 &&
+                        (uint64_t)sweep0 + (uint64_t)n_sweeps <= (uint64_t)c->plan_sweep0 + (uint64_t)c->plan_count;
+    // window size: keep the schedule scratch under ~256 MiB
+    const size_t per_sweep_orders = per_chain ? (size_t)R : 1;
+    const size_t bytes_per_sweep = per_sweep_orders * ((size_t)n * 4 + (size_t)(n + 1) * 4 + 4);
+    int W = n_sweeps;
+    if (!cached) {
+        // stream mode indexes its uniforms/keys by (chain, sweep) over the WHOLE call -> single window there
+        if (!stream_mode) W = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_sweeps, ((size_t)256 << 20) / bytes_per_sweep));
+        const size_t orders = per_sweep_orders * (size_t)W;
+        HIP_TRY(c, c->order.reserve(orders * n));
+        HIP_TRY(c, c->lvl_off.reserve(orders * (size_t)(n + 1)));
+        HIP_TRY(c, c->nlev.reserve(orders));
+    }
+
+    const int nt = sweep_block(n);
+    const int lds_main = c->n_pad * (c->has_flags ? 2 : 1);
+    const int lds_red_off = (lds_main + 15) / 16 * 16;
+    const size_t lds = (size_t)lds_red_off + 16;
+
+    for (int t0 = 0; t0 < n_sweeps; t0 += W) {
+        const int w = std::min(W, n_sweeps - t0);
+        const int32_t *ord, *off, *nlv;
+        hipEvent_t e0 = next_event(c), e1 = next_event(c), e2 = next_event(c);
+        if (!e0 || !e1 || !e2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(c, hipEventRecord(e0, c->stream));
+        if (cached) {
+            const size_t o0 = (size_t)(sweep0 - c->plan_sweep0) + t0;
+            ord = c->p_order.p + o0 * n;
+            off = c->p_lvl_off.p + o0 * (size_t)(n + 1);
+            nlv = c->p_nlev.p + o0;
+        } else {
+            const int n_orders = (int)per_sweep_orders * w;
+            int rc = run_levelize(c, n_orders, keys_dev, per_chain, w, sweep0 + (uint32_t)t0, seed, c->order.p,
+                                  c->lvl_off.p, c->nlev.p);
+            if (rc) return rc;
+            ord = c->order.p; off = c->lvl_off.p; nlv = c->nlev.p;
+            c->stats_nlev_ptr = c->nlev.p;
+            c->stats_nlev_count = n_orders;
+            c->stats_pending = true;
+        }
+        HIP_TRY(c, hipEventRecord(e1, c->stream));
+
+        SweepArgs a{};
+        a.g = c->g;
+        a.chain_base = c->chain_base;
+        a.spins = c->spins.p;
+        a.flags = c->has_flags ? c->flags.p : nullptr;
+        a.temp_x = c->temp_x;
+        a.order = ord; a.lvl_off = off; a.nlev = nlv;
+        a.per_chain = per_chain;
+        a.n_sweeps = w;
+        a.sweep0 = sweep0 + (uint32_t)t0;
+        a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+        a.tab = tab_dev + (size_t)t0 * tab_ss;
+        a.tab_cs = tab_cs; a.tab_ss = tab_ss;
+        a.slot_of_chain = use_slots ? c->slot_of_chain.p : nullptr;
+        a.ladder_len = c->ladder_len;
+        a.ustream = ustream_dev;
+        a.efix = c->efix.p;
+        a.escale = c->escale;
+        a.etrace = o.out_energy ? c->etrace.p : nullptr;
+        a.trace_sweeps = n_sweeps;
+        a.t0 = t0;
+        a.rec_stride = rec ? rec : 1;
+        a.strace = rec ? c->strace.p : nullptr;
+        a.emin = want_min ? c->emin.p : nullptr;
+        a.argmin = c->argmin.p;
+        a.best = (want_min && o.out_argmin_state) ? c->best.p : nullptr;
+        a.lds_red_off = lds_red_off;
+        if (stream_mode)
+            hipLaunchKernelGGL((k_sweep<double, true>), dim3(R), dim3(nt), lds, c->stream, a);
+        else if (precision == NLMC_F64)
+            hipLaunchKernelGGL((k_sweep<double, false>), dim3(R), dim3(nt), lds, c->stream, a);
+        else
+            hipLaunchKernelGGL((k_sweep<float, false>), dim3(R), dim3(nt), lds, c->stream, a);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(e2, c->stream));
+        c->launches_sweep++;
+    }
+
+    // read-out
+    bool need_sync = false;
+    std::vector<long long> h_ll;
+    if (o.out_energy) {
+        h_ll.resize((size_t)R * n_sweeps);
+        HIP_TRY(c, hipMemcpyAsync(h_ll.data(), c->etrace.p, sizeof(long long) * h_ll.size(), hipMemcpyDeviceToHost, c->stream));
+        need_sync = true;
+    }
+    std::vector<long long> h_min;
+    if (o.out_min_energy) {
+        h_min.resize(R);
+        HIP_TRY(c, hipMemcpyAsync(h_min.data(), c->emin.p, sizeof(long long) * R, hipMemcpyDeviceToHost, c->stream));
+        need_sync = true;
+    }
+    if (o.out_argmin) {
+        HIP_TRY(c, hipMemcpyAsync(o.out_argmin, c->argmin.p, sizeof(int32_t) * R, hipMemcpyDeviceToHost, c->stream));
+        need_sync = true;
+    }
+    if (o.out_argmin_state) {
+        HIP_TRY(c, hipMemcpy2DAsync(o.out_argmin_state, n, c->best.p, c->n_pad, n, R, hipMemcpyDeviceToHost, c->stream));
+        need_sync = true;
+    }
+    if (rec) {
+        HIP_TRY(c, hipMemcpyAsync(o.out_spins, c->strace.p, (size_t)R * n_rec * n, hipMemcpyDeviceToHost, c->stream));
+        need_sync = true;
+    }
+    if (need_sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const double inv = std::ldexp(1.0, -c->escale);
+    if (o.out_energy) for (size_t i = 0; i < h_ll.size(); ++i) o.out_energy[i] = (double)h_ll[i] * inv;
+    if (o.out_min_energy) for (int i = 0; i < R; ++i) o.out_min_energy[i] = (double)h_min[i] * inv;
+    return NLMC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nlmc_abi_version(void) { return 1; }
+
+int nlmc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *nlmc_last_error(const nlmc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz, const int32_t *rowptr,
+                const int32_t *colidx, const double *vals, const double *h, int n_chains, int chain_base,
+                int n_chains_global)
+{
+    if (!out) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: out is NULL");
+    *out = nullptr;
+    if (n < 1 || nnz < 0 || !rowptr || (nnz > 0 && (!colidx || !vals)) || !h || n_chains < 0 || chain_base < 0 ||
+        n_chains_global < chain_base + n_chains)
+        return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: bad sizes or NULL arrays");
+    if (n > NLMC_MAX_N) return fail(nullptr, NLMC_ERR_UNSUPPORTED, "nlmc_create: n exceeds NLMC_MAX_N (spins are LDS-resident)");
+    if (rowptr[0] != 0 || rowptr[n] != nnz) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: rowptr[0] != 0 or rowptr[n] != nnz");
+    for (int k = 0; k < n; ++k) {
+        if (rowptr[k + 1] < rowptr[k]) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: rowptr not monotone");
+        for (int e = rowptr[k]; e < rowptr[k + 1]; ++e)
+            if (colidx[e] < 0 || colidx[e] >= n) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: column index out of range");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, NLMC_ERR_HIP, "nlmc_create: no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: device index out of range");
+
+    nlmc_ctx *c = new nlmc_ctx();
+    auto bail = [&](int code) { g_create_error = c->err; nlmc_destroy(c); return code; };
+#define CT(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { c->err = std::string(#expr) + ": " + hipGetErrorString(e__); return bail(NLMC_ERR_HIP); } } while (0)
+    CT(hipSetDevice(device));
+    c->device = device;
+    c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    c->n = n;
+    c->n_pad = (n + 15) / 16 * 16;
+    c->nnz = nnz;
+    c->n_chains = n_chains;
+    c->chain_base = chain_base;
+    c->n_chains_global = n_chains_global;
+
+    // fixed-point scale: |E| <= sum|J|/2 + sum|h|
+    double bound = 0.0;
+    for (int64_t e = 0; e < nnz; ++e) bound += std::fabs(vals[e]) * 0.5;
+    for (int k = 0; k < n; ++k) bound += std::fabs(h[k]);
+    int ex = 0;
+    std::frexp(std::max(bound, 1.0), &ex);       // bound < 2^ex
+    c->escale = std::max(0, std::min(52, 60 - ex));
+
+    std::vector<EdgeF> e32((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<float> h32((size_t)n);
+    for (int64_t e = 0; e < nnz; ++e) { e32[e].col = colidx[e]; e32[e].val = (float)vals[e]; }
+    for (int k = 0; k < n; ++k) h32[k] = (float)h[k];
+
+    CT(c->rowptr.reserve((size_t)n + 1));
+    CT(c->col.reserve((size_t)nnz));
+    CT(c->val64.reserve((size_t)nnz));
+    CT(c->edge32.reserve((size_t)nnz));
+    CT(c->h64.reserve((size_t)n));
+    CT(c->h32.reserve((size_t)n));
+    CT(hipMemcpy(c->rowptr.p, rowptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
+    if (nnz > 0) {
+        CT(hipMemcpy(c->col.p, colidx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+        CT(hipMemcpy(c->val64.p, vals, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+        CT(hipMemcpy(c->edge32.p, e32.data(), sizeof(EdgeF) * (size_t)nnz, hipMemcpyHostToDevice));
+    }
+    CT(hipMemcpy(c->h64.p, h, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    CT(hipMemcpy(c->h32.p, h32.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+
+    const size_t R = (size_t)std::max(n_chains, 1);
+    CT(c->spins.reserve(R * c->n_pad));
+    CT(c->best.reserve(R * c->n_pad));
+    CT(c->flags.reserve(R * c->n_pad));
+    CT(c->efix.reserve(R));
+    CT(c->emin.reserve(R));
+    CT(c->argmin.reserve(R));
+    CT(c->energy.reserve(R));
+    CT(hipMemset(c->spins.p, 0, R * c->n_pad));
+    CT(hipMemset(c->best.p, 0, R * c->n_pad));
+    CT(hipMemset(c->flags.p, 0, R * c->n_pad));
+    CT(hipMemset(c->efix.p, 0, R * sizeof(long long)));
+
+    c->g.n = n; c->g.n_pad = c->n_pad;
+    c->g.rowptr = c->rowptr.p; c->g.col = c->col.p; c->g.val64 = c->val64.p; c->g.edge32 = c->edge32.p;
+    c->g.h64 = c->h64.p; c->g.h32 = c->h32.p;
+
+    // the level-schedule kernel may need more than the default dynamic LDS window
+    CT(hipFuncSetAttribute(reinterpret_cast<const void *>(k_levelize), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CT(hipFuncSetAttribute(reinterpret_cast<const void *>(k_icm_components), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#undef CT
+    *out = c;
+    return NLMC_OK;
+}
+
+void nlmc_destroy(nlmc_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    c->rowptr.release(); c->col.release(); c->val64.release(); c->h64.release(); c->edge32.release(); c->h32.release();
+    c->spins.release(); c->best.release(); c->flags.release(); c->efix.release(); c->emin.release(); c->etrace.release();
+    c->argmin.release(); c->energy.release(); c->tab.release(); c->ustream.release(); c->etrace_d.release();
+    c->keys.release(); c->strace.release(); c->cfg.release(); c->order.release(); c->lvl_off.release(); c->nlev.release();
+    c->p_order.release(); c->p_lvl_off.release(); c->p_nlev.release(); c->pt_tab.release(); c->pt_beta.release();
+    c->slot_of_chain.release(); c->chain_of_slot.release(); c->pt_pairs.release(); c->pt_status.release();
+    c->pt_acc.release(); c->icm_label.release(); c->icm_info.release(); c->icm_pairs.release();
+    delete c;
+}
+
+int nlmc_set_spins(nlmc_ctx *c, const int8_t *spins)
+{
+    if (!c || !spins) return fail(c, NLMC_ERR_ARG, "nlmc_set_spins: NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->n_chains == 0) return NLMC_OK;
+    HIP_TRY(c, hipMemcpy2DAsync(c->spins.p, c->n_pad, spins, c->n, c->n, c->n_chains, hipMemcpyHostToDevice, c->stream));
+    int rc = launch_energy_self(c, nullptr);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NLMC_OK;
+}
+
+int nlmc_get_spins(nlmc_ctx *c, int8_t *spins)
+{
+    if (!c || !spins) return fail(c, NLMC_ERR_ARG, "nlmc_get_spins: NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->n_chains == 0) return NLMC_OK;
+    HIP_TRY(c, hipMemcpy2DAsync(spins, c->n, c->spins.p, c->n_pad, c->n, c->n_chains, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NLMC_OK;
+}
+
+int nlmc_set_flags(nlmc_ctx *c, const uint8_t *flags, double temp_x)
+{
+    if (!c) return NLMC_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!flags) { c->has_flags = false; c->temp_x = 1.0; return NLMC_OK; }
+    if (!(temp_x > 0.0) && !(temp_x < 0.0)) return fail(c, NLMC_ERR_ARG, "nlmc_set_flags: temp_x must be non-zero");
+    for (size_t i = 0; i < (size_t)c->n_chains * c->n; ++i)
+        if (flags[i] > 3) return fail(c, NLMC_ERR_ARG, "nlmc_set_flags: flag value out of range");
+    if (c->n_chains > 0) {
+        HIP_TRY(c, hipMemcpy2DAsync(c->flags.p, c->n_pad, flags, c->n, c->n, c->n_chains, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->has_flags = true;
+    c->temp_x = temp_x;
+    return NLMC_OK;
+}
+
+int nlmc_energy(nlmc_ctx *c, double *out)
+{
+    if (!c || !out) return fail(c, NLMC_ERR_ARG, "nlmc_energy: NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->n_chains == 0) return NLMC_OK;
+    int rc = launch_energy_self(c, c->energy.p);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out, c->energy.p, sizeof(double) * c->n_chains, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NLMC_OK;
+}
+
+int nlmc_energy_dev(nlmc_ctx *c, double *dev_out)
+{
+    if (!c || !dev_out) return fail(c, NLMC_ERR_ARG, "nlmc_energy_dev: NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->n_chains == 0) return NLMC_OK;
+    hipLaunchKernelGGL(k_efix_to_double, dim3((c->n_chains + 255) / 256), dim3(256), 0, c->stream, c->efix.p, dev_out,
+                       c->n_chains, c->escale);
+    HIP_TRY(c, hipGetLastError());
+    return NLMC_OK;
+}
+
+int nlmc_energy_scale(const nlmc_ctx *c) { return c ? c->escale : 0; }
+
+int nlmc_energy_of(nlmc_ctx *c, const int8_t *spins, int64_t count, double *out)
+{
+    if (!c || !spins || !out || count < 0) return fail(c, NLMC_ERR_ARG, "nlmc_energy_of: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int64_t chunk = std::max<int64_t>(1, ((int64_t)64 << 20) / c->n);
+    for (int64_t b = 0; b < count; b += chunk) {
+        const int64_t m = std::min(chunk, count - b);
+        HIP_TRY(c, c->cfg.reserve((size_t)m * c->n));
+        HIP_TRY(c, c->etrace_d.reserve((size_t)m));
+        HIP_TRY(c, hipMemcpyAsync(c->cfg.p, spins + b * c->n, (size_t)m * c->n, hipMemcpyHostToDevice, c->stream));
+        EnergyArgs a{};
+        a.g = c->g; a.spins = c->cfg.p; a.stride = c->n; a.out = c->etrace_d.p; a.efix = nullptr; a.escale = c->escale;
+        hipLaunchKernelGGL(k_energy, dim3((unsigned)m), dim3(256), (size_t)c->n_pad, c->stream, a);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(out + b, c->etrace_d.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return NLMC_OK;
+}
+
+int nlmc_sweep_stream(nlmc_ctx *c, int n_sweeps, const int32_t *perm, const double *u, const double *beta,
+                      int chain_stride, int sweep_stride, int record_stride, int8_t *out_spins, double *out_energy,
+                      double *out_min_energy, int32_t *out_argmin, int8_t *out_argmin_state)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (n_sweeps < 0 || !beta || (n_sweeps > 0 && c->n_chains > 0 && (!perm || !u)) || (out_spins && record_stride < 1))
+        return fail(c, NLMC_ERR_ARG, "nlmc_sweep_stream: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int R = c->n_chains, n = c->n;
+    if (R == 0 || n_sweeps == 0) return NLMC_OK;
+    const size_t tot = (size_t)R * n_sweeps;
+    // scatter the stream by spin: rank[perm[i]] = i, u_spin[perm[i]] = u[i]
+    std::vector<uint32_t> rank(tot * n);
+    std::vector<double> us(tot * n);
+    std::vector<uint8_t> seen((size_t)n);
+    for (size_t o = 0; o < tot; ++o) {
+        const int32_t *p = perm + o * n;
+        const double *uu = u + o * n;
+        std::fill(seen.begin(), seen.end(), 0);
+        for (int i = 0; i < n; ++i) {
+            const int k = p[i];
+            if (k < 0 || k >= n || seen[k]) return fail(c, NLMC_ERR_ARG, "nlmc_sweep_stream: perm is not a permutation");
+            seen[k] = 1;
+            rank[o * n + k] = (uint32_t)i;
+            us[o * n + k] = uu[i];
+        }
+    }
+    // beta table -> dense [R][n_sweeps]
+    std::vector<double> tab(tot);
+    for (int r = 0; r < R; ++r)
+        for (int t = 0; t < n_sweeps; ++t) tab[(size_t)r * n_sweeps + t] = beta[(size_t)r * chain_stride + (size_t)t * sweep_stride];
+    HIP_TRY(c, c->keys.reserve(tot * n));
+    HIP_TRY(c, c->ustream.reserve(tot * n));
+    HIP_TRY(c, c->tab.reserve(tot));
+    HIP_TRY(c, hipMemcpyAsync(c->keys.p, rank.data(), sizeof(uint32_t) * tot * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->ustream.p, us.data(), sizeof(double) * tot * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->tab.p, tab.data(), sizeof(double) * tot, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    SweepOut o{record_stride, out_spins, out_energy, out_min_energy, out_argmin, out_argmin_state};
+    int rc = run_sweeps(c, true, NLMC_F64, NLMC_ORDER_PER_CHAIN, n_sweeps, 0, 0, c->tab.p, n_sweeps, 1, false, c->keys.p,
+                        c->ustream.p, o);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NLMC_OK;
+}
+
+int nlmc_sweep_philox(nlmc_ctx *c, int precision, int order_mode, int n_sweeps, uint32_t sweep0, uint64_t seed,
+                      const double *beta, int chain_stride, int sweep_stride, int record_stride, int8_t *out_spins,
+                      double *out_energy, double *out_min_energy, int32_t *out_argmin, int8_t *out_argmin_state)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (n_sweeps < 0 || (precision != NLMC_F32 && precision != NLMC_F64) ||
+        (order_mode != NLMC_ORDER_SHARED && order_mode != NLMC_ORDER_PER_CHAIN) || (out_spins && record_stride < 1))
+        return fail(c, NLMC_ERR_ARG, "nlmc_sweep_philox: bad argument");
+    if (!beta && c->ladder_len == 0) return fail(c, NLMC_ERR_STATE, "nlmc_sweep_philox: beta == NULL needs nlmc_pt_init first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int R = c->n_chains;
+    if (R == 0 || n_sweeps == 0) return NLMC_OK;
+    const double *tab_dev;
+    int tcs, tss;
+    bool use_slots = false;
+    if (beta) {
+        const int rows = chain_stride ? R : 1, T = sweep_stride ? n_sweeps : 1;
+        std::vector<double> tab((size_t)rows * T * 2);
+        for (int r = 0; r < rows; ++r)
+            for (int t = 0; t < T; ++t) {
+                const double b = beta[(size_t)r * chain_stride + (size_t)t * sweep_stride];
+                tab[((size_t)r * T + t) * 2 + 0] = -2.0 * LOG2E * b;
+                tab[((size_t)r * T + t) * 2 + 1] = -2.0 * LOG2E * (b / c->temp_x);
+            }
+        HIP_TRY(c, c->tab.reserve(tab.size()));
+        HIP_TRY(c, hipMemcpyAsync(c->tab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        tab_dev = c->tab.p;
+        tcs = chain_stride ? T * 2 : 0;
+        tss = sweep_stride ? 2 : 0;
+    } else {
+        // ladder table refreshed here so that a temp_x change after nlmc_pt_init is honoured
+        std::vector<double> tab((size_t)c->ladder_len * 2);
+        for (int r = 0; r < c->ladder_len; ++r) {
+            tab[2 * r + 0] = -2.0 * LOG2E * c->beta_list[r];
+            tab[2 * r + 1] = -2.0 * LOG2E * (c->beta_list[r] / c->temp_x);
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->pt_tab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        tab_dev = c->pt_tab.p;
+        tcs = 2; tss = 0;
+        use_slots = true;
+    }
+    SweepOut o{record_stride, out_spins, out_energy, out_min_energy, out_argmin, out_argmin_state};
+    return run_sweeps(c, false, precision, order_mode, n_sweeps, sweep0, seed, tab_dev, tcs, tss, use_slots, nullptr,
+                      nullptr, o);
+}
+
+int nlmc_plan_philox(nlmc_ctx *c, int order_mode, uint32_t sweep0, int n_sweeps, uint64_t seed)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (order_mode != NLMC_ORDER_SHARED) return fail(c, NLMC_ERR_UNSUPPORTED, "nlmc_plan_philox: only shared orders are cached");
+    if (n_sweeps < 0) return fail(c, NLMC_ERR_ARG, "nlmc_plan_philox: n_sweeps < 0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->plan_valid = false;
+    if (n_sweeps == 0) return NLMC_OK;
+    const size_t n = (size_t)c->n;
+    HIP_TRY(c, c->p_order.reserve((size_t)n_sweeps * n));
+    HIP_TRY(c, c->p_lvl_off.reserve((size_t)n_sweeps * (n + 1)));
+    HIP_TRY(c, c->p_nlev.reserve((size_t)n_sweeps));
+    int rc = run_levelize(c, n_sweeps, nullptr, 0, n_sweeps, sweep0, seed, c->p_order.p, c->p_lvl_off.p, c->p_nlev.p);
+    if (rc) return rc;
+    c->plan_valid = true;
+    c->plan_mode = order_mode;
+    c->plan_sweep0 = sweep0;
+    c->plan_count = n_sweeps;
+    c->plan_seed = seed;
+    return NLMC_OK;
+}
+
+int nlmc_last_timing(nlmc_ctx *c, float *ms_levelize, float *ms_sweep, int32_t *launches_sweep)
+{
+    if (!c) return NLMC_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    float lev = 0.f, sw = 0.f;
+    for (size_t i = 0; i + 2 < c->ev_used + 1 && i + 2 < c->events.size() + 1 && i + 3 <= c->ev_used; i += 3) {
+        HIP_TRY(c, hipEventSynchronize(c->events[i + 2]));
+        float a = 0.f, b = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&a, c->events[i], c->events[i + 1]));
+        HIP_TRY(c, hipEventElapsedTime(&b, c->events[i + 1], c->events[i + 2]));
+        lev += a; sw += b;
+    }
+    if (ms_levelize) *ms_levelize = lev;
+    if (ms_sweep) *ms_sweep = sw;
+    if (launches_sweep) *launches_sweep = c->launches_sweep;
+    return NLMC_OK;
+}
+
+int nlmc_last_schedule_stats(nlmc_ctx *c, int64_t *n_orders, int64_t *n_levels)
+{
+    if (!c) return NLMC_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int32_t *p = c->stats_pending ? c->stats_nlev_ptr : (c->plan_valid ? c->p_nlev.p : nullptr);
+    const int64_t cnt = c->stats_pending ? c->stats_nlev_count : (c->plan_valid ? c->plan_count : 0);
+    int64_t lv = 0;
+    if (p && cnt > 0) {
+        std::vector<int32_t> hnl((size_t)cnt);
+        HIP_TRY(c, hipMemcpy(hnl.data(), p, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToHost));
+        for (int32_t v : hnl) lv += v;
+    }
+    if (n_orders) *n_orders = cnt;
+    if (n_levels) *n_levels = lv;
+    return NLMC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// replica exchange
+// ---------------------------------------------------------------------------------------------------
+int nlmc_pt_init(nlmc_ctx *c, int ladder_len, const double *beta_list)
+{
+    if (!c || !beta_list || ladder_len < 1) return fail(c, NLMC_ERR_ARG, "nlmc_pt_init: bad argument");
+    if (c->n_chains_global % ladder_len != 0) return fail(c, NLMC_ERR_ARG, "nlmc_pt_init: n_chains_global not a multiple of ladder_len");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->ladder_len = ladder_len;
+    c->beta_list.assign(beta_list, beta_list + ladder_len);
+    const int G = c->n_chains_global;
+    HIP_TRY(c, c->pt_tab.reserve((size_t)ladder_len * 2));
+    HIP_TRY(c, c->pt_beta.reserve((size_t)ladder_len));
+    HIP_TRY(c, c->slot_of_chain.reserve((size_t)G));
+    HIP_TRY(c, c->chain_of_slot.reserve((size_t)G));
+    HIP_TRY(c, c->pt_status.reserve(1));
+    std::vector<int32_t> ident((size_t)G);
+    for (int i = 0; i < G; ++i) ident[i] = i % ladder_len;
+    HIP_TRY(c, hipMemcpy(c->slot_of_chain.p, ident.data(), sizeof(int32_t) * G, hipMemcpyHostToDevice));
+    for (int i = 0; i < G; ++i) ident[i] = i;   // chain_of_slot[ladder*L + slot] = global chain id
+    HIP_TRY(c, hipMemcpy(c->chain_of_slot.p, ident.data(), sizeof(int32_t) * G, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->pt_beta.p, beta_list, sizeof(double) * ladder_len, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(c->pt_status.p, 0, sizeof(int32_t)));
+    return NLMC_OK;
+}
+
+int nlmc_pt_get_slots(nlmc_ctx *c, int32_t *slot_of_chain)
+{
+    if (!c || !slot_of_chain) return fail(c, NLMC_ERR_ARG, "nlmc_pt_get_slots: NULL argument");
+    if (c->ladder_len == 0) return fail(c, NLMC_ERR_STATE, "nlmc_pt_get_slots: call nlmc_pt_init first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(slot_of_chain, c->slot_of_chain.p, sizeof(int32_t) * c->n_chains_global, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NLMC_OK;
+}
+
+int nlmc_pt_set_slots(nlmc_ctx *c, const int32_t *slot_of_chain)
+{
+    if (!c || !slot_of_chain) return fail(c, NLMC_ERR_ARG, "nlmc_pt_set_slots: NULL argument");
+    if (c->ladder_len == 0) return fail(c, NLMC_ERR_STATE, "nlmc_pt_set_slots: call nlmc_pt_init first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int G = c->n_chains_global, L = c->ladder_len;
+    std::vector<int32_t> cos((size_t)G, -1);
+    for (int i = 0; i < G; ++i) {
+        const int s = slot_of_chain[i];
+        if (s < 0 || s >= L || cos[(size_t)(i / L) * L + s] != -1) return fail(c, NLMC_ERR_ARG, "nlmc_pt_set_slots: not a permutation per ladder");
+        cos[(size_t)(i / L) * L + s] = i;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->slot_of_chain.p, slot_of_chain, sizeof(int32_t) * G, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->chain_of_slot.p, cos.data(), sizeof(int32_t) * G, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NLMC_OK;
+}
+
+int nlmc_pt_apply_swap(nlmc_ctx *c, int ladder, int slot_a, int slot_b)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (c->ladder_len == 0) return fail(c, NLMC_ERR_STATE, "nlmc_pt_apply_swap: call nlmc_pt_init first");
+    const int L = c->ladder_len;
+    if (ladder < 0 || ladder >= c->n_chains_global / L || slot_a < 0 || slot_a >= L || slot_b < 0 || slot_b >= L || slot_a == slot_b)
+        return fail(c, NLMC_ERR_ARG, "nlmc_pt_apply_swap: bad ladder/slot");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_pt_apply_swap, dim3(1), dim3(1), 0, c->stream, c->slot_of_chain.p, c->chain_of_slot.p, L, ladder, slot_a, slot_b);
+    HIP_TRY(c, hipGetLastError());
+    return NLMC_OK;
+}
+
+int nlmc_pt_swap_philox(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs, const double *energies_all_dev,
+                        int32_t *out_pairs, uint8_t *out_accepted)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (c->ladder_len == 0) return fail(c, NLMC_ERR_STATE, "nlmc_pt_swap_philox: call nlmc_pt_init first");
+    const int L = c->ladder_len, G = c->n_chains_global, nl = G / L;
+    if (n_pairs < 0 || n_pairs > std::max(0, L - 1)) return fail(c, NLMC_ERR_ARG, "Cannot find non-overlapping pairs.");
+    if (!energies_all_dev && (c->chain_base != 0 || c->n_chains != G))
+        return fail(c, NLMC_ERR_ARG, "nlmc_pt_swap_philox: a sharded context needs the all-gathered energies");
+    if (L > 4096) return fail(c, NLMC_ERR_UNSUPPORTED, "nlmc_pt_swap_philox: ladder_len > 4096");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n_pairs == 0) return NLMC_OK;
+    HIP_TRY(c, c->pt_pairs.reserve((size_t)nl * n_pairs * 2));
+    HIP_TRY(c, c->pt_acc.reserve((size_t)nl * n_pairs));
+    PtSwapArgs a{};
+    a.ladder_len = L; a.n_pairs = n_pairs; a.round = round;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.beta = c->pt_beta.p;
+    a.energies = energies_all_dev;
+    a.efix = energies_all_dev ? nullptr : c->efix.p;
+    a.escale = c->escale;
+    a.slot_of_chain = c->slot_of_chain.p; a.chain_of_slot = c->chain_of_slot.p;
+    a.out_pairs = c->pt_pairs.p; a.out_acc = c->pt_acc.p; a.status = c->pt_status.p;
+    hipLaunchKernelGGL(k_pt_swap, dim3(nl), dim3(64), (size_t)L, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    if (out_pairs || out_accepted) {
+        int32_t st = 0;
+        if (out_pairs) HIP_TRY(c, hipMemcpyAsync(out_pairs, c->pt_pairs.p, sizeof(int32_t) * (size_t)nl * n_pairs * 2, hipMemcpyDeviceToHost, c->stream));
+        if (out_accepted) HIP_TRY(c, hipMemcpyAsync(out_accepted, c->pt_acc.p, (size_t)nl * n_pairs, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&st, c->pt_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (st != 0) {
+            HIP_TRY(c, hipMemset(c->pt_status.p, 0, sizeof(int32_t)));
+            return fail(c, NLMC_ERR_ARG, "Cannot find non-overlapping pairs.");
+        }
+    }
+    return NLMC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// iso-cluster move
+// ---------------------------------------------------------------------------------------------------
+static int icm_launch_components(nlmc_ctx *c, const int32_t *pairs_dev, int n_pairs)
+{
+    HIP_TRY(c, c->icm_label.reserve((size_t)n_pairs * c->n));
+    HIP_TRY(c, c->icm_info.reserve((size_t)n_pairs * 2));
+    IcmArgs a{};
+    a.g = c->g; a.spins = c->spins.p; a.pairs = pairs_dev; a.label = c->icm_label.p; a.info = c->icm_info.p;
+    hipLaunchKernelGGL(k_icm_components, dim3(n_pairs), dim3(256), (size_t)c->n * 4 + 16, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    return NLMC_OK;
+}
+
+static int icm_check_pair(nlmc_ctx *c, int a, int b)
+{
+    if (a < 0 || b < 0 || a >= c->n_chains || b >= c->n_chains || a == b) return fail(c, NLMC_ERR_ARG, "icm: bad chain pair");
+    return NLMC_OK;
+}
+
+int nlmc_icm_components(nlmc_ctx *c, int chain_a, int chain_b, int32_t *out_n_components)
+{
+    if (!c || !out_n_components) return fail(c, NLMC_ERR_ARG, "nlmc_icm_components: NULL argument");
+    int rc = icm_check_pair(c, chain_a, chain_b);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, c->icm_pairs.reserve(2));
+    const int32_t pr[2] = {chain_a, chain_b};
+    HIP_TRY(c, hipMemcpyAsync(c->icm_pairs.p, pr, sizeof(pr), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    rc = icm_launch_components(c, c->icm_pairs.p, 1);
+    if (rc) return rc;
+    int32_t info[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(info, c->icm_info.p, sizeof(info), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *out_n_components = info[0];
+    return NLMC_OK;
+}
+
+static int icm_apply(nlmc_ctx *c, int n_pairs, const int64_t *pick_dev_or_null, int64_t pick_host, uint32_t round,
+                     uint64_t seed, int katz, int philox)
+{
+    IcmMoveArgs m{};
+    m.g = c->g; m.spins = c->spins.p; m.pairs = c->icm_pairs.p; m.label = c->icm_label.p; m.info = c->icm_info.p;
+    m.pick_host = pick_host; m.use_philox = philox; m.round = round;
+    m.seed_lo = (uint32_t)seed; m.seed_hi = (uint32_t)(seed >> 32); m.katz = katz; m.chain_base = c->chain_base;
+    (void)pick_dev_or_null;
+    hipLaunchKernelGGL(k_icm_move, dim3(n_pairs), dim3(256), 0, c->stream, m);
+    HIP_TRY(c, hipGetLastError());
+    return NLMC_OK;
+}
+
+int nlmc_icm_move(nlmc_ctx *c, int chain_a, int chain_b, int64_t pick_index, int katzgraber, int32_t *out_info)
+{
+    if (!c) return NLMC_ERR_ARG;
+    int rc = icm_check_pair(c, chain_a, chain_b);
+    if (rc) return rc;
+    if (pick_index < 0) return fail(c, NLMC_ERR_ARG, "nlmc_icm_move: pick_index < 0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, c->icm_pairs.reserve(2));
+    const int32_t pr[2] = {chain_a, chain_b};
+    HIP_TRY(c, hipMemcpyAsync(c->icm_pairs.p, pr, sizeof(pr), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    rc = icm_launch_components(c, c->icm_pairs.p, 1);
+    if (rc) return rc;
+    rc = icm_apply(c, 1, nullptr, pick_index, 0, 0, katzgraber, 0);
+    if (rc) return rc;
+    rc = launch_energy_self(c, nullptr);   // states changed non-incrementally: resync tracked energies
+    if (rc) return rc;
+    int32_t info[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(info, c->icm_info.p, sizeof(info), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (out_info) { out_info[0] = info[0]; out_info[1] = info[1]; }
+    return NLMC_OK;
+}
+
+int nlmc_icm_round_philox(nlmc_ctx *c, const int32_t *pairs, int n_pairs, uint32_t round, uint64_t seed, int katzgraber,
+                          int32_t *out_info)
+{
+    if (!c || (n_pairs > 0 && !pairs) || n_pairs < 0) return fail(c, NLMC_ERR_ARG, "nlmc_icm_round_philox: bad argument");
+    if (n_pairs == 0) return NLMC_OK;
+    std::vector<uint8_t> used((size_t)c->n_chains, 0);
+    for (int p = 0; p < n_pairs; ++p) {
+        int rc = icm_check_pair(c, pairs[2 * p], pairs[2 * p + 1]);
+        if (rc) return rc;
+        if (used[pairs[2 * p]] || used[pairs[2 * p + 1]]) return fail(c, NLMC_ERR_ARG, "nlmc_icm_round_philox: a chain appears in two pairs");
+        used[pairs[2 * p]] = used[pairs[2 * p + 1]] = 1;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, c->icm_pairs.reserve((size_t)n_pairs * 2));
+    HIP_TRY(c, hipMemcpyAsync(c->icm_pairs.p, pairs, sizeof(int32_t) * 2 * n_pairs, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc = icm_launch_components(c, c->icm_pairs.p, n_pairs);
+    if (rc) return rc;
+    rc = icm_apply(c, n_pairs, nullptr, 0, round, seed, katzgraber, 1);
+    if (rc) return rc;
+    rc = launch_energy_self(c, nullptr);
+    if (rc) return rc;
+    if (out_info) {
+        HIP_TRY(c, hipMemcpyAsync(out_info, c->icm_info.p, sizeof(int32_t) * 2 * n_pairs, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return NLMC_OK;
+}
+
+}  // extern "C"

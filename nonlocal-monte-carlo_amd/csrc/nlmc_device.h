@@ -1,0 +1,92 @@
+// nlmc_device.h -- device-side building blocks for gfx950 (wave64): Philox4x32-10, the base-2 logistic test.
+// The arithmetic here is the product's throughput-mode SPEC; oracle/nlo.c restates it independently in C and
+// the -m gpu tests require bit-identical spins between the two.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NLMC_TAG_UNIFORM 1u
+#define NLMC_TAG_ORDER 2u
+#define NLMC_TAG_SWAP 3u
+#define NLMC_TAG_PAIR 4u
+#define NLMC_TAG_ICM 5u
+
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                               uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0;
+        const uint32_t n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+// 2^z from IEEE basic operations only (clamp, rint, fma chain, exponent add): same bits on host and device.
+__device__ __forceinline__ float exp2_spec(float z)
+{
+    z = fminf(fmaxf(z, -100.0f), 100.0f);
+    const float nf = rintf(z);
+    const float f = z - nf;
+    float p = 1.540352969e-04f;
+    p = __fmaf_rn(p, f, 1.333355787e-03f);
+    p = __fmaf_rn(p, f, 9.618128650e-03f);
+    p = __fmaf_rn(p, f, 5.550410971e-02f);
+    p = __fmaf_rn(p, f, 2.402265072e-01f);
+    p = __fmaf_rn(p, f, 6.931471825e-01f);
+    p = __fmaf_rn(p, f, 1.0f);
+    return __uint_as_float(__float_as_uint(p) + (((uint32_t)(int32_t)nf) << 23));
+}
+
+__device__ __forceinline__ double exp2_spec(double z)
+{
+    z = fmin(fmax(z, -1000.0), 1000.0);
+    const double nf = rint(z);
+    const double f = z - nf;
+    double p = 1.36914888539041241e-12;
+    p = __fma_rn(p, f, 2.56784359934881958e-11);
+    p = __fma_rn(p, f, 4.44553827187081007e-10);
+    p = __fma_rn(p, f, 7.05491162080112088e-09);
+    p = __fma_rn(p, f, 1.01780860092396960e-07);
+    p = __fma_rn(p, f, 1.32154867901443053e-06);
+    p = __fma_rn(p, f, 1.52527338040598377e-05);
+    p = __fma_rn(p, f, 1.54035303933816061e-04);
+    p = __fma_rn(p, f, 1.33335581464284411e-03);
+    p = __fma_rn(p, f, 9.61812910762847688e-03);
+    p = __fma_rn(p, f, 5.55041086648215762e-02);
+    p = __fma_rn(p, f, 2.40226506959100694e-01);
+    p = __fma_rn(p, f, 6.93147180559945286e-01);
+    p = __fma_rn(p, f, 1.0);
+    return __longlong_as_double(__double_as_longlong(p) + (long long)(((uint64_t)(int64_t)nf) << 52));
+}
+
+__device__ __forceinline__ float uniform_from(const u32x4 &r, float) { return (float)(r.x >> 8) * 5.9604644775390625e-08f; }
+__device__ __forceinline__ double uniform_from(const u32x4 &r, double)
+{
+    return ((double)(r.x >> 5) * 67108864.0 + (double)(r.y >> 6)) / 9007199254740992.0;
+}
+
+// heat-bath acceptance of s=+1:  u < 1/(1+2^z)  <=>  fma(u, 2^z, u) < 1,   z = -2 log2(e) beta x
+__device__ __forceinline__ bool accept_up(float u, float z) { return __fmaf_rn(u, exp2_spec(z), u) < 1.0f; }
+__device__ __forceinline__ bool accept_up(double u, double z) { return __fma_rn(u, exp2_spec(z), u) < 1.0; }
+
+// 64-bit wave reduction (wave64) by shuffles
+__device__ __forceinline__ long long wave_sum_i64(long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64_tree(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}

@@ -1,0 +1,209 @@
+// nlmc_pt_icm.h -- replica-exchange round and Houdayer iso-cluster move kernels (gfx950).
+#pragma once
+#include "nlmc_kernels.h"
+
+// ------------------------------------------------------------------------------------------------------
+// parallel tempering: label exchange
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_pt_apply_swap(int32_t *slot_of_chain, int32_t *chain_of_slot, int L, int ladder, int sa, int sb)
+{
+    const int ca = chain_of_slot[(size_t)ladder * L + sa], cb = chain_of_slot[(size_t)ladder * L + sb];
+    slot_of_chain[ca] = sb;
+    slot_of_chain[cb] = sa;
+    chain_of_slot[(size_t)ladder * L + sa] = cb;
+    chain_of_slot[(size_t)ladder * L + sb] = ca;
+}
+
+struct PtSwapArgs {
+    int ladder_len, n_pairs;
+    uint32_t round, seed_lo, seed_hi;
+    const double *beta;         // [ladder_len]
+    const double *energies;     // [n_chains_global] or nullptr
+    const long long *efix;      // [n_chains_global] (single-GPU) or nullptr
+    int escale;
+    int32_t *slot_of_chain, *chain_of_slot;
+    int32_t *out_pairs;         // [n_ladders][n_pairs][2]
+    uint8_t *out_acc;           // [n_ladders][n_pairs]
+    int32_t *status;            // sticky: 1 = "Cannot find non-overlapping pairs."
+};
+
+// One workgroup (one wave) per ladder.  Pair selection restates select_non_overlapping_pairs (NPT/npt.py:514-533):
+// repeatedly pick uniformly among the still-available adjacent pairs (ascending list), then drop the pairs that
+// share a replica with the pick.  Acceptance: u < min(1, exp(dBeta dE)) (NPT/npt.py:668-671).
+__global__ void k_pt_swap(PtSwapArgs a)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    unsigned long long *avail = reinterpret_cast<unsigned long long *>(lds_raw);   // bit q = pair (q, q+1) available
+    __shared__ int ok;
+    const int L = a.ladder_len, g = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int npairs_all = L - 1, nw = (npairs_all + 63) / 64;
+    for (int w = tid; w < nw; w += nt) {
+        const int rem = npairs_all - w * 64;
+        avail[w] = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+    }
+    __syncthreads();
+    int32_t *pairs = a.out_pairs + (size_t)g * a.n_pairs * 2;
+    if (tid == 0) {
+        int cnt = npairs_all, good = 1;
+        for (int p = 0; p < a.n_pairs; ++p) {
+            if (cnt == 0) { good = 0; break; }
+            const uint32_t r = philox4x32_10((uint32_t)p, a.round, (uint32_t)g, NLMC_TAG_PAIR, a.seed_lo, a.seed_hi).x;
+            int idx = (int)(((unsigned long long)r * (unsigned long long)cnt) >> 32);
+            int w = 0;
+            for (;; ++w) { const int pc = __popcll(avail[w]); if (idx < pc) break; idx -= pc; }
+            unsigned long long m = avail[w];
+            for (int q = 0; q < idx; ++q) m &= m - 1;          // drop the idx lowest set bits
+            const int i = w * 64 + (__ffsll((long long)m) - 1);
+            pairs[2 * p] = i;
+            pairs[2 * p + 1] = i + 1;
+            for (int q = i - 1; q <= i + 1; ++q)
+                if (q >= 0 && q < npairs_all && ((avail[q >> 6] >> (q & 63)) & 1ull)) { avail[q >> 6] &= ~(1ull << (q & 63)); --cnt; }
+        }
+        ok = good;
+        if (!good) atomicExch(a.status, 1);
+    }
+    __syncthreads();
+    if (!ok) {
+        for (int p = tid; p < a.n_pairs; p += nt) { a.out_acc[(size_t)g * a.n_pairs + p] = 0; pairs[2 * p] = pairs[2 * p + 1] = -1; }
+        return;
+    }
+    const double inv = __longlong_as_double((long long)(1023 - a.escale) << 52);
+    for (int p = tid; p < a.n_pairs; p += nt) {
+        const int i = pairs[2 * p];
+        const int ca = a.chain_of_slot[(size_t)g * L + i], cb = a.chain_of_slot[(size_t)g * L + i + 1];
+        const double Ea = a.energies ? a.energies[ca] : (double)a.efix[ca] * inv;
+        const double Eb = a.energies ? a.energies[cb] : (double)a.efix[cb] * inv;
+        const double dE = Eb - Ea, dB = a.beta[i + 1] - a.beta[i];
+        const u32x4 r = philox4x32_10((uint32_t)p, a.round, (uint32_t)g, NLMC_TAG_SWAP, a.seed_lo, a.seed_hi);
+        const double u = uniform_from(r, 0.0);
+        const double z = (dB * dE) * 1.4426950408889634;
+        const bool acc = u < exp2_spec(z);
+        if (acc) {   // selected pairs are disjoint -> no two threads touch the same entries
+            a.slot_of_chain[ca] = i + 1;
+            a.slot_of_chain[cb] = i;
+            a.chain_of_slot[(size_t)g * L + i] = cb;
+            a.chain_of_slot[(size_t)g * L + i + 1] = ca;
+        }
+        a.out_acc[(size_t)g * a.n_pairs + p] = acc ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// iso-cluster move
+// ------------------------------------------------------------------------------------------------------
+struct IcmArgs {
+    CsrDev g;
+    const int8_t *spins;      // [n_chains][n_pad]
+    const int32_t *pairs;     // [n_pairs][2] local chain ids
+    int32_t *label;           // [n_pairs][n]  min member index of the component, or INT_MAX if the spins agree
+    int32_t *info;            // [n_pairs][2]  {n_components, picked size}
+};
+
+// Connected components of the sub-graph induced by {k : s_a[k] s_b[k] = -1} (NPT/apt_ICM.py:116-143) by min-label
+// propagation with pointer jumping in LDS.  A component's label is its smallest member, so ascending labels
+// reproduce the reference's list order.
+__global__ void k_icm_components(IcmArgs a)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    int32_t *lab = reinterpret_cast<int32_t *>(lds_raw);
+    __shared__ int nroots;
+    const int n = a.g.n, tid = threadIdx.x, nt = blockDim.x, p = blockIdx.x;
+    const int8_t *sa = a.spins + (size_t)a.pairs[2 * p] * a.g.n_pad;
+    const int8_t *sb = a.spins + (size_t)a.pairs[2 * p + 1] * a.g.n_pad;
+    for (int k = tid; k < n; k += nt) lab[k] = ((int)sa[k] * (int)sb[k] == -1) ? k : INT_MAX;
+    if (tid == 0) nroots = 0;
+    __syncthreads();
+    for (int it = 0; it <= n; ++it) {
+        int changed = 0;
+        for (int k = tid; k < n; k += nt) {
+            const int cur = lab[k];
+            if (cur == INT_MAX) continue;
+            int m = cur;
+            for (int e = a.g.rowptr[k]; e < a.g.rowptr[k + 1]; ++e) {
+                if (a.g.val64[e] == 0.0) continue;
+                const int lj = lab[a.g.col[e]];
+                if (lj < m) m = lj;
+            }
+            const int hop = lab[m];          // pointer jumping: lab[m] <= m is a member of the same component
+            if (hop < m) m = hop;
+            if (m < cur) { lab[k] = m; changed = 1; }
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+    int cnt = 0;
+    int32_t *out = a.label + (size_t)p * n;
+    for (int k = tid; k < n; k += nt) { const int l = lab[k]; out[k] = l; cnt += (l == k); }
+    if (cnt) atomicAdd(&nroots, cnt);
+    __syncthreads();
+    if (tid == 0) { a.info[2 * p] = nroots; a.info[2 * p + 1] = 0; }
+}
+
+struct IcmMoveArgs {
+    CsrDev g;
+    int8_t *spins;
+    const int32_t *pairs;
+    const int32_t *label;
+    int32_t *info;
+    long long pick_host;
+    int use_philox;
+    uint32_t round, seed_lo, seed_hi;
+    int katz;
+    int chain_base;
+};
+
+// Pick component number (pick mod n_components) in ascending-label order and apply the move
+// (NPT/apt_ICM.py:232-246).
+__global__ void k_icm_move(IcmMoveArgs a)
+{
+    __shared__ int sh_scan[17];
+    __shared__ int sh_root, sh_size;
+    const int n = a.g.n, tid = threadIdx.x, nt = blockDim.x, p = blockIdx.x;
+    const int ncomp = a.info[2 * p];
+    if (ncomp == 0) return;
+    const int ca = a.pairs[2 * p], cb = a.pairs[2 * p + 1];
+    int8_t *sa = a.spins + (size_t)ca * a.g.n_pad;
+    int8_t *sb = a.spins + (size_t)cb * a.g.n_pad;
+    const int32_t *lab = a.label + (size_t)p * n;
+    int idx;
+    if (a.use_philox) {
+        const uint32_t r = philox4x32_10((uint32_t)(a.chain_base + ca), a.round, (uint32_t)(a.chain_base + cb), NLMC_TAG_ICM,
+                                         a.seed_lo, a.seed_hi).x;
+        idx = (int)(((unsigned long long)r * (unsigned long long)ncomp) >> 32);
+    } else {
+        idx = (int)(a.pick_host % (long long)ncomp);
+    }
+    // locate the idx-th root (label[k] == k) in ascending k: contiguous chunk per thread + block scan
+    const int chunk = (n + nt - 1) / nt;
+    const int b = min(tid * chunk, n), e = min(b + chunk, n);
+    int mine = 0;
+    for (int k = b; k < e; ++k) mine += (lab[k] == k);
+    const int lane = tid & 63, wv = tid >> 6;
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+    if (lane == 63) sh_scan[wv] = incl;
+    if (tid == 0) sh_size = 0;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += sh_scan[w];
+    const int before = base + incl - mine;
+    if (idx >= before && idx < before + mine) {
+        int seen = before;
+        for (int k = b; k < e; ++k)
+            if (lab[k] == k) { if (seen == idx) { sh_root = k; break; } ++seen; }
+    }
+    __syncthreads();
+    const int root = sh_root;
+    int cnt = 0;
+    for (int k = tid; k < n; k += nt) cnt += (lab[k] == root);
+    if (cnt) atomicAdd(&sh_size, cnt);
+    __syncthreads();
+    const int size = sh_size;
+    if (a.katz && size > n / 2) {
+        for (int k = tid; k < n; k += nt) sa[k] = (int8_t)(-sa[k]);
+    } else {
+        for (int k = tid; k < n; k += nt)
+            if (lab[k] == root) { const int8_t t = sa[k]; sa[k] = sb[k]; sb[k] = t; }
+    }
+    if (tid == 0) a.info[2 * p + 1] = size;
+}

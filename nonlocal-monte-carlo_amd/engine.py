@@ -1,0 +1,232 @@
+"""Host-side handle on the HIP engine (one context = one instance (J,h) x a batch of chains on one GPU).
+
+Everything that touches spins runs in the HIP kernels behind the C-ABI (include/nlmc.h).  This module only
+marshals NumPy arrays; it contains no CPU implementation of the sweep and never imports `oracle`.
+"""
+import ctypes
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _abi
+
+
+class Instance:
+    """(J, h) as the engine wants it: CSR, both triangles, sorted columns, explicit zeros dropped -- the matrix
+    `scipy.sparse.csr_matrix(J)` the reference builds at NMC/nmc.py:53 -- without ever densifying a sparse input."""
+
+    def __init__(self, J, h):
+        A = sp.csr_matrix(J).astype(np.float64).copy()
+        if A.shape[0] != A.shape[1]:
+            raise ValueError("J must be square")
+        A.eliminate_zeros()
+        A.sort_indices()
+        self.n = int(A.shape[0])
+        self.indptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        self.indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+        self.data = np.ascontiguousarray(A.data, dtype=np.float64)
+        self.h = np.ascontiguousarray(np.asarray(h, dtype=np.float64).reshape(-1))
+        if self.h.shape[0] != self.n:
+            raise ValueError("h must have one entry per spin")
+        self.csr = A
+        d = A - A.T
+        self.symmetric = (d.nnz == 0) or (np.max(np.abs(d.data)) <= 1e-12 * max(1.0, float(np.max(np.abs(A.data)))
+                                                                                  if A.nnz else 1.0))
+
+    @property
+    def nnz(self):
+        return int(self.data.shape[0])
+
+
+def _beta_table(beta, R, S):
+    """beta: scalar | [R] | [S] (anneal schedule, only if R != S or flagged by shape) | [R,S] -> (array, cs, ss)."""
+    b = np.asarray(beta, dtype=np.float64)
+    if b.ndim == 0:
+        return np.ascontiguousarray(b.reshape(1)), 0, 0
+    if b.ndim == 2:
+        if b.shape != (R, S):
+            raise ValueError("beta table must be [n_chains, n_sweeps]")
+        return np.ascontiguousarray(b), S, 1
+    raise ValueError("pass a scalar or a 2-D table; use per_chain()/per_sweep() helpers for 1-D inputs")
+
+
+class Engine:
+    def __init__(self, J, h, n_chains, device=0, stream=None, chain_base=0, n_chains_global=None):
+        self.inst = J if isinstance(J, Instance) else Instance(J, h)
+        if not self.inst.symmetric:
+            raise ValueError("J must be symmetric: the heat-bath field and the incremental energy assume J == J^T")
+        self.n = self.inst.n
+        self.n_chains = int(n_chains)
+        self.chain_base = int(chain_base)
+        self.n_chains_global = int(n_chains_global if n_chains_global is not None else n_chains)
+        self._L = _abi.lib()
+        h_ = ctypes.c_void_p()
+        rc = self._L.nlmc_create(ctypes.byref(h_), int(device), ctypes.c_void_p(stream) if stream else None, self.n,
+                                 self.inst.nnz, _abi.ptr(self.inst.indptr), _abi.ptr(self.inst.indices),
+                                 _abi.ptr(self.inst.data), _abi.ptr(self.inst.h), self.n_chains, self.chain_base,
+                                 self.n_chains_global)
+        _abi.check(rc, None)
+        self._ctx = h_
+        self.ladder_len = 0
+        self.energy_scale = int(self._L.nlmc_energy_scale(self._ctx))
+
+    # -- lifetime ---------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.nlmc_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+        return False
+
+    def _ck(self, rc):
+        _abi.check(rc, self._ctx)
+
+    # -- state ------------------------------------------------------------------------------------------
+    def set_spins(self, spins):
+        s = _abi.as_c(spins, np.int8).reshape(self.n_chains, self.n)
+        self._ck(self._L.nlmc_set_spins(self._ctx, _abi.ptr(s)))
+
+    def get_spins(self):
+        s = np.empty((self.n_chains, self.n), dtype=np.int8)
+        self._ck(self._L.nlmc_get_spins(self._ctx, _abi.ptr(s)))
+        return s
+
+    def set_flags(self, flags, temp_x=1.0):
+        if flags is None:
+            self._ck(self._L.nlmc_set_flags(self._ctx, None, 1.0))
+            return
+        f = _abi.as_c(flags, np.uint8).reshape(self.n_chains, self.n)
+        self._ck(self._L.nlmc_set_flags(self._ctx, _abi.ptr(f), float(temp_x)))
+
+    def energy(self):
+        out = np.empty(self.n_chains, dtype=np.float64)
+        self._ck(self._L.nlmc_energy(self._ctx, _abi.ptr(out)))
+        return out
+
+    def energy_dev(self, dev_ptr):
+        self._ck(self._L.nlmc_energy_dev(self._ctx, ctypes.c_void_p(int(dev_ptr))))
+
+    def energy_of(self, configs):
+        c = _abi.as_c(configs, np.int8).reshape(-1, self.n)
+        out = np.empty(c.shape[0], dtype=np.float64)
+        self._ck(self._L.nlmc_energy_of(self._ctx, _abi.ptr(c), c.shape[0], _abi.ptr(out)))
+        return out
+
+    # -- sweeps -----------------------------------------------------------------------------------------
+    def _outputs(self, S, record_stride, want_energy, want_min, want_state):
+        R, n = self.n_chains, self.n
+        o = {}
+        o["spins"] = np.empty((R, (S + record_stride - 1) // record_stride, n), np.int8) if record_stride else None
+        o["energy"] = np.empty((R, S), np.float64) if want_energy else None
+        o["min_energy"] = np.empty(R, np.float64) if want_min else None
+        o["argmin"] = np.empty(R, np.int32) if want_min else None
+        o["argmin_state"] = np.empty((R, n), np.int8) if want_state else None
+        return o
+
+    def sweep_stream(self, perm, u, beta, record_stride=0, want_energy=False, want_min=False, want_state=False):
+        """Reference-stream sweeps (NMC/nmc.py:28-91).  perm,u: [R,S,N]; beta: scalar or [R,S] table."""
+        R, n = self.n_chains, self.n
+        perm = _abi.as_c(perm, np.int32).reshape(R, -1, n)
+        S = perm.shape[1]
+        u = _abi.as_c(u, np.float64).reshape(R, S, n)
+        tab, cs, ss = _beta_table(beta, R, S)
+        o = self._outputs(S, record_stride, want_energy, want_min, want_state)
+        self._ck(self._L.nlmc_sweep_stream(self._ctx, S, _abi.ptr(perm), _abi.ptr(u), _abi.ptr(tab), cs, ss,
+                                           max(1, record_stride), _abi.ptr(o["spins"]), _abi.ptr(o["energy"]),
+                                           _abi.ptr(o["min_energy"]), _abi.ptr(o["argmin"]),
+                                           _abi.ptr(o["argmin_state"])))
+        return o
+
+    def sweep_philox(self, n_sweeps, seed, sweep0=0, beta=None, precision="f32", order="shared", record_stride=0,
+                     want_energy=False, want_min=False, want_state=False):
+        """Throughput sweeps (device Philox).  beta: scalar | [R,S] table | None (= PT ladder)."""
+        R = self.n_chains
+        S = int(n_sweeps)
+        if beta is None:
+            tabp, cs, ss = None, 0, 0
+        else:
+            tab, cs, ss = _beta_table(beta, R, S)
+            tabp = _abi.ptr(tab)
+        o = self._outputs(S, record_stride, want_energy, want_min, want_state)
+        prec = {"f32": _abi.F32, "f64": _abi.F64}[precision]
+        om = {"shared": _abi.ORDER_SHARED, "per_chain": _abi.ORDER_PER_CHAIN}[order]
+        self._ck(self._L.nlmc_sweep_philox(self._ctx, prec, om, S, int(sweep0) & 0xFFFFFFFF, int(seed), tabp, cs, ss,
+                                           max(1, record_stride), _abi.ptr(o["spins"]), _abi.ptr(o["energy"]),
+                                           _abi.ptr(o["min_energy"]), _abi.ptr(o["argmin"]),
+                                           _abi.ptr(o["argmin_state"])))
+        return o
+
+    def plan_philox(self, sweep0, n_sweeps, seed):
+        self._ck(self._L.nlmc_plan_philox(self._ctx, _abi.ORDER_SHARED, int(sweep0), int(n_sweeps), int(seed)))
+
+    # -- replica exchange -------------------------------------------------------------------------------
+    def pt_init(self, beta_list):
+        b = _abi.as_c(beta_list, np.float64).reshape(-1)
+        self._ck(self._L.nlmc_pt_init(self._ctx, b.shape[0], _abi.ptr(b)))
+        self.ladder_len = int(b.shape[0])
+
+    def pt_slots(self):
+        s = np.empty(self.n_chains_global, dtype=np.int32)
+        self._ck(self._L.nlmc_pt_get_slots(self._ctx, _abi.ptr(s)))
+        return s
+
+    def pt_set_slots(self, slots):
+        s = _abi.as_c(slots, np.int32).reshape(self.n_chains_global)
+        self._ck(self._L.nlmc_pt_set_slots(self._ctx, _abi.ptr(s)))
+
+    def pt_apply_swap(self, ladder, slot_a, slot_b):
+        self._ck(self._L.nlmc_pt_apply_swap(self._ctx, int(ladder), int(slot_a), int(slot_b)))
+
+    def pt_swap_philox(self, round_idx, seed, n_pairs, energies_all_dev=None, want_log=True):
+        nl = self.n_chains_global // self.ladder_len
+        pairs = np.empty((nl, n_pairs, 2), np.int32) if want_log else None
+        acc = np.empty((nl, n_pairs), np.uint8) if want_log else None
+        dev = ctypes.c_void_p(int(energies_all_dev)) if energies_all_dev else None
+        self._ck(self._L.nlmc_pt_swap_philox(self._ctx, int(round_idx), int(seed), int(n_pairs), dev, _abi.ptr(pairs),
+                                             _abi.ptr(acc)))
+        return pairs, acc
+
+    # -- iso-cluster move -------------------------------------------------------------------------------
+    def icm_components(self, chain_a, chain_b):
+        out = ctypes.c_int32(0)
+        self._ck(self._L.nlmc_icm_components(self._ctx, int(chain_a), int(chain_b), ctypes.byref(out)))
+        return int(out.value)
+
+    def icm_move(self, chain_a, chain_b, pick_index, katzgraber=True):
+        info = np.zeros(2, np.int32)
+        self._ck(self._L.nlmc_icm_move(self._ctx, int(chain_a), int(chain_b), int(pick_index), int(bool(katzgraber)),
+                                       _abi.ptr(info)))
+        return int(info[0]), int(info[1])
+
+    def icm_round_philox(self, pairs, round_idx, seed, katzgraber=True, want_info=False):
+        p = _abi.as_c(pairs, np.int32).reshape(-1, 2)
+        info = np.zeros((p.shape[0], 2), np.int32) if want_info else None
+        self._ck(self._L.nlmc_icm_round_philox(self._ctx, _abi.ptr(p), p.shape[0], int(round_idx), int(seed),
+                                               int(bool(katzgraber)), _abi.ptr(info)))
+        return info
+
+    # -- measurement ------------------------------------------------------------------------------------
+    def last_timing(self):
+        a, b, c = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int32(0)
+        self._ck(self._L.nlmc_last_timing(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"ms_levelize": a.value, "ms_sweep": b.value, "launches_sweep": c.value}
+
+    def last_schedule_stats(self):
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._ck(self._L.nlmc_last_schedule_stats(self._ctx, ctypes.byref(a), ctypes.byref(b)))
+        return {"orders": a.value, "levels": b.value}
+
+
+def device_count():
+    return int(_abi.lib().nlmc_device_count())

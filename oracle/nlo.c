@@ -236,23 +236,31 @@ int nlo_sweeps_philox(int n, const int32_t *rowptr, const int32_t *col, const do
             int accept;
             double xd;
             if (use_f64) {
-                double x = 0.0;
-                for (int e = rowptr[k]; e < rowptr[k + 1]; ++e) x += val[e] * (double)s[col[e]];
+                double x = 0.0, xdg = 0.0; /* xdg: diagonal term, excluded from the energy delta */
+                for (int e = rowptr[k]; e < rowptr[k + 1]; ++e) {
+                    const double tm = val[e] * (double)s[col[e]];
+                    x += tm;
+                    if (col[e] == k) xdg += tm;
+                }
+                xd = (x - xdg) + h[k];
                 x = x + h[k];
                 const double u = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) / 9007199254740992.0;
                 const double z = cb_run[2 * t + (fl == 1u)] * x;
                 const double ee = exp2_spec_f64(z);
                 accept = fma(u, ee, u) < 1.0;
-                xd = x;
             } else {
-                float x = 0.0f;
-                for (int e = rowptr[k]; e < rowptr[k + 1]; ++e) x += valf[e] * (float)s[col[e]];
+                float x = 0.0f, xdg = 0.0f;
+                for (int e = rowptr[k]; e < rowptr[k + 1]; ++e) {
+                    const float tm = valf[e] * (float)s[col[e]];
+                    x += tm;
+                    if (col[e] == k) xdg += tm;
+                }
+                xd = (double)((x - xdg) + hf[k]);
                 x = x + hf[k];
                 const float u = (float)(r[0] >> 8) * 5.9604644775390625e-08f;
                 const float z = (float)cb_run[2 * t + (fl == 1u)] * x;
                 const float ee = exp2_spec_f32(z);
                 accept = fmaf(u, ee, u) < 1.0f;
-                xd = (double)x;
             }
             const int8_t sn = accept ? 1 : -1;
             if (sn != s[k]) {
