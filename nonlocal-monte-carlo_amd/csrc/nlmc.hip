@@ -42,6 +42,7 @@ struct nlmc_ctx {
     int escale = 32;
     double temp_x = 1.0;
     bool has_flags = false;
+    bool lds_opt_levelize = false, lds_opt_icm = false;
 
     DevBuf<int32_t> rowptr, col;
     DevBuf<double> val64, h64;
@@ -158,6 +159,10 @@ int run_levelize(nlmc_ctx *c, int n_orders, const uint32_t *keys_in, int per_cha
     a.lvl_off = lvl_off;
     a.nlev = nlev;
     const size_t lds = (size_t)(c->n + 2) * 4 + (size_t)c->n * 2 + 16;
+    if (lds > 60 * 1024 && !c->lds_opt_levelize) {   // beyond the default dynamic-LDS window: opt in once
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_levelize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        c->lds_opt_levelize = true;
+    }
     hipLaunchKernelGGL(k_levelize, dim3(n_orders), dim3(level_block(c->n)), lds, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return NLMC_OK;
@@ -407,9 +412,6 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
     c->g.rowptr = c->rowptr.p; c->g.col = c->col.p; c->g.val64 = c->val64.p; c->g.edge32 = c->edge32.p;
     c->g.h64 = c->h64.p; c->g.h32 = c->h32.p;
 
-    // the level-schedule kernel may need more than the default dynamic LDS window
-    CT(hipFuncSetAttribute(reinterpret_cast<const void *>(k_levelize), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CT(hipFuncSetAttribute(reinterpret_cast<const void *>(k_icm_components), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef CT
     *out = c;
     return NLMC_OK;
@@ -781,7 +783,12 @@ static int icm_launch_components(nlmc_ctx *c, const int32_t *pairs_dev, int n_pa
     HIP_TRY(c, c->icm_info.reserve((size_t)n_pairs * 2));
     IcmArgs a{};
     a.g = c->g; a.spins = c->spins.p; a.pairs = pairs_dev; a.label = c->icm_label.p; a.info = c->icm_info.p;
-    hipLaunchKernelGGL(k_icm_components, dim3(n_pairs), dim3(256), (size_t)c->n * 4 + 16, c->stream, a);
+    const size_t lds = (size_t)c->n * 4 + 16;
+    if (lds > 60 * 1024 && !c->lds_opt_icm) {
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_icm_components), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        c->lds_opt_icm = true;
+    }
+    hipLaunchKernelGGL(k_icm_components, dim3(n_pairs), dim3(256), lds, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return NLMC_OK;
 }
