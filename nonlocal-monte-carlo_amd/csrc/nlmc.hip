@@ -42,7 +42,8 @@ struct nlmc_ctx {
     int escale = 32;
     double temp_x = 1.0;
     bool has_flags = false;
-    bool lds_opt_levelize = false, lds_opt_icm = false;
+    bool has_diag = false;
+    size_t lds_opt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // dynamic-LDS opt-in already granted per kernel
 
     DevBuf<int32_t> rowptr, col;
     DevBuf<double> val64, h64;
@@ -56,8 +57,8 @@ struct nlmc_ctx {
     DevBuf<uint32_t> keys;
     DevBuf<int8_t> strace, cfg;
     // schedule scratch (per call) and plan cache (persistent)
-    DevBuf<int32_t> order, lvl_off, nlev;
-    DevBuf<int32_t> p_order, p_lvl_off, p_nlev;
+    DevBuf<int2> order, p_order;
+    DevBuf<int32_t> lvl_off, nlev, p_lvl_off, p_nlev;
     bool plan_valid = false;
     int plan_mode = 0;
     uint32_t plan_sweep0 = 0;
@@ -119,6 +120,16 @@ int sweep_block(int n)
     return std::min(1024, std::max(64, nt));
 }
 
+// beyond the default dynamic-LDS window a kernel has to opt in (once per size step)
+int ensure_lds(nlmc_ctx *c, int slot, const void *func, size_t bytes)
+{
+    if (bytes > (size_t)158 * 1024) return fail(c, NLMC_ERR_UNSUPPORTED, "instance too large for the LDS-resident kernels of this build");
+    if (bytes <= (size_t)60 * 1024 || bytes <= c->lds_opt[slot]) return NLMC_OK;
+    HIP_TRY(c, hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    c->lds_opt[slot] = bytes;
+    return NLMC_OK;
+}
+
 int level_block(int n)
 {
     int nt = ((n + 3) / 4 + 63) / 64 * 64;
@@ -142,7 +153,7 @@ int launch_energy_self(nlmc_ctx *c, double *dev_out)
 }
 
 int run_levelize(nlmc_ctx *c, int n_orders, const uint32_t *keys_in, int per_chain, int n_sweeps, uint32_t sweep0,
-                 uint64_t seed, int32_t *order, int32_t *lvl_off, int32_t *nlev)
+                 uint64_t seed, int2 *order, int32_t *lvl_off, int32_t *nlev)
 {
     if (n_orders <= 0) return NLMC_OK;
     LevelizeArgs a{};
@@ -155,14 +166,12 @@ int run_levelize(nlmc_ctx *c, int n_orders, const uint32_t *keys_in, int per_cha
     a.per_chain = per_chain;
     a.n_sweeps = n_sweeps;
     a.chain_base = c->chain_base;
-    a.order = order;
+    a.level_cap = sweep_block(c->n);
+    a.ord2 = order;
     a.lvl_off = lvl_off;
     a.nlev = nlev;
     const size_t lds = (size_t)(c->n + 2) * 4 + (size_t)c->n * 2 + 16;
-    if (lds > 60 * 1024 && !c->lds_opt_levelize) {   // beyond the default dynamic-LDS window: opt in once
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_levelize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        c->lds_opt_levelize = true;
-    }
+    { int rc = ensure_lds(c, 0, reinterpret_cast<const void *>(k_levelize), lds); if (rc) return rc; }
     hipLaunchKernelGGL(k_levelize, dim3(n_orders), dim3(level_block(c->n)), lds, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return NLMC_OK;
@@ -220,13 +229,30 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
     }
 
     const int nt = sweep_block(n);
-    const int lds_main = c->n_pad * (c->has_flags ? 2 : 1);
-    const int lds_red_off = (lds_main + 15) / 16 * 16;
-    const size_t lds = (size_t)lds_red_off + 16;
+    // LDS carve-up: spins | flags | uniforms of one sweep (philox) | level offsets (philox) | reduction scratch
+    const bool f64 = stream_mode || precision == NLMC_F64;
+    const int lds_flags_off = c->n_pad;
+    int cur = c->n_pad * (c->has_flags ? 2 : 1);
+    cur = (cur + 15) / 16 * 16;
+    const int lds_u_off = cur;
+    if (!stream_mode) cur += f64 ? ((n + 1) / 2 * 2) * 8 : ((n + 3) / 4 * 4) * 4;
+    cur = (cur + 15) / 16 * 16;
+    const int lds_loff_off = cur;
+    if (!stream_mode) cur += NLMC_LCAP * 4;
+    const int lds_red_off = cur;
+    const size_t lds = (size_t)cur + 16;
+    const void *kfun = stream_mode ? reinterpret_cast<const void *>(k_sweep_stream)
+                       : f64 ? (c->has_diag ? reinterpret_cast<const void *>(k_sweep_philox<double, true>)
+                                            : reinterpret_cast<const void *>(k_sweep_philox<double, false>))
+                             : (c->has_diag ? reinterpret_cast<const void *>(k_sweep_philox<float, true>)
+                                            : reinterpret_cast<const void *>(k_sweep_philox<float, false>));
+    const int kslot = stream_mode ? 2 : (f64 ? 3 : 5) + (c->has_diag ? 1 : 0);
+    { int rc = ensure_lds(c, kslot, kfun, lds); if (rc) return rc; }
 
     for (int t0 = 0; t0 < n_sweeps; t0 += W) {
         const int w = std::min(W, n_sweeps - t0);
-        const int32_t *ord, *off, *nlv;
+        const int2 *ord;
+        const int32_t *off, *nlv;
         hipEvent_t e0 = next_event(c), e1 = next_event(c), e2 = next_event(c);
         if (!e0 || !e1 || !e2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(c, hipEventRecord(e0, c->stream));
@@ -253,7 +279,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         a.spins = c->spins.p;
         a.flags = c->has_flags ? c->flags.p : nullptr;
         a.temp_x = c->temp_x;
-        a.order = ord; a.lvl_off = off; a.nlev = nlv;
+        a.ord2 = ord; a.lvl_off = off; a.nlev = nlv;
         a.per_chain = per_chain;
         a.n_sweeps = w;
         a.sweep0 = sweep0 + (uint32_t)t0;
@@ -261,7 +287,6 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         a.tab = tab_dev + (size_t)t0 * tab_ss;
         a.tab_cs = tab_cs; a.tab_ss = tab_ss;
         a.slot_of_chain = use_slots ? c->slot_of_chain.p : nullptr;
-        a.ladder_len = c->ladder_len;
         a.ustream = ustream_dev;
         a.efix = c->efix.p;
         a.escale = c->escale;
@@ -273,13 +298,17 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         a.emin = want_min ? c->emin.p : nullptr;
         a.argmin = c->argmin.p;
         a.best = (want_min && o.out_argmin_state) ? c->best.p : nullptr;
-        a.lds_red_off = lds_red_off;
+        a.lds_flags_off = lds_flags_off; a.lds_u_off = lds_u_off; a.lds_loff_off = lds_loff_off; a.lds_red_off = lds_red_off;
         if (stream_mode)
-            hipLaunchKernelGGL((k_sweep<double, true>), dim3(R), dim3(nt), lds, c->stream, a);
-        else if (precision == NLMC_F64)
-            hipLaunchKernelGGL((k_sweep<double, false>), dim3(R), dim3(nt), lds, c->stream, a);
+            hipLaunchKernelGGL(k_sweep_stream, dim3(R), dim3(nt), lds, c->stream, a);
+        else if (f64 && c->has_diag)
+            hipLaunchKernelGGL((k_sweep_philox<double, true>), dim3(R), dim3(nt), lds, c->stream, a);
+        else if (f64)
+            hipLaunchKernelGGL((k_sweep_philox<double, false>), dim3(R), dim3(nt), lds, c->stream, a);
+        else if (c->has_diag)
+            hipLaunchKernelGGL((k_sweep_philox<float, true>), dim3(R), dim3(nt), lds, c->stream, a);
         else
-            hipLaunchKernelGGL((k_sweep<float, false>), dim3(R), dim3(nt), lds, c->stream, a);
+            hipLaunchKernelGGL((k_sweep_philox<float, false>), dim3(R), dim3(nt), lds, c->stream, a);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(e2, c->stream));
         c->launches_sweep++;
@@ -344,10 +373,13 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
         return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: bad sizes or NULL arrays");
     if (n > NLMC_MAX_N) return fail(nullptr, NLMC_ERR_UNSUPPORTED, "nlmc_create: n exceeds NLMC_MAX_N (spins are LDS-resident)");
     if (rowptr[0] != 0 || rowptr[n] != nnz) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: rowptr[0] != 0 or rowptr[n] != nnz");
+    bool diag = false;
     for (int k = 0; k < n; ++k) {
         if (rowptr[k + 1] < rowptr[k]) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: rowptr not monotone");
-        for (int e = rowptr[k]; e < rowptr[k + 1]; ++e)
+        for (int e = rowptr[k]; e < rowptr[k + 1]; ++e) {
             if (colidx[e] < 0 || colidx[e] >= n) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: column index out of range");
+            if (colidx[e] == k && vals[e] != 0.0) diag = true;
+        }
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -366,6 +398,7 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
     c->n_chains = n_chains;
     c->chain_base = chain_base;
     c->n_chains_global = n_chains_global;
+    c->has_diag = diag;
 
     // fixed-point scale: |E| <= sum|J|/2 + sum|h|
     double bound = 0.0;
@@ -381,9 +414,13 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
     for (int k = 0; k < n; ++k) h32[k] = (float)h[k];
 
     CT(c->rowptr.reserve((size_t)n + 1));
-    CT(c->col.reserve((size_t)nnz));
-    CT(c->val64.reserve((size_t)nnz));
-    CT(c->edge32.reserve((size_t)nnz));
+    // +8 entries of padding: the sweep kernel prefetches fixed-width row windows (never used past the row end)
+    CT(c->col.reserve((size_t)nnz + 8));
+    CT(c->val64.reserve((size_t)nnz + 8));
+    CT(c->edge32.reserve((size_t)nnz + 8));
+    CT(hipMemset(c->col.p, 0, sizeof(int32_t) * ((size_t)nnz + 8)));
+    CT(hipMemset(c->val64.p, 0, sizeof(double) * ((size_t)nnz + 8)));
+    CT(hipMemset(c->edge32.p, 0, sizeof(EdgeF) * ((size_t)nnz + 8)));
     CT(c->h64.reserve((size_t)n));
     CT(c->h32.reserve((size_t)n));
     CT(hipMemcpy(c->rowptr.p, rowptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
@@ -784,10 +821,7 @@ static int icm_launch_components(nlmc_ctx *c, const int32_t *pairs_dev, int n_pa
     IcmArgs a{};
     a.g = c->g; a.spins = c->spins.p; a.pairs = pairs_dev; a.label = c->icm_label.p; a.info = c->icm_info.p;
     const size_t lds = (size_t)c->n * 4 + 16;
-    if (lds > 60 * 1024 && !c->lds_opt_icm) {
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_icm_components), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        c->lds_opt_icm = true;
-    }
+    { int rc = ensure_lds(c, 1, reinterpret_cast<const void *>(k_icm_components), lds); if (rc) return rc; }
     hipLaunchKernelGGL(k_icm_components, dim3(n_pairs), dim3(256), lds, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return NLMC_OK;

@@ -4,8 +4,9 @@
 //                permutation) into a LEVEL SCHEDULE: level(k) = 1 + max level(j) over neighbours j visited before k.
 //                Spins of one level are mutually non-adjacent, so updating levels in ascending order, each level
 //                in parallel, is bit-identical to the reference's sequential pass (NMC/nmc.py:71-87).
-//   k_sweep    : one workgroup per chain; the chain's spins (and phase flags) live in LDS for the whole launch;
-//                loops sweeps x levels with one s_barrier per level; CSR rows come from L2; energy is tracked
+//   k_sweep_*  : one workgroup per chain; the chain's spins (and phase flags, and one sweep's uniforms) live in LDS
+//                for the whole launch; loops sweeps x levels with one s_barrier per level; CSR rows come from L2
+//                and are prefetched one level ahead (they do not depend on spin values); energy is tracked
 //                incrementally in 64-bit fixed point (associative -> reduction order cannot change a bit).
 //   k_energy   : E = -(m^T J m/2 + m^T h) in fp64, one workgroup per configuration.
 #pragma once
@@ -35,7 +36,8 @@ struct LevelizeArgs {
     int per_chain;        // philox: order id o = c * n_sweeps + t  (group = chain_base + c + 1) else o = t (group 0)
     int n_sweeps;
     int chain_base;
-    int32_t *order;       // [n_orders][n]
+    int level_cap;        // levels wider than this are split (any subset of an independent set is independent)
+    int2 *ord2;           // [n_orders][n]  { k | deg << 16, row start }
     int32_t *lvl_off;     // [n_orders][n+1]
     int32_t *nlev;        // [n_orders]
 };
@@ -114,38 +116,53 @@ __global__ void k_levelize(LevelizeArgs a)
     for (int w = 0; w < wv; ++w) base += sh_scan[w];
     int run = base + incl - s;
     int32_t *off = a.lvl_off + (size_t)o * (n + 1);
-    for (int l = b; l < e; ++l) { const int c = (int)cnt[l]; off[l] = run; cnt[l] = (uint32_t)run; run += c; }
-    if (tid == 0) { off[nl] = n; a.nlev[o] = nl; }
+    // cursors for the placement; the published offsets additionally split levels wider than level_cap, so that
+    // the sweep kernel sees at most one spin per thread and level (sub-levels run back to back, barrier between)
+    for (int l = b; l < e; ++l) { const int c = (int)cnt[l]; cnt[l] = (uint32_t)run; run += c; }
+    __syncthreads();
+    if (tid == 0) {
+        const int cap = a.level_cap > 0 ? a.level_cap : n;
+        int m = 0;
+        for (int l = 0; l < nl; ++l) {
+            const int lo = (int)cnt[l], hi = (l + 1 < nl) ? (int)cnt[l + 1] : n;
+            for (int p = lo; p < hi; p += cap) off[m++] = p;
+        }
+        off[m] = n;
+        a.nlev[o] = m;      // m <= n because every (sub-)level holds at least one spin
+    }
     __syncthreads();
 
     // placement (intra-level order is irrelevant: same-level spins are independent)
-    int32_t *ord = a.order + (size_t)o * n;
+    int2 *ord = a.ord2 + (size_t)o * n;
     for (int k = tid; k < n; k += nt) {
         const uint32_t pos = atomicAdd(&cnt[lvl[k]], 1u);
-        ord[pos] = k;
+        const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
+        ord[pos] = make_int2(k | (deg << 16), rs);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // sweeps
 // ------------------------------------------------------------------------------------------------------
+#define NLMC_LCAP 1024          // level offsets of one sweep kept in LDS by the pipelined path
+
 struct SweepArgs {
     CsrDev g;
     int chain_base;
     int8_t *spins;            // [n_chains][n_pad]
     const uint8_t *flags;     // [n_chains][n_pad] or nullptr
     double temp_x;
-    // schedule
-    const int32_t *order, *lvl_off, *nlev;
-    int per_chain;            // order id = c * sched_sweeps + (t - 0) else t
-    int n_sweeps;             // sweeps in this launch (== orders per chain in the schedule window)
+    // schedule: ord2[o][i] = { k | deg << 16, row start }, lvl_off[o][0..nlev], nlev[o]
+    const int2 *ord2;
+    const int32_t *lvl_off, *nlev;
+    int per_chain;            // order id = c * n_sweeps + t, else t
+    int n_sweeps;             // sweeps in this launch
     uint32_t sweep0;          // global index of sweep 0 of this launch
     uint32_t seed_lo, seed_hi;
     // temperature table: element (row, t, j) at tab[row*tab_cs + t*tab_ss + j], row = slot or local chain
     const double *tab;
     int tab_cs, tab_ss;
     const int32_t *slot_of_chain;   // [n_chains_global] or nullptr
-    int ladder_len;
     // stream mode
     const double *ustream;    // [n_chains*n_sweeps][n] uniform to be consumed by spin k
     // energies
@@ -158,181 +175,331 @@ struct SweepArgs {
     long long *emin;          // [n_chains] (in/out) or nullptr
     int32_t *argmin;          // [n_chains]
     int8_t *best;             // [n_chains][n_pad] or nullptr
-    int lds_red_off;
+    // LDS carve-up (bytes from the dynamic base)
+    int lds_flags_off, lds_u_off, lds_loff_off, lds_red_off;
 };
 
-template <typename T> struct RowAcc;
+// ---- pieces shared by the two sweep kernels ------------------------------------------------------------
+struct ChainCtx {
+    int8_t *s;
+    uint8_t *fl;
+    long long *red;
+    int tid, nt, c, n, n_pad;
+    long long e_loc, E, Emin;
+    int amin;
+    bool per_sweep;
+};
 
-template <> struct RowAcc<float> {
-    // x = ((0 + v0 s0) + v1 s1) + ...  in fp32; xd = diagonal term (excluded from the energy delta)
-    static __device__ __forceinline__ void field(const CsrDev &g, const int8_t *s, int k, int rs, int re, float &x,
-                                                 float &xd)
-    {
-        x = 0.0f; xd = 0.0f;
-        for (int e = rs; e < re; e += 8) {
-            EdgeF ed[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) ed[q] = g.edge32[min(e + q, re - 1)];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float t = ed[q].val * (float)s[ed[q].col];
-                if (e + q < re) { x += t; if (ed[q].col == k) xd += t; }
-            }
+__device__ __forceinline__ void chain_load(const SweepArgs &a, unsigned char *lds_raw, ChainCtx &x)
+{
+    x.n = a.g.n; x.n_pad = a.g.n_pad;
+    x.tid = threadIdx.x; x.nt = blockDim.x; x.c = blockIdx.x;
+    x.s = reinterpret_cast<int8_t *>(lds_raw);
+    x.fl = a.flags ? (lds_raw + a.lds_flags_off) : nullptr;
+    x.red = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);   // [0] sweep sum, [1] broadcast flag
+    const int4 *src = reinterpret_cast<const int4 *>(a.spins + (size_t)x.c * x.n_pad);
+    int4 *dst = reinterpret_cast<int4 *>(x.s);
+    for (int i = x.tid; i < x.n_pad / 16; i += x.nt) dst[i] = src[i];
+    if (x.fl) {
+        const int4 *fsrc = reinterpret_cast<const int4 *>(a.flags + (size_t)x.c * x.n_pad);
+        int4 *fdst = reinterpret_cast<int4 *>(x.fl);
+        for (int i = x.tid; i < x.n_pad / 16; i += x.nt) fdst[i] = fsrc[i];
+    }
+    if (x.tid == 0) { x.red[0] = 0; x.red[1] = 0; }
+    x.e_loc = 0;
+    x.E = a.efix[x.c];
+    x.Emin = a.emin ? a.emin[x.c] : 0;
+    x.amin = a.emin ? a.argmin[x.c] : 0;
+    x.per_sweep = (a.etrace != nullptr) || (a.emin != nullptr);
+    __syncthreads();
+}
+
+// end-of-sweep bookkeeping: energy trace, running minimum + argmin state, recorded configurations
+__device__ __forceinline__ void sweep_epilogue(const SweepArgs &a, ChainCtx &x, int t)
+{
+    const int tg = a.t0 + t;                                 // sweep index inside the call
+    const bool rec = a.strace && (tg % a.rec_stride == 0);   // M[:, ::M_skip]  (NMC/nmc.py:390)
+    if (x.per_sweep) {
+        const long long w = wave_sum_i64(x.e_loc);
+        x.e_loc = 0;
+        if ((x.tid & 63) == 0 && w != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&x.red[0]), (unsigned long long)w);
+        __syncthreads();
+        if (x.tid == 0) {
+            x.E += x.red[0];
+            x.red[0] = 0;
+            if (a.etrace) a.etrace[(size_t)x.c * a.trace_sweeps + tg] = x.E;
+            int better = 0;
+            if (a.emin && x.E < x.Emin) { x.Emin = x.E; x.amin = tg; better = 1; }   // strict <: first argmin (np.argmin)
+            x.red[1] = better;
+        }
+        __syncthreads();
+        if (a.best && x.red[1]) {
+            int4 *dst = reinterpret_cast<int4 *>(a.best + (size_t)x.c * x.n_pad);
+            const int4 *src = reinterpret_cast<const int4 *>(x.s);
+            for (int i = x.tid; i < x.n_pad / 16; i += x.nt) dst[i] = src[i];
         }
     }
-    static __device__ __forceinline__ float h(const CsrDev &g, int k) { return g.h32[k]; }
-};
-
-template <> struct RowAcc<double> {
-    static __device__ __forceinline__ void field(const CsrDev &g, const int8_t *s, int k, int rs, int re, double &x,
-                                                 double &xd)
-    {
-        x = 0.0; xd = 0.0;
-        for (int e = rs; e < re; e += 4) {
-            int cj[4]; double vj[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const int ee = min(e + q, re - 1); cj[q] = g.col[ee]; vj[q] = g.val64[ee]; }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double t = vj[q] * (double)s[cj[q]];
-                if (e + q < re) { x += t; if (cj[q] == k) xd += t; }
-            }
-        }
+    if (rec) {
+        const int n_rec = (a.trace_sweeps + a.rec_stride - 1) / a.rec_stride;
+        int8_t *dst = a.strace + ((size_t)x.c * n_rec + (size_t)(tg / a.rec_stride)) * x.n;
+        for (int i = x.tid; i < x.n; i += x.nt) dst[i] = x.s[i];
     }
-    static __device__ __forceinline__ double h(const CsrDev &g, int k) { return g.h64[k]; }
-};
+    if (x.per_sweep || rec) __syncthreads();   // LDS spins / red[1] are rewritten next sweep
+}
 
-template <typename T, bool STREAM>
-__global__ void k_sweep(SweepArgs a)
+__device__ __forceinline__ void chain_store(const SweepArgs &a, ChainCtx &x)
+{
+    if (!x.per_sweep) {
+        const long long w = wave_sum_i64(x.e_loc);
+        if ((x.tid & 63) == 0 && w != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&x.red[0]), (unsigned long long)w);
+        __syncthreads();
+        if (x.tid == 0) x.E += x.red[0];
+    }
+    int4 *dst = reinterpret_cast<int4 *>(a.spins + (size_t)x.c * x.n_pad);
+    const int4 *src = reinterpret_cast<const int4 *>(x.s);
+    for (int i = x.tid; i < x.n_pad / 16; i += x.nt) dst[i] = src[i];
+    if (x.tid == 0) {
+        a.efix[x.c] = x.E;
+        if (a.emin) { a.emin[x.c] = x.Emin; a.argmin[x.c] = x.amin; }
+    }
+}
+
+// ---- STREAM mode: the reference's arithmetic, fp64, externally drawn uniforms --------------------------
+// m_k = sign(tanh(beta x_k) - 2u + 1),  x = (sum_e J_e m_e) + h_k in CSR order  (NMC/nmc.py:86-87)
+__global__ void k_sweep_stream(SweepArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int n = a.g.n, n_pad = a.g.n_pad;
-    int8_t *s = reinterpret_cast<int8_t *>(lds_raw);
-    uint8_t *fl = a.flags ? (lds_raw + n_pad) : nullptr;
-    long long *red = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);   // [0] sweep sum, [1] broadcast flag
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int c = blockIdx.x;
-    const uint32_t gc = (uint32_t)(a.chain_base + c);
-
-    {   // chain state -> LDS (16-byte vectors; rows are padded to 16)
-        const int4 *src = reinterpret_cast<const int4 *>(a.spins + (size_t)c * n_pad);
-        int4 *dst = reinterpret_cast<int4 *>(s);
-        for (int i = tid; i < n_pad / 16; i += nt) dst[i] = src[i];
-        if (fl) {
-            const int4 *fsrc = reinterpret_cast<const int4 *>(a.flags + (size_t)c * n_pad);
-            int4 *fdst = reinterpret_cast<int4 *>(fl);
-            for (int i = tid; i < n_pad / 16; i += nt) fdst[i] = fsrc[i];
-        }
-    }
-    if (tid == 0) { red[0] = 0; red[1] = 0; }
-    __syncthreads();
-
-    const int row = a.slot_of_chain ? a.slot_of_chain[gc] : c;
+    ChainCtx x;
+    chain_load(a, lds_raw, x);
+    const int n = x.n, tid = x.tid, nt = x.nt, c = x.c;
+    int8_t *s = x.s;
+    const uint8_t *fl = x.fl;
     const double esc = __longlong_as_double((long long)(1023 + a.escale) << 52);   // 2^escale
-    long long e_loc = 0;                       // this thread's share of the running energy delta
-    long long E = a.efix[c];                   // meaningful in thread 0
-    long long Emin = a.emin ? a.emin[c] : 0;
-    int amin = a.emin ? a.argmin[c] : 0;
-    const bool per_sweep = (a.etrace != nullptr) || (a.emin != nullptr);
 
     for (int t = 0; t < a.n_sweeps; ++t) {
         const int oid = a.per_chain ? (c * a.n_sweeps + t) : t;
-        const int32_t *__restrict__ ord = a.order + (size_t)oid * n;
+        const int2 *__restrict__ ord = a.ord2 + (size_t)oid * n;
         const int32_t *__restrict__ off = a.lvl_off + (size_t)oid * (n + 1);
         const int nl = a.nlev[oid];
-        const double tb0 = a.tab[(size_t)row * a.tab_cs + (size_t)t * a.tab_ss];
-        const double tb1 = STREAM ? tb0 : a.tab[(size_t)row * a.tab_cs + (size_t)t * a.tab_ss + 1];
-        const uint32_t tt = a.sweep0 + (uint32_t)t;
-
+        const double beta = a.tab[(size_t)c * a.tab_cs + (size_t)t * a.tab_ss];
+        const double *__restrict__ ut = a.ustream + ((size_t)c * a.n_sweeps + t) * n;
         for (int l = 0; l < nl; ++l) {
             const int lo = off[l], hi = off[l + 1];
             for (int i = lo + tid; i < hi; i += nt) {
-                const int k = ord[i];
+                const int2 en = ord[i];
+                const int k = en.x & 0xFFFF, rs = en.y, re = en.y + (int)((unsigned)en.x >> 16);
                 const unsigned f = fl ? (unsigned)fl[k] : 0u;
-                const int rs = a.g.rowptr[k], re = a.g.rowptr[k + 1];
                 const int so = (int)s[k];
-                int sn;
-                double x_true;   // field of the UNMODIFIED (J,h) without the diagonal term, for the energy delta
-                if constexpr (STREAM) {
-                    // reference arithmetic: x = (sum_e J_e m_e) + h_k on the phase matrices, fp64, CSR order
-                    double x, xd;
-                    RowAcc<double>::field(a.g, s, k, rs, re, x, xd);
-                    x_true = (x - xd) + a.g.h64[k];
-                    double xp;
-                    if (f == 0u) xp = x + a.g.h64[k];
-                    else if (f == 1u) {   // rows of cluster spins divided element-wise by temp_x (NMC/nmc.py:379-380)
-                        double y = 0.0;
-                        for (int e = rs; e < re; ++e) y += (a.g.val64[e] / a.temp_x) * (double)s[a.g.col[e]];
-                        xp = y + a.g.h64[k] / a.temp_x;
-                    } else xp = x + ((f == 2u) ? 10000.0 : -10000.0);   // NMC/nmc.py:381,401
-                    const double u = a.ustream[((size_t)c * a.n_sweeps + t) * n + k];
-                    const double v = tanh(tb0 * xp) - 2.0 * u + 1.0;
-                    sn = (v > 0.0) - (v < 0.0);                          // np.sign
-                } else {
-                    if (f >= 2u) continue;                               // frozen
-                    T x, xd;
-                    RowAcc<T>::field(a.g, s, k, rs, re, x, xd);
-                    const T hk = RowAcc<T>::h(a.g, k);
-                    x_true = (double)((x - xd) + hk);
-                    x = x + hk;
-                    const u32x4 r = philox4x32_10((uint32_t)k, tt, gc, NLMC_TAG_UNIFORM, a.seed_lo, a.seed_hi);
-                    const T u = uniform_from(r, T(0));
-                    const T z = (T)(f == 1u ? tb1 : tb0) * x;
-                    sn = accept_up(u, z) ? 1 : -1;
+                double xs = 0.0, xd = 0.0;   // xd: diagonal term, excluded from the energy delta
+                for (int e = rs; e < re; ++e) {
+                    const int j = a.g.col[e];
+                    const double tm = a.g.val64[e] * (double)s[j];
+                    xs += tm;
+                    if (j == k) xd += tm;
                 }
+                const double hk = a.g.h64[k];
+                const double x_true = (xs - xd) + hk;   // field of the UNMODIFIED (J,h)
+                double xp;
+                if (f == 0u) xp = xs + hk;
+                else if (f == 1u) {   // cluster rows divided element-wise by temp_x (NMC/nmc.py:379-380)
+                    double y = 0.0;
+                    for (int e = rs; e < re; ++e) y += (a.g.val64[e] / a.temp_x) * (double)s[a.g.col[e]];
+                    xp = y + hk / a.temp_x;
+                } else xp = xs + ((f == 2u) ? 10000.0 : -10000.0);   // NMC/nmc.py:381,401
+                const double v = tanh(beta * xp) - 2.0 * ut[k] + 1.0;
+                const int sn = (v > 0.0) - (v < 0.0);                // np.sign
                 if (sn != so) {
-                    e_loc += __double2ll_rn(-(double)(sn - so) * x_true * esc);
+                    x.e_loc += __double2ll_rn(-(double)(sn - so) * x_true * esc);
                     s[k] = (int8_t)sn;
                 }
             }
             __syncthreads();
         }
-
-        const int tg = a.t0 + t;                                 // sweep index inside the call
-        const bool rec = a.strace && (tg % a.rec_stride == 0);   // M[:, ::M_skip]  (NMC/nmc.py:390)
-        if (per_sweep) {
-            const long long w = wave_sum_i64(e_loc);
-            e_loc = 0;
-            if ((tid & 63) == 0 && w != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&red[0]), (unsigned long long)w);
-            __syncthreads();
-            if (tid == 0) {
-                E += red[0];
-                red[0] = 0;
-                if (a.etrace) a.etrace[(size_t)c * a.trace_sweeps + tg] = E;
-                int better = 0;
-                if (a.emin && E < Emin) { Emin = E; amin = tg; better = 1; }   // strict <: first argmin (np.argmin)
-                red[1] = better;
-            }
-            __syncthreads();
-            if (a.best && red[1]) {
-                int4 *dst = reinterpret_cast<int4 *>(a.best + (size_t)c * n_pad);
-                const int4 *src = reinterpret_cast<const int4 *>(s);
-                for (int i = tid; i < n_pad / 16; i += nt) dst[i] = src[i];
-            }
-        }
-        if (rec) {
-            const int n_rec = (a.trace_sweeps + a.rec_stride - 1) / a.rec_stride;
-            int8_t *dst = a.strace + ((size_t)c * n_rec + (size_t)(tg / a.rec_stride)) * n;
-            for (int i = tid; i < n; i += nt) dst[i] = s[i];
-        }
-        if (per_sweep || rec) __syncthreads();   // LDS spins / red[1] are rewritten next sweep
+        sweep_epilogue(a, x, t);
     }
+    chain_store(a, x);
+}
 
-    if (!per_sweep) {
-        const long long w = wave_sum_i64(e_loc);
-        if ((tid & 63) == 0 && w != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&red[0]), (unsigned long long)w);
-        __syncthreads();
-        if (tid == 0) E += red[0];
-    }
+// ---- PHILOX mode (throughput) ---------------------------------------------------------------------------
+template <typename T> struct Pf;            // prefetched first chunk of a CSR row
+template <> struct Pf<float> {
+    static constexpr int W = 8;
+    EdgeF ed[W];
+    float h;
+    __device__ __forceinline__ void load(const CsrDev &g, int k, int rs, int deg)
     {
-        int4 *dst = reinterpret_cast<int4 *>(a.spins + (size_t)c * n_pad);
-        const int4 *src = reinterpret_cast<const int4 *>(s);
-        for (int i = tid; i < n_pad / 16; i += nt) dst[i] = src[i];
+        // unconditional window [rs, rs+W): one address + W immediate offsets; entries past the row end are
+        // never used (q < deg below) and the device array is padded by W entries, so the reads stay in bounds
+        const EdgeF *__restrict__ p = g.edge32 + rs;
+#pragma unroll
+        for (int q = 0; q < W; ++q) ed[q] = p[q];
+        (void)deg;
+        h = g.h32[k];
     }
-    if (tid == 0) {
-        a.efix[c] = E;
-        if (a.emin) { a.emin[c] = Emin; a.argmin[c] = amin; }
+    __device__ __forceinline__ int col(int q) const { return ed[q].col; }
+    __device__ __forceinline__ float val(int q) const { return ed[q].val; }
+    static __device__ __forceinline__ void tail(const CsrDev &g, int e, int &cj, float &vj) { const EdgeF t = g.edge32[e]; cj = t.col; vj = t.val; }
+};
+template <> struct Pf<double> {
+    static constexpr int W = 4;
+    int cj[W];
+    double vj[W];
+    double h;
+    __device__ __forceinline__ void load(const CsrDev &g, int k, int rs, int deg)
+    {
+        const int32_t *__restrict__ pc = g.col + rs;
+        const double *__restrict__ pv = g.val64 + rs;
+#pragma unroll
+        for (int q = 0; q < W; ++q) { cj[q] = pc[q]; vj[q] = pv[q]; }
+        (void)deg;
+        h = g.h64[k];
     }
+    __device__ __forceinline__ int col(int q) const { return cj[q]; }
+    __device__ __forceinline__ double val(int q) const { return vj[q]; }
+    static __device__ __forceinline__ void tail(const CsrDev &g, int e, int &c, double &v) { c = g.col[e]; v = g.val64[e]; }
+};
+
+__device__ __forceinline__ float fma_rn(float a, float b, float c) { return __fmaf_rn(a, b, c); }
+__device__ __forceinline__ double fma_rn(double a, double b, double c) { return __fma_rn(a, b, c); }
+
+// Heat-bath update of one spin from a prefetched row.  J*s is exact (s = +-1), so fma(J, s, x) == x + J*s.
+template <typename T, bool DIAG>
+__device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, const T *ur, int kd, int rs, const Pf<T> &pf,
+                                            T cb0, T cb1, double esc)
+{
+    const int k = kd & 0xFFFF, deg = (int)((unsigned)kd >> 16);
+    const unsigned f = x.fl ? (unsigned)x.fl[k] : 0u;
+    if (f >= 2u) return;                       // frozen
+    int8_t *s = x.s;
+    T xs = T(0), xd = T(0);
+    // branch-free over the prefetched window: every LDS read is issued up front (window entries past the row end
+    // hold valid column indices of later rows / zero padding), the select keeps the reference summation order
+    T sj[Pf<T>::W];
+#pragma unroll
+    for (int q = 0; q < Pf<T>::W; ++q) sj[q] = (T)s[pf.col(q)];
+#pragma unroll
+    for (int q = 0; q < Pf<T>::W; ++q) {
+        const T nx = fma_rn(pf.val(q), sj[q], xs);
+        xs = (q < deg) ? nx : xs;
+        if (DIAG) { const T nd = fma_rn(pf.val(q), sj[q], xd); xd = (q < deg && pf.col(q) == k) ? nd : xd; }
+    }
+    for (int e = Pf<T>::W; e < deg; ++e) {     // rows longer than the prefetch window
+        int j; T v;
+        Pf<T>::tail(a.g, rs + e, j, v);
+        const T sj = (T)s[j];
+        xs = fma_rn(v, sj, xs);
+        if (DIAG && j == k) xd = fma_rn(v, sj, xd);
+    }
+    const T x_true = DIAG ? ((xs - xd) + pf.h) : (xs + pf.h);
+    const T xf = xs + pf.h;
+    const T z = (f == 1u ? cb1 : cb0) * xf;
+    const int so = (int)s[k];
+    const int sn = accept_up(ur[k], z) ? 1 : -1;
+    if (sn != so) {
+        x.e_loc += __double2ll_rn(-(double)(sn - so) * (double)x_true * esc);
+        s[k] = (int8_t)sn;
+    }
+}
+
+// uniforms of one sweep for every spin of this chain -> LDS.  One Philox4x32-10 call serves 4 (f32) / 2 (f64) spins:
+//   f32: u(k) = 24 high bits of word (k & 3) of philox(k >> 2, t, chain, UNIFORM)
+//   f64: u(k) = 53 bits from words (2(k&1), 2(k&1)+1) of philox(k >> 1, t, chain, UNIFORM)
+__device__ __forceinline__ void fill_uniforms(float *ur, int n, uint32_t tt, uint32_t gc, uint32_t k0, uint32_t k1, int tid, int nt)
+{
+    for (int b = tid; b < (n + 3) / 4; b += nt) {
+        const u32x4 r = philox4x32_10((uint32_t)b, tt, gc, NLMC_TAG_UNIFORM, k0, k1);
+        float4 v;
+        v.x = (float)(r.x >> 8) * 5.9604644775390625e-08f;
+        v.y = (float)(r.y >> 8) * 5.9604644775390625e-08f;
+        v.z = (float)(r.z >> 8) * 5.9604644775390625e-08f;
+        v.w = (float)(r.w >> 8) * 5.9604644775390625e-08f;
+        reinterpret_cast<float4 *>(ur)[b] = v;     // ur has (n+3)/4*4 entries
+    }
+}
+__device__ __forceinline__ void fill_uniforms(double *ur, int n, uint32_t tt, uint32_t gc, uint32_t k0, uint32_t k1, int tid, int nt)
+{
+    for (int b = tid; b < (n + 1) / 2; b += nt) {
+        const u32x4 r = philox4x32_10((uint32_t)b, tt, gc, NLMC_TAG_UNIFORM, k0, k1);
+        double2 v;
+        v.x = ((double)(r.x >> 5) * 67108864.0 + (double)(r.y >> 6)) / 9007199254740992.0;
+        v.y = ((double)(r.z >> 5) * 67108864.0 + (double)(r.w >> 6)) / 9007199254740992.0;
+        reinterpret_cast<double2 *>(ur)[b] = v;    // ur has (n+1)/2*2 entries
+    }
+}
+
+template <typename T, bool DIAG>
+__global__ void k_sweep_philox(SweepArgs a)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    ChainCtx x;
+    chain_load(a, lds_raw, x);
+    const int n = x.n, tid = x.tid, nt = x.nt, c = x.c;
+    T *ur = reinterpret_cast<T *>(lds_raw + a.lds_u_off);
+    int *loff = reinterpret_cast<int *>(lds_raw + a.lds_loff_off);
+    const uint32_t gc = (uint32_t)(a.chain_base + c);
+    const int row = a.slot_of_chain ? a.slot_of_chain[gc] : c;
+    const double esc = __longlong_as_double((long long)(1023 + a.escale) << 52);   // 2^escale
+
+    for (int t = 0; t < a.n_sweeps; ++t) {
+        const int oid = a.per_chain ? (c * a.n_sweeps + t) : t;
+        const int2 *__restrict__ ord = a.ord2 + (size_t)oid * n;
+        const int32_t *__restrict__ off = a.lvl_off + (size_t)oid * (n + 1);
+        const int nl = a.nlev[oid];
+        const T cb0 = (T)a.tab[(size_t)row * a.tab_cs + (size_t)t * a.tab_ss];
+        const T cb1 = (T)a.tab[(size_t)row * a.tab_cs + (size_t)t * a.tab_ss + 1];
+        const uint32_t tt = a.sweep0 + (uint32_t)t;
+
+        // sweep prologue: all lanes busy -- uniforms for every spin, level offsets into LDS
+        fill_uniforms(ur, n, tt, gc, a.seed_lo, a.seed_hi, tid, nt);
+        const bool fast = nl < NLMC_LCAP;
+        if (fast) for (int l = tid; l <= nl; l += nt) loff[l] = off[l];
+        __syncthreads();
+
+        if (fast) {
+            // software pipeline over levels: while level l is computed, the (k,row) entry of level l+2 and the
+            // CSR row of level l+1 are already in flight -- none of those loads depends on spin values.
+            // The schedule was built with level_cap == blockDim.x: at most one spin per thread and level.
+            // All prefetch loads are unconditional (clamped to valid memory) so that no select or copy ever waits
+            // on a load issued in the same stage; validity comes from the LDS offsets alone.
+            int2 e0, e1, e2;               // raw schedule entries of levels l, l+1, l+2 for this thread
+            bool v0, v1, v2;
+            Pf<T> pfa, pfb;                // ping-pong row windows (manual 2x unroll: no register rotation)
+            auto entry = [&](int l, int2 &en, bool &valid) {
+                const int lc = min(l, nl - 1);
+                const int i = loff[lc] + tid;
+                valid = (l < nl) && (i < loff[lc + 1]);
+                en = ord[min(i, n - 1)];
+            };
+            auto stage = [&](int l, Pf<T> &pc, Pf<T> &pn) {
+                entry(l + 2, e2, v2);                                            // A: level l+2
+                pn.load(a.g, e1.x & 0xFFFF, e1.y, (int)((unsigned)e1.x >> 16));  // B: level l+1
+                if (v0) update_spin<T, DIAG>(a, x, ur, e0.x, e0.y, pc, cb0, cb1, esc);
+                __syncthreads();
+                e0 = e1; v0 = v1; e1 = e2; v1 = v2;
+            };
+            entry(0, e0, v0);
+            entry(1, e1, v1);
+            pfa.load(a.g, e0.x & 0xFFFF, e0.y, (int)((unsigned)e0.x >> 16));
+            for (int l = 0; l < nl; l += 2) {
+                stage(l, pfa, pfb);
+                if (l + 1 < nl) stage(l + 1, pfb, pfa);
+            }
+        } else {
+            // very deep schedules (dense graphs): plain level loop
+            for (int l = 0; l < nl; ++l) {
+                const int lo = off[l], hi = off[l + 1];
+                for (int i = lo + tid; i < hi; i += nt) {
+                    const int2 en = ord[i];
+                    Pf<T> pe;
+                    pe.load(a.g, en.x & 0xFFFF, en.y, (int)((unsigned)en.x >> 16));
+                    update_spin<T, DIAG>(a, x, ur, en.x, en.y, pe, cb0, cb1, esc);
+                }
+                __syncthreads();
+            }
+        }
+        sweep_epilogue(a, x, t);
+    }
+    chain_store(a, x);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -194,7 +194,8 @@ static int keyed_cmp(const void *a, const void *b)
 
 /* Sequential specification of the product's throughput mode, one chain.
  *   order of sweep t   : spins sorted by (philox(k, t, order_group, ORDER)[0], k)
- *   uniform of (t, k)  : philox(k, t, chain_id, UNIFORM) -> 24-bit (f32) or 53-bit (f64) uniform in [0,1)
+ *   uniform of (t, k)  : f32: 24 high bits of word (k&3) of philox(k>>2, t, chain_id, UNIFORM);
+ *                        f64: 53 bits from words (2(k&1), 2(k&1)+1) of philox(k>>1, t, chain_id, UNIFORM)
  *   field              : x = ((0 + J_e0 s_c0) + J_e1 s_c1 ...) + h_k     in precision T
  *   test               : z = cb * x ; e = exp2_spec(z) ; s' = (fma(u, e, u) < 1) ? +1 : -1
  *                        cb = (T)(-2 log2(e) beta), beta = flags==1 ? beta_scaled : beta  (rounded by the caller)
@@ -232,7 +233,8 @@ int nlo_sweeps_philox(int n, const int32_t *rowptr, const int32_t *col, const do
             const int k = ord[i].idx;
             const unsigned fl = flags ? flags[k] : 0u;
             if (fl >= 2u) continue;
-            philox4x32_10((uint32_t)k, tt, chain_id, NLMC_TAG_UNIFORM, seed_lo, seed_hi, r);
+            /* one Philox call serves 4 (f32) / 2 (f64) consecutive spins */
+            philox4x32_10((uint32_t)(use_f64 ? (k >> 1) : (k >> 2)), tt, chain_id, NLMC_TAG_UNIFORM, seed_lo, seed_hi, r);
             int accept;
             double xd;
             if (use_f64) {
@@ -244,7 +246,8 @@ int nlo_sweeps_philox(int n, const int32_t *rowptr, const int32_t *col, const do
                 }
                 xd = (x - xdg) + h[k];
                 x = x + h[k];
-                const double u = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) / 9007199254740992.0;
+                const int w0 = 2 * (k & 1);
+                const double u = ((double)(r[w0] >> 5) * 67108864.0 + (double)(r[w0 + 1] >> 6)) / 9007199254740992.0;
                 const double z = cb_run[2 * t + (fl == 1u)] * x;
                 const double ee = exp2_spec_f64(z);
                 accept = fma(u, ee, u) < 1.0;
@@ -257,7 +260,7 @@ int nlo_sweeps_philox(int n, const int32_t *rowptr, const int32_t *col, const do
                 }
                 xd = (double)((x - xdg) + hf[k]);
                 x = x + hf[k];
-                const float u = (float)(r[0] >> 8) * 5.9604644775390625e-08f;
+                const float u = (float)(r[k & 3] >> 8) * 5.9604644775390625e-08f;
                 const float z = (float)cb_run[2 * t + (fl == 1u)] * x;
                 const float ee = exp2_spec_f32(z);
                 accept = fmaf(u, ee, u) < 1.0f;
