@@ -101,8 +101,9 @@ int nlmc_sweep_philox(nlmc_ctx *ctx, int precision, int order_mode, int n_sweeps
                       double *out_energy, double *out_min_energy, int32_t *out_argmin, int8_t *out_argmin_state);
 
 /* Optional: build and cache the level schedules of sweeps [sweep0, sweep0+n_sweeps) ahead of time (shared-order
- * philox mode).  Later nlmc_sweep_philox calls inside that range with the same seed skip their schedule pass. */
-int nlmc_plan_philox(nlmc_ctx *ctx, int order_mode, uint32_t sweep0, int n_sweeps, uint64_t seed);
+ * philox mode).  Later nlmc_sweep_philox calls inside that range with the same seed and precision skip their
+ * schedule pass. */
+int nlmc_plan_philox(nlmc_ctx *ctx, int precision, int order_mode, uint32_t sweep0, int n_sweeps, uint64_t seed);
 
 /* Replica exchange (NPT/npt.py:602-683).  Chains are grouped into ladders of ladder_len consecutive global
  * chain ids; slot r of a ladder runs at beta_list[r].  Accepted swaps exchange the beta slots of two chains

@@ -85,7 +85,7 @@ def lib():
     L.nlmc_sweep_philox.restype = _i
     L.nlmc_sweep_philox.argtypes = [_vp, _i, _i, _i, _u32, _u64, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
     L.nlmc_plan_philox.restype = _i
-    L.nlmc_plan_philox.argtypes = [_vp, _i, _u32, _i, _u64]
+    L.nlmc_plan_philox.argtypes = [_vp, _i, _i, _u32, _i, _u64]
     L.nlmc_pt_init.restype = _i
     L.nlmc_pt_init.argtypes = [_vp, _i, _vp]
     L.nlmc_pt_apply_swap.restype = _i

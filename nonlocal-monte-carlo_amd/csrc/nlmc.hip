@@ -57,8 +57,31 @@ struct nlmc_ctx {
     DevBuf<uint32_t> keys;
     DevBuf<int8_t> strace, cfg;
     // schedule scratch (per call) and plan cache (persistent)
-    DevBuf<int2> order, p_order;
-    DevBuf<int32_t> lvl_off, nlev, p_lvl_off, p_nlev;
+    struct Sched {            // one set of level-schedule buffers (per-call scratch, or the persistent plan)
+        DevBuf<int2> order, head32;
+        DevBuf<int32_t> lvl_off, nlev, ellc64;
+        DevBuf<EdgeF> ell32;
+        DevBuf<double> ellv64, headh64;
+        hipError_t reserve(size_t orders, size_t n, int mode /*0 none, 1 f32, 2 f64*/)
+        {
+            hipError_t e;
+            if ((e = order.reserve(orders * n)) != hipSuccess) return e;
+            if ((e = lvl_off.reserve(orders * (n + 1))) != hipSuccess) return e;
+            if ((e = nlev.reserve(orders)) != hipSuccess) return e;
+            if (mode == 1) {
+                if ((e = head32.reserve(orders * n)) != hipSuccess) return e;
+                if ((e = ell32.reserve(orders * n * NLMC_ELL_W)) != hipSuccess) return e;
+            } else if (mode == 2) {
+                if ((e = headh64.reserve(orders * n)) != hipSuccess) return e;
+                if ((e = ellc64.reserve(orders * n * NLMC_ELL_W)) != hipSuccess) return e;
+                if ((e = ellv64.reserve(orders * n * NLMC_ELL_W)) != hipSuccess) return e;
+            }
+            return hipSuccess;
+        }
+        void release() { order.release(); head32.release(); lvl_off.release(); nlev.release(); ellc64.release(); ell32.release(); ellv64.release(); headh64.release(); }
+    };
+    Sched scratch, plan;
+    int plan_precision = 0;
     bool plan_valid = false;
     int plan_mode = 0;
     uint32_t plan_sweep0 = 0;
@@ -153,7 +176,7 @@ int launch_energy_self(nlmc_ctx *c, double *dev_out)
 }
 
 int run_levelize(nlmc_ctx *c, int n_orders, const uint32_t *keys_in, int per_chain, int n_sweeps, uint32_t sweep0,
-                 uint64_t seed, int2 *order, int32_t *lvl_off, int32_t *nlev)
+                 uint64_t seed, nlmc_ctx::Sched &sc, int ell_mode)
 {
     if (n_orders <= 0) return NLMC_OK;
     LevelizeArgs a{};
@@ -167,9 +190,11 @@ int run_levelize(nlmc_ctx *c, int n_orders, const uint32_t *keys_in, int per_cha
     a.n_sweeps = n_sweeps;
     a.chain_base = c->chain_base;
     a.level_cap = sweep_block(c->n);
-    a.ord2 = order;
-    a.lvl_off = lvl_off;
-    a.nlev = nlev;
+    a.ord2 = sc.order.p;
+    a.lvl_off = sc.lvl_off.p;
+    a.nlev = sc.nlev.p;
+    if (ell_mode == 1) { a.ell32 = sc.ell32.p; a.head32 = sc.head32.p; }
+    if (ell_mode == 2) { a.ellc64 = sc.ellc64.p; a.ellv64 = sc.ellv64.p; a.headh64 = sc.headh64.p; }
     const size_t lds = (size_t)(c->n + 2) * 4 + (size_t)c->n * 2 + 16;
     { int rc = ensure_lds(c, 0, reinterpret_cast<const void *>(k_levelize), lds); if (rc) return rc; }
     hipLaunchKernelGGL(k_levelize, dim3(n_orders), dim3(level_block(c->n)), lds, c->stream, a);
@@ -212,25 +237,25 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
 
     const int per_chain = (stream_mode || order_mode == NLMC_ORDER_PER_CHAIN) ? 1 : 0;
     // plan cache hit?
+    const bool f64 = stream_mode || precision == NLMC_F64;
+    const int ell_mode = stream_mode ? 0 : (f64 ? 2 : 1);
     const bool cached = !stream_mode && c->plan_valid && c->plan_mode == order_mode && c->plan_seed == seed &&
-                        !per_chain && sweep0 >= c->plan_sweep0 &&
+                        c->plan_precision == precision && !per_chain && sweep0 >= c->plan_sweep0 &&
                         (uint64_t)sweep0 + (uint64_t)n_sweeps <= (uint64_t)c->plan_sweep0 + (uint64_t)c->plan_count;
     // window size: keep the schedule scratch under ~256 MiB
     const size_t per_sweep_orders = per_chain ? (size_t)R : 1;
-    const size_t bytes_per_sweep = per_sweep_orders * ((size_t)n * 4 + (size_t)(n + 1) * 4 + 4);
+    const size_t item_bytes = ell_mode == 1 ? 8 + 8 + 8 * NLMC_ELL_W : (ell_mode == 2 ? 8 + 8 + 12 * NLMC_ELL_W : 8);
+    const size_t bytes_per_sweep = per_sweep_orders * ((size_t)n * item_bytes + (size_t)(n + 1) * 4 + 4);
     int W = n_sweeps;
     if (!cached) {
         // stream mode indexes its uniforms/keys by (chain, sweep) over the WHOLE call -> single window there
         if (!stream_mode) W = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_sweeps, ((size_t)256 << 20) / bytes_per_sweep));
         const size_t orders = per_sweep_orders * (size_t)W;
-        HIP_TRY(c, c->order.reserve(orders * n));
-        HIP_TRY(c, c->lvl_off.reserve(orders * (size_t)(n + 1)));
-        HIP_TRY(c, c->nlev.reserve(orders));
+        HIP_TRY(c, c->scratch.reserve(orders, (size_t)n, ell_mode));
     }
 
     const int nt = sweep_block(n);
     // LDS carve-up: spins | flags | uniforms of one sweep (philox) | level offsets (philox) | reduction scratch
-    const bool f64 = stream_mode || precision == NLMC_F64;
     const int lds_flags_off = c->n_pad;
     int cur = c->n_pad * (c->has_flags ? 2 : 1);
     cur = (cur + 15) / 16 * 16;
@@ -251,23 +276,18 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
 
     for (int t0 = 0; t0 < n_sweeps; t0 += W) {
         const int w = std::min(W, n_sweeps - t0);
-        const int2 *ord;
-        const int32_t *off, *nlv;
+        const nlmc_ctx::Sched &sc = cached ? c->plan : c->scratch;
+        size_t o0 = 0;
         hipEvent_t e0 = next_event(c), e1 = next_event(c), e2 = next_event(c);
         if (!e0 || !e1 || !e2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(c, hipEventRecord(e0, c->stream));
         if (cached) {
-            const size_t o0 = (size_t)(sweep0 - c->plan_sweep0) + t0;
-            ord = c->p_order.p + o0 * n;
-            off = c->p_lvl_off.p + o0 * (size_t)(n + 1);
-            nlv = c->p_nlev.p + o0;
+            o0 = (size_t)(sweep0 - c->plan_sweep0) + t0;
         } else {
             const int n_orders = (int)per_sweep_orders * w;
-            int rc = run_levelize(c, n_orders, keys_dev, per_chain, w, sweep0 + (uint32_t)t0, seed, c->order.p,
-                                  c->lvl_off.p, c->nlev.p);
+            int rc = run_levelize(c, n_orders, keys_dev, per_chain, w, sweep0 + (uint32_t)t0, seed, c->scratch, ell_mode);
             if (rc) return rc;
-            ord = c->order.p; off = c->lvl_off.p; nlv = c->nlev.p;
-            c->stats_nlev_ptr = c->nlev.p;
+            c->stats_nlev_ptr = c->scratch.nlev.p;
             c->stats_nlev_count = n_orders;
             c->stats_pending = true;
         }
@@ -279,7 +299,15 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         a.spins = c->spins.p;
         a.flags = c->has_flags ? c->flags.p : nullptr;
         a.temp_x = c->temp_x;
-        a.ord2 = ord; a.lvl_off = off; a.nlev = nlv;
+        a.ord2 = sc.order.p + o0 * n;
+        a.lvl_off = sc.lvl_off.p + o0 * (size_t)(n + 1);
+        a.nlev = sc.nlev.p + o0;
+        if (ell_mode == 1) { a.ell32 = sc.ell32.p + o0 * (size_t)n * NLMC_ELL_W; a.head32 = sc.head32.p + o0 * n; }
+        if (ell_mode == 2) {
+            a.ellc64 = sc.ellc64.p + o0 * (size_t)n * NLMC_ELL_W;
+            a.ellv64 = sc.ellv64.p + o0 * (size_t)n * NLMC_ELL_W;
+            a.headh64 = sc.headh64.p + o0 * n;
+        }
         a.per_chain = per_chain;
         a.n_sweeps = w;
         a.sweep0 = sweep0 + (uint32_t)t0;
@@ -463,8 +491,8 @@ void nlmc_destroy(nlmc_ctx *c)
     c->rowptr.release(); c->col.release(); c->val64.release(); c->h64.release(); c->edge32.release(); c->h32.release();
     c->spins.release(); c->best.release(); c->flags.release(); c->efix.release(); c->emin.release(); c->etrace.release();
     c->argmin.release(); c->energy.release(); c->tab.release(); c->ustream.release(); c->etrace_d.release();
-    c->keys.release(); c->strace.release(); c->cfg.release(); c->order.release(); c->lvl_off.release(); c->nlev.release();
-    c->p_order.release(); c->p_lvl_off.release(); c->p_nlev.release(); c->pt_tab.release(); c->pt_beta.release();
+    c->keys.release(); c->strace.release(); c->cfg.release(); c->scratch.release(); c->plan.release();
+    c->pt_tab.release(); c->pt_beta.release();
     c->slot_of_chain.release(); c->chain_of_slot.release(); c->pt_pairs.release(); c->pt_status.release();
     c->pt_acc.release(); c->icm_label.release(); c->icm_info.release(); c->icm_pairs.release();
     delete c;
@@ -648,22 +676,21 @@ int nlmc_sweep_philox(nlmc_ctx *c, int precision, int order_mode, int n_sweeps, 
                       nullptr, o);
 }
 
-int nlmc_plan_philox(nlmc_ctx *c, int order_mode, uint32_t sweep0, int n_sweeps, uint64_t seed)
+int nlmc_plan_philox(nlmc_ctx *c, int precision, int order_mode, uint32_t sweep0, int n_sweeps, uint64_t seed)
 {
     if (!c) return NLMC_ERR_ARG;
     if (order_mode != NLMC_ORDER_SHARED) return fail(c, NLMC_ERR_UNSUPPORTED, "nlmc_plan_philox: only shared orders are cached");
-    if (n_sweeps < 0) return fail(c, NLMC_ERR_ARG, "nlmc_plan_philox: n_sweeps < 0");
+    if (n_sweeps < 0 || (precision != NLMC_F32 && precision != NLMC_F64)) return fail(c, NLMC_ERR_ARG, "nlmc_plan_philox: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     c->plan_valid = false;
     if (n_sweeps == 0) return NLMC_OK;
-    const size_t n = (size_t)c->n;
-    HIP_TRY(c, c->p_order.reserve((size_t)n_sweeps * n));
-    HIP_TRY(c, c->p_lvl_off.reserve((size_t)n_sweeps * (n + 1)));
-    HIP_TRY(c, c->p_nlev.reserve((size_t)n_sweeps));
-    int rc = run_levelize(c, n_sweeps, nullptr, 0, n_sweeps, sweep0, seed, c->p_order.p, c->p_lvl_off.p, c->p_nlev.p);
+    const int ell_mode = precision == NLMC_F64 ? 2 : 1;
+    HIP_TRY(c, c->plan.reserve((size_t)n_sweeps, (size_t)c->n, ell_mode));
+    int rc = run_levelize(c, n_sweeps, nullptr, 0, n_sweeps, sweep0, seed, c->plan, ell_mode);
     if (rc) return rc;
     c->plan_valid = true;
     c->plan_mode = order_mode;
+    c->plan_precision = precision;
     c->plan_sweep0 = sweep0;
     c->plan_count = n_sweeps;
     c->plan_seed = seed;
@@ -692,7 +719,7 @@ int nlmc_last_schedule_stats(nlmc_ctx *c, int64_t *n_orders, int64_t *n_levels)
 {
     if (!c) return NLMC_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    const int32_t *p = c->stats_pending ? c->stats_nlev_ptr : (c->plan_valid ? c->p_nlev.p : nullptr);
+    const int32_t *p = c->stats_pending ? c->stats_nlev_ptr : (c->plan_valid ? c->plan.nlev.p : nullptr);
     const int64_t cnt = c->stats_pending ? c->stats_nlev_count : (c->plan_valid ? c->plan_count : 0);
     int64_t lv = 0;
     if (p && cnt > 0) {

@@ -40,7 +40,15 @@ struct LevelizeArgs {
     int2 *ord2;           // [n_orders][n]  { k | deg << 16, row start }
     int32_t *lvl_off;     // [n_orders][n+1]
     int32_t *nlev;        // [n_orders]
+    // optional packed per-order schedule in ELL form (slot-major, position-minor) so that the sweep kernel's
+    // loads are fully coalesced: lane i of a level reads slot q at [(o*8+q)*n + i]
+    EdgeF *ell32;         // [n_orders][8][n]  first 8 entries of row k(i), zero-padded (col 0, val 0)
+    int2 *head32;         // [n_orders][n]     { k | deg << 16, bits of (float)h_k }
+    int32_t *ellc64;      // [n_orders][8][n]
+    double *ellv64;       // [n_orders][8][n]
+    double *headh64;      // [n_orders][n]
 };
+#define NLMC_ELL_W 8
 
 __device__ __forceinline__ bool precedes(uint32_t kj, int j, uint32_t kk, int k) { return kj < kk || (kj == kk && j < k); }
 
@@ -137,7 +145,27 @@ __global__ void k_levelize(LevelizeArgs a)
     for (int k = tid; k < n; k += nt) {
         const uint32_t pos = atomicAdd(&cnt[lvl[k]], 1u);
         const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
-        ord[pos] = make_int2(k | (deg << 16), rs);
+        const int kd = k | (deg << 16);
+        ord[pos] = make_int2(kd, rs);
+        if (a.ell32) {
+            a.head32[(size_t)o * n + pos] = make_int2(kd, __float_as_int(a.g.h32[k]));
+#pragma unroll
+            for (int q = 0; q < NLMC_ELL_W; ++q) {
+                EdgeF ed{0, 0.0f};
+                if (q < deg) ed = a.g.edge32[rs + q];
+                a.ell32[((size_t)o * NLMC_ELL_W + q) * n + pos] = ed;
+            }
+        }
+        if (a.ellc64) {
+            a.headh64[(size_t)o * n + pos] = a.g.h64[k];
+#pragma unroll
+            for (int q = 0; q < NLMC_ELL_W; ++q) {
+                int cj = 0; double vj = 0.0;
+                if (q < deg) { cj = a.g.col[rs + q]; vj = a.g.val64[rs + q]; }
+                a.ellc64[((size_t)o * NLMC_ELL_W + q) * n + pos] = cj;
+                a.ellv64[((size_t)o * NLMC_ELL_W + q) * n + pos] = vj;
+            }
+        }
     }
 }
 
@@ -155,6 +183,10 @@ struct SweepArgs {
     // schedule: ord2[o][i] = { k | deg << 16, row start }, lvl_off[o][0..nlev], nlev[o]
     const int2 *ord2;
     const int32_t *lvl_off, *nlev;
+    const EdgeF *ell32;       // packed schedule (philox kernels), see LevelizeArgs
+    const int2 *head32;
+    const int32_t *ellc64;
+    const double *ellv64, *headh64;
     int per_chain;            // order id = c * n_sweeps + t, else t
     int n_sweeps;             // sweeps in this launch
     uint32_t sweep0;          // global index of sweep 0 of this launch
@@ -321,38 +353,54 @@ __global__ void k_sweep_stream(SweepArgs a)
 }
 
 // ---- PHILOX mode (throughput) ---------------------------------------------------------------------------
-template <typename T> struct Pf;            // prefetched first chunk of a CSR row
+template <typename T> struct Pf;            // one schedule item: k, degree, h_k and the first 8 entries of row k
 template <> struct Pf<float> {
-    static constexpr int W = 8;
-    EdgeF ed[W];
+    EdgeF ed[NLMC_ELL_W];
+    int kd;
     float h;
-    __device__ __forceinline__ void load(const CsrDev &g, int k, int rs, int deg)
+    // coalesced: consecutive lanes read consecutive positions of every slot plane
+    __device__ __forceinline__ void load(const SweepArgs &a, size_t oid, int n, int i)
     {
-        // unconditional window [rs, rs+W): one address + W immediate offsets; entries past the row end are
-        // never used (q < deg below) and the device array is padded by W entries, so the reads stay in bounds
-        const EdgeF *__restrict__ p = g.edge32 + rs;
+        const int2 hd = a.head32[oid * n + i];
+        const EdgeF *__restrict__ p = a.ell32 + oid * NLMC_ELL_W * n + i;
 #pragma unroll
-        for (int q = 0; q < W; ++q) ed[q] = p[q];
-        (void)deg;
-        h = g.h32[k];
+        for (int q = 0; q < NLMC_ELL_W; ++q) ed[q] = p[(size_t)q * n];
+        kd = hd.x;
+        h = __int_as_float(hd.y);
+    }
+    // Declare every register of the item dead (no instruction): lets a lane-masked load land directly in these
+    // registers without a merge copy that would wait on the load right after issuing it.
+    __device__ __forceinline__ void kill()
+    {
+#pragma unroll
+        for (int q = 0; q < NLMC_ELL_W; ++q) { asm volatile("" : "=v"(ed[q].col)); asm volatile("" : "=v"(ed[q].val)); }
+        asm volatile("" : "=v"(kd));
+        asm volatile("" : "=v"(h));
     }
     __device__ __forceinline__ int col(int q) const { return ed[q].col; }
     __device__ __forceinline__ float val(int q) const { return ed[q].val; }
     static __device__ __forceinline__ void tail(const CsrDev &g, int e, int &cj, float &vj) { const EdgeF t = g.edge32[e]; cj = t.col; vj = t.val; }
 };
 template <> struct Pf<double> {
-    static constexpr int W = 4;
-    int cj[W];
-    double vj[W];
+    int cj[NLMC_ELL_W];
+    double vj[NLMC_ELL_W];
+    int kd;
     double h;
-    __device__ __forceinline__ void load(const CsrDev &g, int k, int rs, int deg)
+    __device__ __forceinline__ void load(const SweepArgs &a, size_t oid, int n, int i)
     {
-        const int32_t *__restrict__ pc = g.col + rs;
-        const double *__restrict__ pv = g.val64 + rs;
+        const int32_t *__restrict__ pc = a.ellc64 + oid * NLMC_ELL_W * n + i;
+        const double *__restrict__ pv = a.ellv64 + oid * NLMC_ELL_W * n + i;
 #pragma unroll
-        for (int q = 0; q < W; ++q) { cj[q] = pc[q]; vj[q] = pv[q]; }
-        (void)deg;
-        h = g.h64[k];
+        for (int q = 0; q < NLMC_ELL_W; ++q) { cj[q] = pc[(size_t)q * n]; vj[q] = pv[(size_t)q * n]; }
+        kd = a.ord2[oid * n + i].x;
+        h = a.headh64[oid * n + i];
+    }
+    __device__ __forceinline__ void kill()
+    {
+#pragma unroll
+        for (int q = 0; q < NLMC_ELL_W; ++q) { asm volatile("" : "=v"(cj[q])); asm volatile("" : "=v"(vj[q])); }
+        asm volatile("" : "=v"(kd));
+        asm volatile("" : "=v"(h));
     }
     __device__ __forceinline__ int col(int q) const { return cj[q]; }
     __device__ __forceinline__ double val(int q) const { return vj[q]; }
@@ -362,33 +410,34 @@ template <> struct Pf<double> {
 __device__ __forceinline__ float fma_rn(float a, float b, float c) { return __fmaf_rn(a, b, c); }
 __device__ __forceinline__ double fma_rn(double a, double b, double c) { return __fma_rn(a, b, c); }
 
-// Heat-bath update of one spin from a prefetched row.  J*s is exact (s = +-1), so fma(J, s, x) == x + J*s.
+// Heat-bath update of one spin from a prefetched schedule item.  J*s is exact (s = +-1), so fma(J, s, x) == x + J*s;
+// the zero-padded slots add +-0 and leave x unchanged, which keeps the oracle's row-order sum bit for bit.
 template <typename T, bool DIAG>
-__device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, const T *ur, int kd, int rs, const Pf<T> &pf,
+__device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, const T *ur, const Pf<T> &pf, size_t oid, int i,
                                             T cb0, T cb1, double esc)
 {
-    const int k = kd & 0xFFFF, deg = (int)((unsigned)kd >> 16);
+    const int k = pf.kd & 0xFFFF, deg = (int)((unsigned)pf.kd >> 16);
     const unsigned f = x.fl ? (unsigned)x.fl[k] : 0u;
     if (f >= 2u) return;                       // frozen
     int8_t *s = x.s;
+    T sj[NLMC_ELL_W];
+#pragma unroll
+    for (int q = 0; q < NLMC_ELL_W; ++q) sj[q] = (T)s[pf.col(q)];     // all LDS reads in flight together
     T xs = T(0), xd = T(0);
-    // branch-free over the prefetched window: every LDS read is issued up front (window entries past the row end
-    // hold valid column indices of later rows / zero padding), the select keeps the reference summation order
-    T sj[Pf<T>::W];
 #pragma unroll
-    for (int q = 0; q < Pf<T>::W; ++q) sj[q] = (T)s[pf.col(q)];
-#pragma unroll
-    for (int q = 0; q < Pf<T>::W; ++q) {
-        const T nx = fma_rn(pf.val(q), sj[q], xs);
-        xs = (q < deg) ? nx : xs;
+    for (int q = 0; q < NLMC_ELL_W; ++q) {
+        xs = fma_rn(pf.val(q), sj[q], xs);
         if (DIAG) { const T nd = fma_rn(pf.val(q), sj[q], xd); xd = (q < deg && pf.col(q) == k) ? nd : xd; }
     }
-    for (int e = Pf<T>::W; e < deg; ++e) {     // rows longer than the prefetch window
-        int j; T v;
-        Pf<T>::tail(a.g, rs + e, j, v);
-        const T sj = (T)s[j];
-        xs = fma_rn(v, sj, xs);
-        if (DIAG && j == k) xd = fma_rn(v, sj, xd);
+    if (deg > NLMC_ELL_W) {                    // rows longer than the packed window: rest from the CSR arrays
+        const int rs = a.ord2[oid * x.n + i].y;
+        for (int e = NLMC_ELL_W; e < deg; ++e) {
+            int j; T v;
+            Pf<T>::tail(a.g, rs + e, j, v);
+            const T sv = (T)s[j];
+            xs = fma_rn(v, sv, xs);
+            if (DIAG && j == k) xd = fma_rn(v, sv, xd);
+        }
     }
     const T x_true = DIAG ? ((xs - xd) + pf.h) : (xs + pf.h);
     const T xf = xs + pf.h;
@@ -442,7 +491,6 @@ __global__ void k_sweep_philox(SweepArgs a)
 
     for (int t = 0; t < a.n_sweeps; ++t) {
         const int oid = a.per_chain ? (c * a.n_sweeps + t) : t;
-        const int2 *__restrict__ ord = a.ord2 + (size_t)oid * n;
         const int32_t *__restrict__ off = a.lvl_off + (size_t)oid * (n + 1);
         const int nl = a.nlev[oid];
         const T cb0 = (T)a.tab[(size_t)row * a.tab_cs + (size_t)t * a.tab_ss];
@@ -455,44 +503,42 @@ __global__ void k_sweep_philox(SweepArgs a)
         if (fast) for (int l = tid; l <= nl; l += nt) loff[l] = off[l];
         __syncthreads();
 
+        const size_t so = (size_t)oid;
         if (fast) {
-            // software pipeline over levels: while level l is computed, the (k,row) entry of level l+2 and the
-            // CSR row of level l+1 are already in flight -- none of those loads depends on spin values.
-            // The schedule was built with level_cap == blockDim.x: at most one spin per thread and level.
-            // All prefetch loads are unconditional (clamped to valid memory) so that no select or copy ever waits
-            // on a load issued in the same stage; validity comes from the LDS offsets alone.
-            int2 e0, e1, e2;               // raw schedule entries of levels l, l+1, l+2 for this thread
-            bool v0, v1, v2;
-            Pf<T> pfa, pfb;                // ping-pong row windows (manual 2x unroll: no register rotation)
-            auto entry = [&](int l, int2 &en, bool &valid) {
+            // software pipeline over levels: while level l is computed, the schedule items of level l+1 are in
+            // flight.  Their addresses depend only on the level offsets (LDS), never on spin values, and the
+            // schedule was built with level_cap == blockDim.x: at most one spin per thread and level.
+            Pf<T> pfa, pfb;                // ping-pong (manual 2x unroll: no register rotation)
+            bool va, vb;
+            int ia, ib;
+            auto fetch = [&](int l, Pf<T> &p, bool &valid, int &ic) {
                 const int lc = min(l, nl - 1);
                 const int i = loff[lc] + tid;
                 valid = (l < nl) && (i < loff[lc + 1]);
-                en = ord[min(i, n - 1)];
+                ic = valid ? i : 0;        // idle lanes of a busy wave all read item 0 (one extra cache line)
+                // a vector-memory instruction costs the CU's address unit ~16 cycles per wave whatever its lanes
+                // do, so waves without any item in this level skip the loads altogether (wave-uniform branch)
+                if (__ballot(valid) != 0ull) p.load(a, so, n, ic);
             };
-            auto stage = [&](int l, Pf<T> &pc, Pf<T> &pn) {
-                entry(l + 2, e2, v2);                                            // A: level l+2
-                pn.load(a.g, e1.x & 0xFFFF, e1.y, (int)((unsigned)e1.x >> 16));  // B: level l+1
-                if (v0) update_spin<T, DIAG>(a, x, ur, e0.x, e0.y, pc, cb0, cb1, esc);
-                __syncthreads();
-                e0 = e1; v0 = v1; e1 = e2; v1 = v2;
-            };
-            entry(0, e0, v0);
-            entry(1, e1, v1);
-            pfa.load(a.g, e0.x & 0xFFFF, e0.y, (int)((unsigned)e0.x >> 16));
+            fetch(0, pfa, va, ia);
             for (int l = 0; l < nl; l += 2) {
-                stage(l, pfa, pfb);
-                if (l + 1 < nl) stage(l + 1, pfb, pfa);
+                fetch(l + 1, pfb, vb, ib);
+                if (va) update_spin<T, DIAG>(a, x, ur, pfa, so, ia, cb0, cb1, esc);
+                __syncthreads();
+                if (l + 1 < nl) {
+                    fetch(l + 2, pfa, va, ia);
+                    if (vb) update_spin<T, DIAG>(a, x, ur, pfb, so, ib, cb0, cb1, esc);
+                    __syncthreads();
+                }
             }
         } else {
             // very deep schedules (dense graphs): plain level loop
             for (int l = 0; l < nl; ++l) {
                 const int lo = off[l], hi = off[l + 1];
                 for (int i = lo + tid; i < hi; i += nt) {
-                    const int2 en = ord[i];
                     Pf<T> pe;
-                    pe.load(a.g, en.x & 0xFFFF, en.y, (int)((unsigned)en.x >> 16));
-                    update_spin<T, DIAG>(a, x, ur, en.x, en.y, pe, cb0, cb1, esc);
+                    pe.load(a, so, n, i);
+                    update_spin<T, DIAG>(a, x, ur, pe, so, i, cb0, cb1, esc);
                 }
                 __syncthreads();
             }

@@ -167,8 +167,9 @@ class Engine:
                                            _abi.ptr(o["argmin_state"])))
         return o
 
-    def plan_philox(self, sweep0, n_sweeps, seed):
-        self._ck(self._L.nlmc_plan_philox(self._ctx, _abi.ORDER_SHARED, int(sweep0), int(n_sweeps), int(seed)))
+    def plan_philox(self, sweep0, n_sweeps, seed, precision="f32"):
+        prec = {"f32": _abi.F32, "f64": _abi.F64}[precision]
+        self._ck(self._L.nlmc_plan_philox(self._ctx, prec, _abi.ORDER_SHARED, int(sweep0), int(n_sweeps), int(seed)))
 
     # -- replica exchange -------------------------------------------------------------------------------
     def pt_init(self, beta_list):

@@ -164,7 +164,7 @@ def test_philox_results_do_not_depend_on_sharding_or_windows(product):
         with product.Engine(J, h, 4, chain_base=base, n_chains_global=R) as eng:
             eng.set_spins(m0[base:base + 4])
             eng.sweep_philox(4, 1234, sweep0=0, beta=betas[base:base + 4, :4])
-            eng.plan_philox(4, 6, 1234)
+            eng.plan_philox(4, 6, 1234, precision="f32")
             eng.sweep_philox(6, 1234, sweep0=4, beta=betas[base:base + 4, 4:])
             out[base:base + 4] = eng.get_spins()
             assert np.array_equal(eng.energy(), Eref[base:base + 4])
