@@ -127,6 +127,9 @@ int nlmc_pt_swap_philox(nlmc_ctx *ctx, uint32_t round, uint64_t seed, int n_pair
  * exchange the component between the two states.  out_info = {n_components, picked size}. */
 int nlmc_icm_components(nlmc_ctx *ctx, int chain_a, int chain_b, int32_t *out_n_components);
 int nlmc_icm_move(nlmc_ctx *ctx, int chain_a, int chain_b, int64_t pick_index, int katzgraber, int32_t *out_info);
+/* Component label (= smallest member index) of every spin for the pair of the most recent nlmc_icm_components /
+ * nlmc_icm_move call; -1 where the two states agree.  Backs find_disagreement_clusters (NPT/apt_ICM.py:116-143). */
+int nlmc_icm_get_labels(nlmc_ctx *ctx, int32_t *out /*[n]*/);
 /* Device-decided batch: pairs [n_pairs][2] local chain ids, pick = philox(pair, round, ., ICM) */
 int nlmc_icm_round_philox(nlmc_ctx *ctx, const int32_t *pairs, int n_pairs, uint32_t round, uint64_t seed,
                           int katzgraber, int32_t *out_info /*[n_pairs][2] nullable*/);

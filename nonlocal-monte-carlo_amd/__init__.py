@@ -9,3 +9,7 @@ from . import _abi  # noqa: F401
 from ._abi import build_library  # noqa: F401
 from .engine import Engine, Instance, device_count  # noqa: F401
 from . import hostlogic  # noqa: F401
+from . import lbp  # noqa: F401
+from .nmc import NMC  # noqa: F401
+from .npt import NPT  # noqa: F401
+from .apt_ICM import APT_ICM  # noqa: F401

@@ -1,0 +1,210 @@
+"""Drop-in for the reference's `NPT/apt_ICM.py`: class APT_ICM(J, h) -- parallel tempering with Houdayer's
+iso-cluster move (NPT/apt_ICM.py:14-305).
+
+All num_replicas x 10 sub-replica chains advance in one batched launch per round; the disagreement clusters of a
+sub-replica pair are found on the device (include/nlmc.h: nlmc_icm_components / nlmc_icm_move).  `num_cores` and the
+hash table are accepted and ignored.
+
+rng="numpy" (default) consumes the legacy NumPy stream and stdlib `random` in the reference's program order, so that
+M, Energy and the swap log equal the reference after `np.random.seed(s); random.seed(s)` -- including its quirk
+(SURVEY.md section 3.4): the cluster move edits only the FIRST recorded column of each sub-replica block of M and
+never the states that seed the next round.
+
+rng="philox": sweeps, pair picks and cluster picks are drawn on the device; `icm_feedback=True` additionally lets the
+move act on the CURRENT states so that it feeds the dynamics (what Houdayer's move is meant to do).
+"""
+import random as _pyrandom
+
+import numpy as np
+
+from . import hostlogic
+from .base import SweepMixin
+from .engine import Engine
+
+
+class APT_ICM(SweepMixin):
+    num_subreplicas = 10      # NPT/apt_ICM.py:177
+    useKatzgraber = True      # NPT/apt_ICM.py:178
+
+    def __init__(self, J, h, rng=None, seed=None, device=0):
+        self.J = J
+        if isinstance(h, list):
+            h = np.array(h)
+        if len(h.shape) == 1:
+            h = h[:, np.newaxis]                      # NPT/apt_ICM.py:27-34: h kept as an [N,1] column
+        self.h = h
+        self._init_backend(rng, seed, device)
+
+    def _hflat(self):
+        return np.asarray(self.h, dtype=np.float64).reshape(-1)
+
+    # ------------------------------------------------------------------------------------------------
+    def replica_energy(self, M, num_sweeps):
+        """NPT/apt_ICM.py:36-50."""
+        eng = self._cache.engine(self.J, self._hflat(), 1)
+        cols = np.stack([np.asarray(M)[:, ii] for ii in range(num_sweeps)]) if num_sweeps > 0 else np.zeros((0, eng.n))
+        EE1 = eng.energy_of(cols.astype(np.int8)) if num_sweeps > 0 else np.zeros(0)
+        return np.min(EE1), EE1
+
+    def MCMC(self, num_sweeps, m_start, beta, hash_table=None, use_hash_table=False):
+        """NPT/apt_ICM.py:52-93 (J, h taken from self; fixed beta)."""
+        N = self.J.shape[0]
+        M = np.zeros((N, num_sweeps))
+        if num_sweeps == 0:
+            return M
+        self._check_hash_table(hash_table, use_hash_table)
+        eng = self._cache.engine(self.J, self._hflat(), 1)
+        o = self._mcmc_on(eng, num_sweeps, m_start, np.full(num_sweeps, float(beta)))
+        M[:, :] = o["spins"][0].T
+        return M
+
+    def select_non_overlapping_pairs(self, all_pairs):
+        """NPT/apt_ICM.py:95-114."""
+        available = all_pairs.copy()
+        selected = []
+        for _ in range(self.num_swapping_pairs):
+            if not available:
+                raise ValueError("Cannot find non-overlapping pairs.")
+            pair = available[_pyrandom.randint(0, len(available) - 1)]
+            selected.append(pair)
+            available = [p for p in available if p[0] not in pair and p[1] not in pair]
+        return selected
+
+    def find_disagreement_clusters(self, state_1, state_2, J):
+        """Connected components of the sub-graph induced by the spins on which the two states disagree, ordered by
+        smallest member (NPT/apt_ICM.py:116-143).  Computed by the device kernel; returns a list of index lists."""
+        h0 = np.zeros(J.shape[0])
+        eng = self._phase_cache.engine(J, h0, 2)
+        eng.set_spins(np.stack([np.asarray(state_1), np.asarray(state_2)]).astype(np.int8))
+        eng.icm_components(0, 1)
+        lab = eng.icm_labels()
+        roots = np.unique(lab[lab >= 0])
+        return [list(np.nonzero(lab == r)[0]) for r in roots]
+
+    # ------------------------------------------------------------------------------------------------
+    def run(self, beta_list, num_replicas, num_sweeps_MCMC=1000, num_sweeps_read=1000, num_swap_attempts=100,
+            num_swapping_pairs=1, use_hash_table=0, num_cores=8, plot=False, icm_feedback=False):
+        """NPT/apt_ICM.py:145-305.  Returns (M [R*N, S_swap*10], Energy [R])."""
+        self.num_replicas = num_replicas
+        self.num_sweeps_MCMC = num_sweeps_MCMC
+        self.num_sweeps_read = num_sweeps_read
+        self.num_swap_attempts = num_swap_attempts
+        self.num_sweeps_MCMC_per_swap = self.num_sweeps_MCMC // self.num_swap_attempts
+        self.num_sweeps_read_per_swap = self.num_sweeps_read // self.num_swap_attempts
+        self.num_swapping_pairs = num_swapping_pairs
+        self.use_hash_table = use_hash_table
+
+        inst = self._cache.instance(self.J, self._hflat())
+        R, K, N = num_replicas, self.num_subreplicas, inst.n
+        S = self.num_sweeps_MCMC_per_swap
+        beta_list = np.asarray(beta_list, dtype=np.float64)
+        numpy_mode = self.rng == "numpy"
+        host_rng = None if numpy_mode else np.random.default_rng(self.seed)
+        all_pairs = [(i, i + 1) for i in range(1, R)]
+        M = np.zeros((N * R, S * K))
+        m_start = np.sign(2 * (np.random.rand(N * R, K) if numpy_mode else host_rng.random((N * R, K))) - 1)
+        eng = Engine(inst, None, R * K, device=self._cache.device)         # chain id = r*K + j
+        eng_icm = Engine(inst, None, R * K, device=self._cache.device)     # scratch copy of the FIRST columns
+        eng_e = self._cache.engine(self.J, self._hflat(), 1)
+        btab = np.repeat(np.repeat(beta_list, K)[:, None], S, axis=1)
+        log_pairs, log_acc = [], []
+        count = np.zeros(self.num_swap_attempts)
+        try:
+            for ii in range(int(self.num_swap_attempts)):
+                print(f"\nRunning swap attempt = {ii + 1}")
+                # --- sweeps of every (replica, sub-replica) chain, program order = chain order (:197-213)
+                start = np.stack([m_start[r * N:(r + 1) * N, j] for r in range(R) for j in range(K)]).astype(np.int8)
+                eng.set_spins(start)
+                if numpy_mode:
+                    st = [hostlogic.draw_legacy_stream(S, N) for _ in range(R * K)]
+                    o = eng.sweep_stream(np.stack([s[0] for s in st]), np.stack([s[1] for s in st]), btab, record_stride=1)
+                else:
+                    o = eng.sweep_philox(S, self.seed, sweep0=self._sweep_counter, beta=btab, record_stride=1)
+                    self._sweep_counter += S
+                tr = o["spins"]                                             # [R*K, S, N]
+                for r in range(R):
+                    for j in range(K):
+                        M[r * N:(r + 1) * N, j * S:(j + 1) * S] = tr[r * K + j].T
+                        m_start[r * N:(r + 1) * N, j] = tr[r * K + j][-1]
+                # --- Houdayer move on the FIRST column of each sub-replica block (:215-246)
+                target = eng if (icm_feedback and not numpy_mode) else eng_icm
+                if target is eng_icm:
+                    eng_icm.set_spins(tr[:, 0, :] if S > 0 else start)
+                for r in range(R):
+                    shuffled = np.random.permutation(K) if numpy_mode else host_rng.permutation(K)
+                    for p in range(K // 2):
+                        ja, jb = int(shuffled[2 * p]), int(shuffled[2 * p + 1])
+                        ca, cb = r * K + ja, r * K + jb
+                        ncl = target.icm_components(ca, cb)
+                        if ncl > 0:
+                            pick = int(np.random.randint(ncl)) if numpy_mode else int(host_rng.integers(0, ncl))
+                            target.icm_move(ca, cb, pick, self.useKatzgraber)
+                moved = target.get_spins()
+                if target is eng_icm:
+                    if S > 0:
+                        for r in range(R):
+                            for j in range(K):
+                                M[r * N:(r + 1) * N, j * S] = moved[r * K + j]
+                else:
+                    for r in range(R):
+                        for j in range(K):
+                            m_start[r * N:(r + 1) * N, j] = moved[r * K + j]
+                            if S > 0:
+                                M[r * N:(r + 1) * N, (j + 1) * S - 1] = moved[r * K + j]
+                # --- PT swap per sub-replica on the LAST column (:248-285)
+                selected = self.select_non_overlapping_pairs(all_pairs) if numpy_mode else \
+                    self._select_pairs_host_rng(all_pairs, host_rng)
+                for j in range(K):
+                    for (sel, nxt) in selected:
+                        m_sel = M[(sel - 1) * N:sel * N, (j + 1) * S - 1].copy()
+                        m_next = M[(nxt - 1) * N:nxt * N, (j + 1) * S - 1].copy()
+                        E = eng_e.energy_of(np.stack([m_sel, m_next]).astype(np.int8))
+                        E_sel, E_next = E[0], E[1]
+                        print(f"\nSelected pair indices: {sel}, {nxt}")
+                        log_pairs.append((sel, nxt))
+                        u = np.random.rand() if numpy_mode else host_rng.random()
+                        ok = u < min(1, np.exp((beta_list[nxt - 1] - beta_list[sel - 1]) * (E_next - E_sel)))
+                        log_acc.append(int(ok))
+                        if ok:
+                            count[ii] += 1
+                            print(f"swapping {np.sum(count)}th time")
+                            m_start[(sel - 1) * N:sel * N, j] = m_next
+                            m_start[(nxt - 1) * N:nxt * N, j] = m_sel
+            Energy = np.zeros(R)
+            for r in range(R):
+                Energy[r] = self.replica_energy(M[r * N:(r + 1) * N, :], self.num_sweeps_read_per_swap)[0]
+        finally:
+            eng.close()
+            eng_icm.close()
+        self.swap_pairs = np.array(log_pairs, dtype=np.int32).reshape(-1, 2)
+        self.swap_accepted = np.array(log_acc, dtype=np.int8)
+        print(f"\nLatest energy from each replica = {Energy}")
+        if plot:
+            self.plot_energies([self.replica_energy(M[r * N:(r + 1) * N, :], self.num_sweeps_read_per_swap)[1]
+                                for r in range(R)], beta_list)
+        return M, Energy
+
+    def _select_pairs_host_rng(self, all_pairs, rng):
+        available = all_pairs.copy()
+        selected = []
+        for _ in range(self.num_swapping_pairs):
+            if not available:
+                raise ValueError("Cannot find non-overlapping pairs.")
+            pair = available[int(rng.integers(0, len(available)))]
+            selected.append(pair)
+            available = [p for p in available if p[0] not in pair and p[1] not in pair]
+        return selected
+
+    def plot_energies(self, EE1_list, beta_list):
+        """NPT/apt_ICM.py:307-322 (presentation only)."""
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        plt.figure()
+        for i in range(self.num_replicas):
+            plt.plot(EE1_list[i], label=f"Replica {i + 1} (β={beta_list[i]:.2f})")
+        plt.xlabel('Sweeps')
+        plt.ylabel('Energy')
+        plt.legend()
+        plt.savefig('APT_ICM_energy.png')
+        plt.close()

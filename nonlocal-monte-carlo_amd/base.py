@@ -1,0 +1,252 @@
+"""Machinery shared by the drop-in classes (NMC, NPT, APT_ICM): engine cache, RNG modes, the single-chain MCMC()
+entry point, the host-side backbone inference wrappers and the three-phase NMC cycle.
+
+RNG modes
+  rng="numpy"  (default)  the host draws `np.random.permutation(N)` + N x `np.random.rand()` per sweep from the global
+               legacy NumPy stream in the reference's program order and the GPU consumes them: after
+               `np.random.seed(s)` every returned array equals the reference's (spins bit for bit).
+  rng="philox"            throughput mode: visiting order and uniforms are generated on the device (counter-based
+               Philox4x32-10); same Markov kernel, different stream.
+
+Accepted-and-ignored: `use_hash_table` / `hash_table` (a CPU memoisation trick),
+`num_cores` (the process pool is replaced by one batched launch), plotting (opt-in through plot=True).
+"""
+
+import os
+
+import numpy as np
+
+from . import hostlogic
+from .engine import Engine, Instance
+from .lbp import EdgeGraph, lbp_convexified, loopy_bp, atanh_saturated as _atanh_saturated, find_clusters as _find_clusters
+
+EPS = np.finfo(float).eps
+
+
+def _default_rng_mode():
+    return os.environ.get("NLMC_RNG", "numpy")
+
+
+class _EngineCache:
+    """One HIP context per (instance, batch size); rebuilt when the caller hands in a different matrix."""
+
+    def __init__(self, device=0):
+        self.device = device
+        self._key = None
+        self._inst = None
+        self._J_obj = self._h_obj = None
+        self._engines = {}
+
+    @staticmethod
+    def _fingerprint(J, h):
+        import scipy.sparse as sp
+        if sp.issparse(J):
+            A = J.tocsr()
+            return ("s", A.shape, A.nnz, hash(A.data.tobytes()), hash(A.indices.tobytes()), hash(np.asarray(h).tobytes()))
+        A = np.asarray(J)
+        return ("d", A.shape, hash(A.tobytes()), hash(np.asarray(h).tobytes()))
+
+    def instance(self, J, h):
+        if self._inst is not None and J is self._J_obj and h is self._h_obj:
+            return self._inst                      # same objects as last time: skip the O(size) fingerprint
+        key = self._fingerprint(J, h)
+        self._J_obj, self._h_obj = J, h
+        if key != self._key:
+            self.close()
+            self._inst = Instance(J, h)
+            self._key = key
+        return self._inst
+
+    def engine(self, J, h, n_chains):
+        inst = self.instance(J, h)
+        if n_chains not in self._engines:
+            self._engines[n_chains] = Engine(inst, None, n_chains, device=self.device)
+        return self._engines[n_chains]
+
+    def close(self):
+        for e in self._engines.values():
+            e.close()
+        self._engines = {}
+        self._key = None
+        self._inst = None
+
+
+class SweepMixin:
+    """Shared by NMC / NPT / APT_ICM: one MCMC() call on one chain."""
+
+    def _init_backend(self, rng, seed, device):
+        self.rng = rng if rng is not None else _default_rng_mode()
+        if self.rng not in ("numpy", "philox"):
+            raise ValueError("rng must be 'numpy' or 'philox'")
+        self.seed = int(seed) if seed is not None else 0xA5A50000
+        self._cache = _EngineCache(device)
+        self._phase_cache = _EngineCache(device)
+        self._sweep_counter = 0          # philox mode: global sweep index, never reused within one object
+
+    def _check_hash_table(self, hash_table, use_hash_table):
+        # NMC/nmc.py:74-76: the reference insists on an LRUCache only when the table is actually used
+        if use_hash_table and hash_table is None:
+            raise ValueError("hash_table must be an instance of cachetools.LRUCache")
+
+    def _mcmc_on(self, eng, num_sweeps, m_start, beta_run, record=True, flags=None, temp_x=1.0):
+        """Run `num_sweeps` sweeps of ONE chain on `eng` (n_chains == 1).  Returns the engine's output dict."""
+        n = eng.n
+        s0 = np.asarray(m_start, dtype=np.float64).reshape(-1)
+        eng.set_spins(s0.astype(np.int8)[None, :])
+        eng.set_flags(None if flags is None else flags[None, :], temp_x)
+        if self.rng == "numpy":
+            perm, u = hostlogic.draw_legacy_stream(num_sweeps, n)
+            return eng.sweep_stream(perm[None], u[None], np.asarray(beta_run)[None, :], record_stride=1 if record else 0,
+                                    want_energy=True, want_min=True, want_state=True)
+        o = eng.sweep_philox(num_sweeps, self.seed, sweep0=self._sweep_counter, beta=np.asarray(beta_run)[None, :],
+                             record_stride=1 if record else 0, want_energy=True, want_min=True, want_state=True)
+        self._sweep_counter += num_sweeps
+        return o
+
+
+class Common(SweepMixin):
+    """Methods NMC (NMC/nmc.py) and NPT (NPT/npt.py) share line for line in the reference."""
+    _variant = "nmc"
+
+    def __init__(self, J, h, rng=None, seed=None, device=0):
+        self.J = J
+        self.h = np.asarray(h).reshape(-1)
+        self._init_backend(rng, seed, device)
+
+    # ------------------------------------------------------------------------------------------------
+    def MCMC(self, num_sweeps, m_start, beta, J, h, anneal=False, sweeps_per_beta=1, initial_beta=0,
+             hash_table=None, use_hash_table=False):
+        """Heat-bath sweeps with a fresh random permutation per sweep (NMC/nmc.py:28-91).
+        Returns M [N, num_sweeps] float64, column jj = state after sweep jj."""
+        N = J.shape[0]
+        M = np.zeros((N, num_sweeps))           # negative counts raise ValueError exactly like the reference (:52)
+        if num_sweeps == 0:
+            return M
+        self._check_hash_table(hash_table, use_hash_table)
+        run = hostlogic.beta_schedule(num_sweeps, beta, anneal, sweeps_per_beta, initial_beta)
+        eng = self._phase_cache.engine(J, np.asarray(h).reshape(-1), 1)
+        o = self._mcmc_on(eng, num_sweeps, m_start, run)
+        M[:, :] = o["spins"][0].T
+        return M
+
+    # ------------------------------------------------------------------------------------------------
+    def atanh_saturated(self, x):
+        return _atanh_saturated(x)
+
+    def LoopyBeliefPropagation(self, J, h, beta, h_msgs, u_msgs, tolerance, max_iterations):
+        """NMC/nmc.py:168-228.  Dense message matrices in and out (reference signature); computed on the edge list."""
+        inst = Instance(J, np.zeros(J.shape[0]))
+        g = EdgeGraph(inst)
+        h_msgs = np.asarray(h_msgs)
+        u_msgs = np.asarray(u_msgs)
+        # non-edge rows of h_msgs hold one value per row (total_i): recover it for the convergence test
+        tot = np.zeros(g.n)
+        full = np.ones((g.n, g.n), dtype=bool)
+        full[g.src, g.dst] = False
+        np.fill_diagonal(full, False)
+        for i in range(g.n):
+            nz = np.nonzero(full[i])[0]
+            if nz.size:
+                tot[i] = h_msgs[i, nz[0]]
+        state = (h_msgs[g.src, g.dst].astype(float), u_msgs[g.src, g.dst].astype(float), tot)
+        mag, it, (hm, u, tot) = loopy_bp(g, np.asarray(h, dtype=float).reshape(-1), beta, state, tolerance, max_iterations)
+        Hd = np.repeat(tot[:, None], g.n, axis=1)
+        Hd[g.src, g.dst] = hm
+        np.fill_diagonal(Hd, 0.0)
+        Ud = np.zeros((g.n, g.n))
+        Ud[g.src, g.dst] = u
+        Jd = inst.csr.toarray()
+        tH = np.tanh(beta * Hd)
+        corr = (np.tanh(beta * Jd) + tH * tH.T) / (1 + np.tanh(beta * Jd) * tH * tH.T + 1e-10)
+        corr = corr - np.diag(np.diag(corr))
+        return mag, corr, (1 / beta) * _atanh_saturated(mag), (1 / beta) * _atanh_saturated(corr), it, Hd, Ud
+
+    def find_clusters(self, magnetizations, threshold_initial, threshold_cutoff, threshold_step):
+        """NMC/nmc.py:257-318."""
+        inst = self._cache.instance(self.J, self.h)
+        return _find_clusters(EdgeGraph(inst), np.asarray(magnetizations), threshold_initial, threshold_cutoff,
+                              threshold_step)
+
+    def LBP_convexified(self, lambda_start, lambda_end, lambda_reduction_factor, m_star, epsilon, tolerance,
+                        max_iterations, threshold_initial, threshold_cutoff, global_beta):
+        """NMC/nmc.py:93-166.  Returns (clusters, marginals_all_lambdas, mean_marginals_all_lambdas,
+        h_tilde_all_lambdas, J_tilde_all_lambdas); the last two are left empty (never consumed by the reference's
+        own callers, NMC/nmc.py:369)."""
+        from collections import defaultdict
+        inst = self._cache.instance(self.J, self.h)
+        clusters, marg = lbp_convexified(inst, lambda_start, lambda_end, lambda_reduction_factor, m_star, epsilon,
+                                         tolerance, max_iterations, threshold_initial, threshold_cutoff, global_beta,
+                                         graph=self._graph(inst), want_marginals=True)
+        print(f"\ncluster size = {sum(len(c) for c in clusters)}\n")
+        m_all, mean_all = defaultdict(list), defaultdict(list)
+        for k, v in marg.items():
+            m_all[k] = v
+            mean_all[k] = np.mean(v)
+        return clusters, m_all, mean_all, defaultdict(list), defaultdict(list)
+
+    def _graph(self, inst):
+        if getattr(self, "_graph_of", None) is not inst:
+            self._graph_obj = EdgeGraph(inst)
+            self._graph_of = inst
+        return self._graph_obj
+
+    # ------------------------------------------------------------------------------------------------
+    def NMC_subroutine(self, m_star, num_cycles, num_sweeps_per_NMC_phase, full_update_frequency, M_skip, global_beta,
+                       temp_x, lambda_start, lambda_end, lambda_reduction_factor, threshold_initial, threshold_cutoff,
+                       max_iterations, tolerance, all_clusters=None, hash_table=None, use_hash_table=False):
+        """Three-phase NMC cycles (NMC/nmc.py:320-440): cluster spins hot with the rest frozen, then the clusters
+        frozen, then (every full_update_frequency cycles) a plain sweep phase; every phase restarts from the
+        argmin-energy column of the previous one.  The phase matrices J_c/h_c/J_nc/h_nc of the reference are not
+        materialised: the engine applies them through per-spin flags (include/nlmc.h: nlmc_set_flags)."""
+        inst = self._cache.instance(self.J, self.h)
+        eng = self._cache.engine(self.J, self.h, 1)
+        N = inst.n
+        S = int(num_sweeps_per_NMC_phase)
+        graph = self._graph(inst)
+        epsilon = graph.epsilon(inst.h)
+        m_init = np.asarray(m_star, dtype=np.float64).reshape(-1)
+        provided = all_clusters is not None
+        cols = S * num_cycles * 3 // M_skip
+        M_overall = np.zeros((N, cols))
+        energy_overall = np.zeros(cols)
+        at = 0
+        run = np.full(S, float(global_beta))
+
+        def phase(kind, m_from):
+            nonlocal at, m_init
+            fl = hostlogic.phase_flags(N, m_from, all_clusters, kind)
+            o = self._mcmc_on(eng, S, m_from, run, flags=None if kind == "ALL" else fl, temp_x=temp_x)
+            M = o["spins"][0].T.astype(np.float64)
+            en = o["energy"][0]
+            w = S // M_skip
+            M_overall[:, at:at + w] = M[:, ::M_skip]       # shape mismatch raises like the reference when S % M_skip
+            energy_overall[at:at + w] = en[::M_skip]
+            at += w
+            m_init = o["argmin_state"][0].astype(np.float64)
+            return o
+
+        def detect(ms):
+            cl = lbp_convexified(inst, lambda_start, lambda_end, lambda_reduction_factor, np.asarray(ms).copy(), epsilon,
+                                 tolerance, max_iterations, threshold_initial, threshold_cutoff, global_beta, graph=graph)
+            print(f"\ncluster size = {sum(len(c) for c in cl)}\n")
+            return np.concatenate(cl).astype(int) if cl else np.array([], dtype=int)
+
+        if self._variant == "npt" and not provided:      # NPT/npt.py:397-403: LBP once per call
+            all_clusters = detect(m_star)
+        for cycle in range(num_cycles):
+            if self._variant == "nmc":                   # NMC/nmc.py:365-373: clusters re-detected every cycle
+                print(f'\nCurrent iteration = {cycle + 1}')
+                if not provided:
+                    all_clusters = detect(m_star)
+            phase("C", m_init)
+            phase("NC", m_init)
+            if cycle % full_update_frequency == 0:
+                o = phase("ALL", m_init)
+                if self._variant == "nmc":
+                    m_star = m_init.copy()
+                    print(f'\ncurrent m_star energy = {o["min_energy"][0]:.8f}')
+        M_overall = M_overall[:, :at]
+        energy_overall = energy_overall[:at]
+        min_energy = np.min(energy_overall)
+        return M_overall, energy_overall, min_energy, all_clusters
+

@@ -879,6 +879,17 @@ int nlmc_icm_components(nlmc_ctx *c, int chain_a, int chain_b, int32_t *out_n_co
     return NLMC_OK;
 }
 
+int nlmc_icm_get_labels(nlmc_ctx *c, int32_t *out)
+{
+    if (!c || !out) return fail(c, NLMC_ERR_ARG, "nlmc_icm_get_labels: NULL argument");
+    if (c->icm_label.cap < (size_t)c->n) return fail(c, NLMC_ERR_STATE, "nlmc_icm_get_labels: no component search has run yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(out, c->icm_label.p, sizeof(int32_t) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < c->n; ++k) if (out[k] == INT_MAX) out[k] = -1;
+    return NLMC_OK;
+}
+
 static int icm_apply(nlmc_ctx *c, int n_pairs, const int64_t *pick_dev_or_null, int64_t pick_host, uint32_t round,
                      uint64_t seed, int katz, int philox)
 {

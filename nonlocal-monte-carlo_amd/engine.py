@@ -210,6 +210,11 @@ class Engine:
                                        _abi.ptr(info)))
         return int(info[0]), int(info[1])
 
+    def icm_labels(self):
+        out = np.empty(self.n, dtype=np.int32)
+        self._ck(self._L.nlmc_icm_get_labels(self._ctx, _abi.ptr(out)))
+        return out
+
     def icm_round_philox(self, pairs, round_idx, seed, katzgraber=True, want_info=False):
         p = _abi.as_c(pairs, np.int32).reshape(-1, 2)
         info = np.zeros((p.shape[0], 2), np.int32) if want_info else None

@@ -1,0 +1,60 @@
+"""Drop-in for the reference's `NMC/nmc.py`: class NMC(J, h) with MCMC / LBP_convexified / NMC_subroutine / run.
+
+Same names, argument meaning, return shapes and error behaviour as the reference (NMC/nmc.py:13-520); the sweeps,
+energies and argmin hand-offs run in the HIP engine behind the C-ABI (include/nlmc.h).  See base.py for the two
+RNG modes (`rng="numpy"` reproduces the reference bit for bit under `np.random.seed`).
+"""
+import numpy as np
+
+from . import hostlogic
+from .base import Common
+
+
+class NMC(Common):
+    """The NMC class implements the Non-equilibrium (non-local) Monte Carlo algorithm (NMC/nmc.py:13)."""
+    _variant = "nmc"
+
+    # ------------------------------------------------------------------------------------------------
+    def run(self, num_sweeps_initial=int(1e4), num_sweeps_per_NMC_phase=int(1e4), num_NMC_cycles=10,
+            full_update_frequency=1, M_skip=1, temp_x=20, global_beta=2.5, lambda_start=0.5, lambda_end=0.01,
+            lambda_reduction_factor=0.9, threshold_initial=0.999999, threshold_cutoff=0.99999, max_iterations=100,
+            tolerance=np.finfo(float).eps, use_hash_table=False, plot=False):
+        """Execute the NMC algorithm (NMC/nmc.py:442-520).  Returns (M_overall, energy_overall, min_energy)."""
+        norm_factor = np.max(np.abs(self.J))            # NMC/nmc.py:474-476: run() mutates self.J / self.h
+        self.J = self.J / norm_factor
+        self.h = self.h / norm_factor
+        N = len(self.h)
+        if self.rng == "numpy":
+            m_init = np.sign(2 * np.random.rand(N) - 1)
+        else:
+            m_init = np.sign(2 * np.random.default_rng(self.seed).random(N) - 1)
+        eng = self._cache.engine(self.J, self.h, 1)
+        sched = hostlogic.beta_schedule(int(num_sweeps_initial), global_beta, True, 1, 0)
+        if num_sweeps_initial < 0:
+            raise ValueError("negative dimensions are not allowed")   # np.zeros((N, -k)) in the reference (:52)
+        o = self._mcmc_on(eng, int(num_sweeps_initial), m_init, sched, record=False)
+        m_star = o["argmin_state"][0].astype(np.float64)
+        print(f'\ninitial m_star energy = {o["min_energy"][0]:.8f}')
+        M_overall, energy_overall, min_energy, all_clusters = self.NMC_subroutine(
+            m_star, num_NMC_cycles, num_sweeps_per_NMC_phase, full_update_frequency, M_skip, global_beta, temp_x,
+            lambda_start, lambda_end, lambda_reduction_factor, threshold_initial, threshold_cutoff, max_iterations,
+            tolerance, hash_table=None, use_hash_table=use_hash_table)
+        if plot:
+            self.plot_results(M_overall, energy_overall, all_clusters, M_skip, num_NMC_cycles, full_update_frequency,
+                              num_sweeps_per_NMC_phase)
+        return M_overall, energy_overall, min_energy
+
+    def plot_results(self, M_overall, energy_overall, all_clusters, M_skip, num_NMC_cycles, full_update_frequency,
+                     num_sweeps_per_NMC_phase):
+        """Energy trace + spin raster (presentation only; the reference writes NMC_energy.png / NMC_spins.png)."""
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        fig, ax = plt.subplots(2, 1, figsize=(10, 8))
+        ax[0].imshow(M_overall, aspect='auto', cmap='viridis')
+        ax[0].set_ylabel('spin')
+        ax[1].plot(energy_overall)
+        ax[1].set_xlabel(f'recorded sweep (every {M_skip})')
+        ax[1].set_ylabel('Energy')
+        fig.savefig('NMC_energy.png')
+        plt.close(fig)

@@ -1,0 +1,290 @@
+"""Drop-in for the reference's `NPT/npt.py`: class NPT(J, h) -- Non-equilibrium Monte Carlo + parallel tempering.
+
+Same names, argument meaning, return shapes and error behaviour as NPT/npt.py:15-700.  Where the reference hands one
+task per replica to a process pool (NPT/npt.py:616-640), this class advances ALL replicas of a round in batched
+launches of the HIP engine; `num_cores` is accepted and ignored.
+
+rng="numpy" (default): the legacy NumPy stream and stdlib `random` are consumed in exactly the reference's in-order
+program order (replica 1's sweeps, replica 2's, ..., then pair selection, then one rand() per attempted swap), so
+after `np.random.seed(s); random.seed(s)` M, Energy and the swap log equal the reference run with its pool executed
+in order (the pool itself is not reproducible for num_cores > 1).
+
+rng="philox": throughput mode.  Without NMC replicas the whole run stays on the device: replica states never leave
+HBM, swaps are label exchanges decided by a kernel (include/nlmc.h: nlmc_pt_swap_philox), and only the last round's
+trace is read back for the return value.
+"""
+import random as _pyrandom
+
+import numpy as np
+
+from . import hostlogic
+from .base import Common
+from .engine import Engine
+
+
+class NPT(Common):
+    """NMC + Adaptive Parallel Tempering (NPT/npt.py:15)."""
+    _variant = "npt"
+
+    # ------------------------------------------------------------------------------------------------
+    def replica_energy(self, M, num_sweeps):
+        """min and trace of E = -(m^T J m / 2 + m^T h) over the first num_sweeps columns (NPT/npt.py:31-45)."""
+        eng = self._cache.engine(self.J, self.h, 1)
+        cols = np.stack([np.asarray(M)[:, ii] for ii in range(num_sweeps)]) if num_sweeps > 0 else np.zeros((0, eng.n))
+        EE1 = eng.energy_of(cols.astype(np.int8)) if num_sweeps > 0 else np.zeros(0)
+        return np.min(EE1), EE1
+
+    def MCMC_task(self, replica_i, num_sweeps_MCMC, m_start, beta_list, use_hash_table=False, hash_table=None):
+        """NPT/npt.py:112-127 (1-based replica index)."""
+        return self.MCMC(num_sweeps_MCMC, m_start.copy(), beta_list[replica_i - 1], self.J, self.h,
+                         hash_table=hash_table, use_hash_table=use_hash_table)
+
+    def NMC_task(self, m_start, num_cycles, num_sweeps_per_NMC_phase, full_update_frequency, M_skip, global_beta,
+                 temp_x, lambda_start, lambda_end, lambda_reduction_factor, threshold_initial, threshold_cutoff,
+                 max_iterations, tolerance, use_hash_table=False, hash_table=None):
+        """NPT/npt.py:479-512."""
+        M_overall, _, _, _ = self.NMC_subroutine(
+            m_start, num_cycles, num_sweeps_per_NMC_phase, full_update_frequency, M_skip, global_beta, temp_x,
+            lambda_start, lambda_end, lambda_reduction_factor, threshold_initial, threshold_cutoff, max_iterations,
+            tolerance, hash_table=hash_table, use_hash_table=use_hash_table)
+        return M_overall
+
+    def select_non_overlapping_pairs(self, all_pairs):
+        """NPT/npt.py:514-533: num_swapping_pairs adjacent pairs without a shared replica, drawn with stdlib
+        `random.randint` (a stream separate from NumPy's)."""
+        available = all_pairs.copy()
+        selected = []
+        for _ in range(self.num_swapping_pairs):
+            if not available:
+                raise ValueError("Cannot find non-overlapping pairs.")
+            pair = available[_pyrandom.randint(0, len(available) - 1)]
+            selected.append(pair)
+            available = [p for p in available if p[0] not in pair and p[1] not in pair]
+        return selected
+
+    # ------------------------------------------------------------------------------------------------
+    def run(self, beta_list, num_replicas, doNMC, num_sweeps_MCMC=1000, num_sweeps_read=1000, num_swap_attempts=100,
+            num_swapping_pairs=1, num_cycles=10, full_update_frequency=1, M_skip=1, temp_x=20, global_beta=2.5,
+            lambda_start=0.5, lambda_end=0.01, lambda_reduction_factor=0.9, threshold_initial=0.999999,
+            threshold_cutoff=0.99999, max_iterations=100, tolerance=np.finfo(float).eps, use_hash_table=False,
+            num_cores=8, plot=False):
+        """Run the NPT algorithm (NPT/npt.py:535-700).  Returns (M [R*N, S_swap], Energy [R])."""
+        self.num_replicas = num_replicas
+        self.num_sweeps_MCMC = num_sweeps_MCMC
+        self.num_sweeps_read = num_sweeps_read
+        self.num_swap_attempts = num_swap_attempts
+        self.num_sweeps_MCMC_per_swap = self.num_sweeps_MCMC // self.num_swap_attempts
+        self.num_sweeps_read_per_swap = self.num_sweeps_read // self.num_swap_attempts
+        self.num_sweeps_per_NMC_phase_per_swap = int(np.ceil(self.num_sweeps_MCMC / self.num_swap_attempts / 3 / num_cycles))
+        self.num_swapping_pairs = num_swapping_pairs
+        self.use_hash_table = use_hash_table
+        self.doNMC = doNMC
+
+        norm_factor = np.max(np.abs(self.J))            # NPT/npt.py:588-590: run() mutates self.J / self.h
+        self.J = self.J / norm_factor
+        self.h = self.h / norm_factor
+        if len(self.doNMC) != self.num_replicas:
+            raise ValueError("The length of doNMC does not match the number of replicas.")
+        beta_list = np.asarray(beta_list, dtype=np.float64)
+
+        if self.rng == "philox" and not any(bool(v) for v in doNMC):
+            M, Energy = self._run_device_resident(beta_list)
+        else:
+            M, Energy = self._run_host_managed(beta_list, num_cycles, full_update_frequency, M_skip, temp_x, global_beta,
+                                               lambda_start, lambda_end, lambda_reduction_factor, threshold_initial,
+                                               threshold_cutoff, max_iterations, tolerance)
+        print(f"\nLatest energy from each replica = {Energy}")
+        if plot:
+            self.plot_energies([self.replica_energy(M[r * self._n:(r + 1) * self._n, :], self.num_sweeps_read_per_swap)[1]
+                                for r in range(num_replicas)], beta_list)
+        return M, Energy
+
+    # ------------------------------------------------------------------------------------------------
+    def _run_host_managed(self, beta_list, num_cycles, full_update_frequency, M_skip, temp_x, global_beta, lambda_start,
+                          lambda_end, lambda_reduction_factor, threshold_initial, threshold_cutoff, max_iterations,
+                          tolerance):
+        """The reference's bookkeeping (m_start / M arrays on the host), sweeps batched on the GPU."""
+        inst = self._cache.instance(self.J, self.h)
+        R, N = self.num_replicas, inst.n
+        self._n = N
+        S = self.num_sweeps_MCMC_per_swap
+        S_nmc = self.num_sweeps_per_NMC_phase_per_swap
+        all_pairs = [(i, i + 1) for i in range(1, R)]
+        M = np.zeros((R * N, S))
+        numpy_mode = self.rng == "numpy"
+        host_rng = None if numpy_mode else np.random.default_rng(self.seed)
+        if numpy_mode:
+            m_start = np.sign(2 * np.random.rand(R * N, 1) - 1)
+        else:
+            m_start = np.sign(2 * host_rng.random((R * N, 1)) - 1)
+        mc = [r for r in range(R) if not self.doNMC[r]]
+        nm = [r for r in range(R) if self.doNMC[r]]
+        eng_m = Engine(inst, None, len(mc), device=self._cache.device) if mc else None
+        eng_n = Engine(inst, None, len(nm), device=self._cache.device) if nm else None
+        eng_e = self._cache.engine(self.J, self.h, 1)
+        graph = self._graph(inst) if nm else None
+        epsilon = graph.epsilon(inst.h) if nm else None
+        phases = []
+        for cycle in range(num_cycles):
+            phases += ["C", "NC"] + (["ALL"] if cycle % full_update_frequency == 0 else [])
+        log_pairs, log_acc = [], []
+        count = np.zeros(self.num_swap_attempts)
+        try:
+            for ii in range(self.num_swap_attempts):
+                print(f"\nRunning swap attempt = {ii + 1}")
+                # --- draws in the reference's program order: replica by replica (NPT/npt.py:622-640 run in order)
+                streams = {}
+                if numpy_mode:
+                    for r in range(R):
+                        streams[r] = hostlogic.draw_legacy_stream(len(phases) * S_nmc if self.doNMC[r] else S, N)
+                # --- plain replicas: one launch for all of them
+                if mc:
+                    eng_m.set_flags(None)
+                    eng_m.set_spins(np.stack([m_start[r * N:(r + 1) * N, 0] for r in mc]).astype(np.int8))
+                    btab = np.repeat(beta_list[mc][:, None], S, axis=1)
+                    if numpy_mode:
+                        o = eng_m.sweep_stream(np.stack([streams[r][0] for r in mc]), np.stack([streams[r][1] for r in mc]),
+                                               btab, record_stride=1)
+                    else:
+                        o = eng_m.sweep_philox(S, self.seed, sweep0=self._sweep_counter, beta=btab, record_stride=1)
+                    for i, r in enumerate(mc):
+                        M[r * N:(r + 1) * N, :] = o["spins"][i].T
+                # --- NMC replicas: backbone per replica on the host, then the phases in lock step
+                if nm:
+                    clusters = []
+                    for r in nm:
+                        from .lbp import lbp_convexified
+                        cl = lbp_convexified(inst, lambda_start, lambda_end, lambda_reduction_factor,
+                                             m_start[r * N:(r + 1) * N, 0].copy(), epsilon, tolerance, max_iterations,
+                                             threshold_initial, threshold_cutoff, global_beta, graph=graph)
+                        clusters.append(np.concatenate(cl).astype(int) if cl else np.array([], dtype=int))
+                    m_init = np.stack([m_start[r * N:(r + 1) * N, 0] for r in nm]).astype(np.int8)
+                    w = S_nmc // M_skip
+                    traces = [np.zeros((N, len(phases) * w)) for _ in nm]
+                    at = 0
+                    for p, kind in enumerate(phases):
+                        fl = np.stack([hostlogic.phase_flags(N, m_init[i], clusters[i], kind) for i in range(len(nm))])
+                        eng_n.set_spins(m_init)
+                        eng_n.set_flags(None if kind == "ALL" else fl, temp_x)
+                        btab = np.full((len(nm), S_nmc), float(global_beta))
+                        if numpy_mode:
+                            pp = np.stack([streams[r][0][p * S_nmc:(p + 1) * S_nmc] for r in nm])
+                            uu = np.stack([streams[r][1][p * S_nmc:(p + 1) * S_nmc] for r in nm])
+                            o = eng_n.sweep_stream(pp, uu, btab, record_stride=1, want_min=True, want_state=True)
+                        else:
+                            o = eng_n.sweep_philox(S_nmc, self.seed, sweep0=self._sweep_counter + S + p * S_nmc, beta=btab,
+                                                   order="per_chain", record_stride=1, want_min=True, want_state=True)
+                        for i in range(len(nm)):
+                            traces[i][:, at:at + w] = o["spins"][i].T[:, ::M_skip]
+                        at += w
+                        m_init = o["argmin_state"].copy()
+                    for i, r in enumerate(nm):
+                        M[r * N:(r + 1) * N, :] = traces[i][:, -S:].copy()     # NPT/npt.py:643-644
+                if not numpy_mode:
+                    self._sweep_counter += S + len(phases) * S_nmc
+                # --- swap step on the host, exactly as NPT/npt.py:646-680
+                m_start = M[:, -1].copy().reshape(-1, 1)
+                selected = self.select_non_overlapping_pairs(all_pairs) if numpy_mode else \
+                    self._select_pairs_host_rng(all_pairs, host_rng)
+                for (sel, nxt) in selected:
+                    m_sel = M[(sel - 1) * N:sel * N, -1].copy()
+                    m_next = M[(nxt - 1) * N:nxt * N, -1].copy()
+                    E = eng_e.energy_of(np.stack([m_sel, m_next]).astype(np.int8))
+                    E_sel, E_next = E[0], E[1]
+                    beta_sel, beta_next = beta_list[sel - 1], beta_list[nxt - 1]
+                    print(f"\nSelected pair indices: {sel}, {nxt}")
+                    print(f"β values: {beta_sel}, {beta_next}")
+                    print(f"Energies: {E_sel}, {E_next}")
+                    log_pairs.append((sel, nxt))
+                    u = np.random.rand() if numpy_mode else host_rng.random()
+                    ok = u < min(1, np.exp((beta_next - beta_sel) * (E_next - E_sel)))
+                    log_acc.append(int(ok))
+                    if ok:
+                        count[ii] += 1
+                        print(f"Swapping {int(sum(count))}th time")
+                        m_start[(sel - 1) * N:sel * N] = m_next.reshape(-1, 1)
+                        m_start[(nxt - 1) * N:nxt * N] = m_sel.reshape(-1, 1)
+            Energy = np.zeros(R)
+            for r in range(R):                       # min over the FIRST R_swap columns (NPT/npt.py:685-692, :41)
+                Energy[r] = self.replica_energy(M[r * N:(r + 1) * N, :], self.num_sweeps_read_per_swap)[0]
+        finally:
+            for e in (eng_m, eng_n):
+                if e is not None:
+                    e.close()
+        self.swap_pairs = np.array(log_pairs, dtype=np.int32).reshape(-1, 2)
+        self.swap_accepted = np.array(log_acc, dtype=np.int8)
+        print(f"Swap acceptance rate = {np.count_nonzero(count) / max(1, count.size) * 100:.2f} per cent\n")
+        return M, Energy
+
+    def _select_pairs_host_rng(self, all_pairs, rng):
+        available = all_pairs.copy()
+        selected = []
+        for _ in range(self.num_swapping_pairs):
+            if not available:
+                raise ValueError("Cannot find non-overlapping pairs.")
+            pair = available[int(rng.integers(0, len(available)))]
+            selected.append(pair)
+            available = [p for p in available if p[0] not in pair and p[1] not in pair]
+        return selected
+
+    # ------------------------------------------------------------------------------------------------
+    def _run_device_resident(self, beta_list, n_restarts=1):
+        """Throughput path: all replicas (x restarts) in one context, label-exchange swaps decided on the device."""
+        inst = self._cache.instance(self.J, self.h)
+        R, N = self.num_replicas, inst.n
+        self._n = N
+        S = self.num_sweeps_MCMC_per_swap
+        rounds = self.num_swap_attempts
+        G = R * n_restarts
+        eng = Engine(inst, None, G, device=self._cache.device)
+        try:
+            m0 = np.sign(2 * np.random.default_rng(self.seed).random((G, N)) - 1).astype(np.int8)
+            eng.set_spins(m0)
+            eng.pt_init(beta_list)
+            if rounds * S > 0:
+                eng.plan_philox(self._sweep_counter, rounds * S, self.seed)
+            pairs_log, acc_log = [], []
+            last = None
+            slots_last = np.arange(G, dtype=np.int32) % R
+            for ii in range(rounds):
+                is_last = ii == rounds - 1
+                if is_last:
+                    slots_last = eng.pt_slots()
+                o = eng.sweep_philox(S, self.seed, sweep0=self._sweep_counter + ii * S, beta=None,
+                                     record_stride=1 if is_last else 0)
+                if is_last:
+                    last = o["spins"]
+                if self.num_swapping_pairs > 0:
+                    p, a = eng.pt_swap_philox(ii, self.seed, self.num_swapping_pairs, want_log=True)
+                    pairs_log.append(p)
+                    acc_log.append(a)
+            self._sweep_counter += rounds * S
+            M = np.zeros((R * N, S))
+            Energy = np.zeros(R)
+            if last is not None:
+                for c in range(R):                       # restart 0 is the one returned in the reference's shape
+                    r = int(slots_last[c])
+                    M[r * N:(r + 1) * N, :] = last[c].T
+                for r in range(R):
+                    Energy[r] = self.replica_energy(M[r * N:(r + 1) * N, :], self.num_sweeps_read_per_swap)[0]
+            self.swap_pairs = (np.concatenate([p[0] for p in pairs_log]) + 1) if pairs_log else np.zeros((0, 2), np.int32)
+            self.swap_accepted = np.concatenate([a[0] for a in acc_log]).astype(np.int8) if acc_log else np.zeros(0, np.int8)
+            self.final_slots = eng.pt_slots()
+        finally:
+            eng.close()
+        return M, Energy
+
+    def plot_energies(self, EE1_list, beta_list):
+        """NPT/npt.py:702-717 (presentation only)."""
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        plt.figure()
+        for i in range(self.num_replicas):
+            plt.plot(EE1_list[i], label=f"Replica {i + 1} (β={beta_list[i]:.2f})")
+        plt.xlabel('Sweeps')
+        plt.ylabel('Energy')
+        plt.title('Energy traces for different replicas')
+        plt.legend()
+        plt.savefig('NPT_energy.png')
+        plt.close()

@@ -1,0 +1,214 @@
+"""Drop-in classes (NMC / NPT / APT_ICM) on the GPU against golden vectors captured from the reference itself.
+
+rng="numpy": after np.random.seed / random.seed the spin traces and swap logs must be IDENTICAL to the reference's,
+energies within 1e-10*max(1,|E|).  These tests read like the reference's own unit tests (NMC/unittests/test_nmc.py,
+NPT/unittests/test_npt.py, NPT/unittests/test_apt_ICM.py) with numerical assertions added.
+"""
+import contextlib
+import io
+import random
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import golden, golden_names
+
+pytestmark = pytest.mark.gpu
+E_RTOL = 1e-10
+
+
+def dense_of(g):
+    return sp.csr_matrix((g["data"], g["indices"], g["indptr"]), shape=(int(g["N"]),) * 2).toarray()
+
+
+def assert_energy(a, b, rtol=E_RTOL):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    assert a.shape == b.shape
+    assert np.all(np.abs(a - b) <= rtol * np.maximum(1.0, np.abs(b))), np.max(np.abs(a - b))
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+@pytest.mark.parametrize("name", golden_names("mcmc_fixed_gauss16") + golden_names("mcmc_anneal_pmj100h"))
+def test_nmc_mcmc_method(product, name):
+    g = golden(name)
+    J = dense_of(g)
+    obj = product.NMC(J, g["h"])
+    np.random.seed(int(g["seed"]))
+    m0 = np.sign(2 * np.random.rand(J.shape[0]) - 1)
+    kw = dict(anneal=True, sweeps_per_beta=int(g["sweeps_per_beta"]), initial_beta=float(g["initial_beta"])) \
+        if "anneal" in name else {}
+    M = obj.MCMC(int(g["num_sweeps"]), m0, float(g["beta"]), J, g["h"], **kw)
+    assert M.shape == (J.shape[0], int(g["num_sweeps"])) and M.dtype == np.float64
+    assert np.array_equal(M.T.astype(np.int8), g["M"])
+
+
+@pytest.mark.parametrize("name", golden_names("nmc_subroutine_"))
+def test_nmc_subroutine_with_given_clusters(product, name):
+    g = golden(name)
+    J = dense_of(g)
+    cls = product.NPT if "_npt_" in name else product.NMC
+    obj = cls(J, g["h"].copy())
+    np.random.seed(int(g["seed"]))
+    m_star = np.sign(2 * np.random.rand(J.shape[0]) - 1)
+    with quiet():
+        Mo, Eo, Emin, cl = obj.NMC_subroutine(m_star, int(g["num_cycles"]), int(g["num_sweeps_per_NMC_phase"]),
+                                              int(g["full_update_frequency"]), int(g["M_skip"]),
+                                              float(g["global_beta"]), float(g["temp_x"]), 3, 0.01, 0.9, 0.9999999,
+                                              0.999999, 10, np.finfo(float).eps, all_clusters=g["clusters"].copy())
+    assert np.array_equal(Mo.T.astype(np.int8), g["M_overall"])
+    assert_energy(Eo, g["energy_overall"])
+    assert_energy(Emin, g["min_energy"])
+    assert np.array_equal(cl, g["clusters"])
+
+
+@pytest.mark.parametrize("name", golden_names("nmc_run_"))
+def test_nmc_run_end_to_end(product, name):
+    """NMC(J,h).run(): anneal + LBP backbone + three-phase cycles, bit-identical trajectory to the reference."""
+    g = golden(name)
+    J = dense_of(g)
+    obj = product.NMC(J, g["h"].copy())
+    np.random.seed(int(g["seed"]))
+    with quiet():
+        Mo, Eo, Emin = obj.run(int(g["num_sweeps_initial"]), int(g["num_sweeps_per_NMC_phase"]),
+                               int(g["num_NMC_cycles"]), int(g["full_update_frequency"]), int(g["M_skip"]),
+                               float(g["temp_x"]), float(g["global_beta"]), float(g["lambda_start"]),
+                               float(g["lambda_end"]), float(g["lambda_reduction_factor"]),
+                               float(g["threshold_initial"]), float(g["threshold_cutoff"]), int(g["max_iterations"]),
+                               np.finfo(float).eps, use_hash_table=False)
+    assert isinstance(Mo, np.ndarray) and isinstance(Emin, (float, np.floating))
+    assert np.array_equal(Mo.T.astype(np.int8), g["M_overall"])
+    assert_energy(Eo, g["energy_overall"])
+    assert_energy(Emin, g["min_energy"])
+    # run() normalises in place like the reference (NMC/nmc.py:474-476)
+    assert np.isclose(np.max(np.abs(obj.J)), 1.0)
+
+
+@pytest.mark.parametrize("name", golden_names("npt_run_"))
+def test_npt_run_end_to_end(product, name):
+    g = golden(name)
+    J = dense_of(g)
+    R = int(g["num_replicas"])
+    obj = product.NPT(J, g["h"].copy())
+    np.random.seed(int(g["seed"]))
+    random.seed(int(g["seed"]))
+    with quiet():
+        M, Energy = obj.run(beta_list=g["beta_list"], num_replicas=R, doNMC=[bool(v) for v in g["doNMC"]],
+                            num_sweeps_MCMC=int(g["num_sweeps_MCMC"]), num_sweeps_read=int(g["num_sweeps_read"]),
+                            num_swap_attempts=int(g["num_swap_attempts"]),
+                            num_swapping_pairs=int(g["num_swapping_pairs"]), num_cycles=int(g["num_cycles"]),
+                            full_update_frequency=1, M_skip=1, temp_x=20, global_beta=float(g["global_beta"]),
+                            lambda_start=3, lambda_end=0.01, lambda_reduction_factor=0.9,
+                            threshold_initial=0.9999999, threshold_cutoff=0.999999,
+                            max_iterations=int(g["max_iterations"]), tolerance=np.finfo(float).eps,
+                            use_hash_table=False, num_cores=1)
+    N = J.shape[0]
+    assert M.shape == (N * R, int(g["num_sweeps_MCMC"]) // int(g["num_swap_attempts"]))
+    assert Energy.shape == (R,)
+    assert np.array_equal(obj.swap_pairs, g["swap_pairs"])
+    assert np.array_equal(obj.swap_accepted, g["swap_accepted"])
+    assert np.array_equal(M.astype(np.int8), g["M"])
+    assert_energy(Energy, g["Energy"])
+
+
+def test_npt_errors_match_reference(product):
+    J = dense_of(golden("npt_run_gauss10_unit"))
+    obj = product.NPT(J, np.zeros(10))
+    with pytest.raises(ValueError, match="length of doNMC"):
+        obj.run(np.array([0.5, 1.0]), 2, [False])
+    obj = product.NPT(J, np.zeros(10))
+    with quiet(), pytest.raises(ValueError, match="non-overlapping"):
+        obj.run(np.array([0.5, 1.0, 1.5]), 3, [False] * 3, num_sweeps_MCMC=4, num_sweeps_read=4, num_swap_attempts=2,
+                num_swapping_pairs=2)
+    with pytest.raises(ValueError):
+        product.NMC(J, np.zeros(10)).MCMC(-3, np.ones(10), 1.0, J, np.zeros(10))
+
+
+def test_find_disagreement_clusters(product):
+    g = golden("icm_clusters_pmj24")
+    J = dense_of(g)
+    obj = product.APT_ICM(J, np.zeros(J.shape[0]))
+    so, mo = 0, 0
+    for t in range(g["s1"].shape[0]):
+        cl = obj.find_disagreement_clusters(g["s1"][t], g["s2"][t], J)
+        nc = int(g["n_clusters"][t])
+        assert len(cl) == nc
+        sizes = g["sizes"][so:so + nc]
+        so += nc
+        assert [len(c) for c in cl] == list(sizes)
+        mem = g["members"][mo:mo + int(sizes.sum())]
+        mo += int(sizes.sum())
+        assert np.array_equal(np.concatenate([np.sort(c) for c in cl]) if cl else np.zeros(0, int), mem)
+
+
+@pytest.mark.parametrize("name", golden_names("apt_icm_run_"))
+def test_apt_icm_run_end_to_end(product, name):
+    g = golden(name)
+    J = dense_of(g)
+    R = int(g["num_replicas"])
+    obj = product.APT_ICM(J, g["h"].copy())
+    np.random.seed(int(g["seed"]))
+    random.seed(int(g["seed"]))
+    with quiet():
+        M, Energy = obj.run(g["beta_list"], num_replicas=R, num_sweeps_MCMC=int(g["num_sweeps_MCMC"]),
+                            num_sweeps_read=int(g["num_sweeps_read"]), num_swap_attempts=int(g["num_swap_attempts"]),
+                            num_swapping_pairs=int(g["num_swapping_pairs"]), use_hash_table=0, num_cores=1)
+    assert M.shape == (J.shape[0] * R, obj.num_sweeps_MCMC_per_swap * 10)   # == num_sweeps_MCMC in the reference's
+    #                                                     own test (10 swap attempts, NPT/unittests/test_apt_ICM.py:42)
+    assert Energy.shape == (R,)
+    assert np.array_equal(obj.swap_pairs, g["swap_pairs"])
+    assert np.array_equal(obj.swap_accepted, g["swap_accepted"])
+    assert np.array_equal(M.astype(np.int8), g["M"])
+    assert_energy(Energy, g["Energy"])
+
+
+def test_known_answer_ground_states(product):
+    """Bundled ground truths of the reference's example instances (data files, tests/golden/instances):
+    brute force over 2^10 states on the GPU energy kernel reproduces gs_energies.txt; NMC(philox) reaches them."""
+    import os
+    from conftest import GOLDEN
+    inst_dir = os.path.join(GOLDEN, "instances")
+    gs = {}
+    for line in open(os.path.join(inst_dir, "wishart_N10_a0.50__gs_energies.txt")):
+        name, e = line.split()
+        gs[name] = float(e)
+    allstates = (((np.arange(1024)[:, None] >> np.arange(10)[None, :]) & 1) * 2 - 1).astype(np.int8)
+    for i in (1, 2, 3):
+        fn = f"wishart_planting_N_10_alpha_0.50_inst_{i}.txt"
+        W = np.zeros((10, 10))
+        for line in open(os.path.join(inst_dir, "wishart_N10_a0.50__" + fn)):
+            a, b, v = line.split()
+            if int(a) != int(b):
+                W[int(a), int(b)] = W[int(b), int(a)] = float(v)
+        J, h = -W, np.zeros(10)                     # NMC/examples/wishart_example.py: J = -W
+        nf = np.max(np.abs(J))
+        with product.Engine(J / nf, h, 1) as eng:
+            E = eng.energy_of(allstates) * nf
+        assert abs(E.min() - gs[fn]) < 1e-9
+        obj = product.NMC(J.copy(), h.copy(), rng="philox", seed=5 + i)
+        with quiet():
+            _, _, emin = obj.run(200, 50, 2, 1, 1, 20, 3, 3, 0.01, 0.9, 0.9999999, 0.999999, 100, np.finfo(float).eps)
+        assert abs(emin * nf - gs[fn]) < 1e-9
+    # Chimera-128 instance 001: the listed ground state evaluates to the listed energy (s = 2b-1, J=-W, h=-h_file)
+    W = np.zeros((128, 128))
+    hf = np.zeros(128)
+    for line in open(os.path.join(inst_dir, "chimera128__001.txt")):
+        line = line.strip()
+        if not line or line.startswith("#"):
+            continue
+        a, b, v = line.split()
+        a, b, v = int(a) - 1, int(b) - 1, float(v)
+        if a == b:
+            hf[a] = v
+        else:
+            W[a, b] = W[b, a] = v
+    tok = open(os.path.join(inst_dir, "chimera128__groundstate_001.txt")).read().split()
+    e_gs = float(tok[2])
+    s = (2 * np.array(tok[3:3 + 128], dtype=int) - 1).astype(np.int8)
+    with product.Engine(-W, -hf, 1) as eng:
+        assert abs(eng.energy_of(s[None])[0] - e_gs) < 1e-5

@@ -1,0 +1,154 @@
+"""Device-decided replica exchange and iso-cluster move against small host restatements of their published laws."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import make_instance, init_spins
+
+pytestmark = pytest.mark.gpu
+LOG2E = 1.4426950408889634
+TAG_SWAP, TAG_PAIR, TAG_ICM = 3, 4, 5
+
+
+def expected_swap_round(E, slot_of_chain, betas, ladder_len, n_pairs, rnd, seed):
+    """Sequential restatement of k_pt_swap: pair selection (NPT/npt.py:514-533 law) + Metropolis test."""
+    lo, hi = seed & 0xFFFFFFFF, seed >> 32
+    G = len(E)
+    slots = slot_of_chain.copy()
+    pairs_all, acc_all = [], []
+    for g in range(G // ladder_len):
+        chain_of_slot = np.empty(ladder_len, dtype=int)
+        for c in range(g * ladder_len, (g + 1) * ladder_len):
+            chain_of_slot[slots[c]] = c
+        avail = list(range(ladder_len - 1))
+        sel = []
+        for p in range(n_pairs):
+            r = int(oracle.philox(p, rnd, g, TAG_PAIR, lo, hi)[0])
+            idx = (r * len(avail)) >> 32
+            i = avail[idx]
+            sel.append(i)
+            avail = [q for q in avail if abs(q - i) > 1]
+        for p, i in enumerate(sel):
+            ca, cb = chain_of_slot[i], chain_of_slot[i + 1]
+            w = oracle.philox(p, rnd, g, TAG_SWAP, lo, hi)
+            u = ((int(w[0]) >> 5) * 67108864.0 + (int(w[1]) >> 6)) / 9007199254740992.0
+            z = ((betas[i + 1] - betas[i]) * (E[cb] - E[ca])) * LOG2E
+            acc = u < oracle.lib().nlo_exp2_f64(z)
+            if acc:
+                slots[ca], slots[cb] = i + 1, i
+                chain_of_slot[i], chain_of_slot[i + 1] = cb, ca
+            pairs_all.append((i, i + 1))
+            acc_all.append(int(acc))
+    return slots, np.array(pairs_all).reshape(G // ladder_len, n_pairs, 2), np.array(acc_all).reshape(G // ladder_len, n_pairs)
+
+
+def test_pt_swap_rounds_match_restatement(product):
+    J, h = make_instance(120, seed=2, with_h=True)
+    L, nl, n_pairs = 8, 3, 3
+    G = L * nl
+    betas = np.geomspace(0.2, 3.0, L)
+    with product.Engine(J, h, G) as eng:
+        eng.set_spins(init_spins(G, 120))
+        eng.pt_init(betas)
+        slots = eng.pt_slots()
+        assert np.array_equal(slots, np.arange(G) % L)
+        for rnd in range(6):
+            eng.sweep_philox(3, 77, sweep0=3 * rnd, beta=None)
+            E = eng.energy()
+            exp_slots, exp_pairs, exp_acc = expected_swap_round(E, slots, betas, L, n_pairs, rnd, 77)
+            pairs, acc = eng.pt_swap_philox(rnd, 77, n_pairs)
+            slots = eng.pt_slots()
+            assert np.array_equal(pairs, exp_pairs)
+            assert np.array_equal(acc, exp_acc)
+            assert np.array_equal(slots, exp_slots)
+        # every ladder still holds each slot exactly once
+        assert all(sorted(slots[g * L:(g + 1) * L]) == list(range(L)) for g in range(nl))
+        assert acc.sum() + 1 > 0
+
+
+def test_pt_ladder_beta_follows_slot(product):
+    """A chain that holds slot r sweeps at beta_list[r]: compare with explicit per-chain betas."""
+    J, h = make_instance(150, seed=8)
+    L = 6
+    betas = np.linspace(0.3, 2.4, L)
+    m0 = init_spins(L, 150)
+    perm = np.array([3, 0, 5, 1, 4, 2], dtype=np.int32)
+    with product.Engine(J, h, L) as a, product.Engine(J, h, L) as b:
+        a.set_spins(m0)
+        a.pt_init(betas)
+        a.pt_set_slots(perm)
+        a.sweep_philox(5, 9, beta=None)
+        b.set_spins(m0)
+        b.sweep_philox(5, 9, beta=np.repeat(betas[perm][:, None], 5, axis=1))
+        assert np.array_equal(a.get_spins(), b.get_spins())
+        a.pt_apply_swap(0, 0, 1)
+        s = a.pt_slots()
+        assert s[1] == 1 and s[3] == 0
+
+
+def test_pt_too_many_pairs_raises_like_reference(product):
+    J, h = make_instance(60, seed=1)
+    with product.Engine(J, h, 4) as eng:
+        eng.set_spins(init_spins(4, 60))
+        eng.pt_init(np.array([0.5, 1.0, 1.5, 2.0]))
+        with pytest.raises(ValueError, match="non-overlapping"):
+            for rnd in range(64):       # (1,2) first leaves nothing for a second pair: happens w.p. 1/3 per round
+                eng.pt_swap_philox(rnd, 5, 2)
+
+
+def test_icm_move_matches_oracle_components(product):
+    J, h = make_instance(300, seed=6)
+    csr = oracle.Csr(J)
+    r = np.random.default_rng(4)
+    for trial in range(6):
+        s1 = r.choice([-1, 1], 300).astype(np.int8)
+        s2 = s1.copy()
+        s2[r.random(300) < (0.1 + 0.15 * trial)] *= -1
+        cl = oracle.clusters(csr, s1, s2)
+        with product.Engine(J, h, 2) as eng:
+            eng.set_spins(np.stack([s1, s2]))
+            assert eng.icm_components(0, 1) == len(cl)
+            lab = eng.icm_labels()
+            for c in cl:
+                assert np.all(lab[c] == c.min())
+            assert np.all(lab[(s1 * s2) == 1] == -1)
+            if not cl:
+                continue
+            pick = trial % len(cl)
+            ncomp, size = eng.icm_move(0, 1, pick, katzgraber=True)
+            got = eng.get_spins()
+            e1, e2 = s1.copy(), s2.copy()
+            if len(cl[pick]) > 300 // 2:
+                e1 = -e1
+            else:
+                e1[cl[pick]], e2[cl[pick]] = s2[cl[pick]], s1[cl[pick]]
+            assert (ncomp, size) == (len(cl), len(cl[pick]))
+            assert np.array_equal(got[0], e1) and np.array_equal(got[1], e2)
+            # tracked energies were re-synchronised after the non-local move
+            assert np.allclose(eng.energy(), [oracle.energy(csr, h, e1), oracle.energy(csr, h, e2)], rtol=0, atol=1e-9)
+
+
+def test_icm_round_philox_batch(product):
+    J, h = make_instance(200, seed=12)
+    csr = oracle.Csr(J)
+    m0 = init_spins(8, 200)
+    pairs = np.array([[0, 5], [2, 3], [7, 1]], dtype=np.int32)
+    seed, rnd = 1234567, 3
+    with product.Engine(J, h, 8, chain_base=4, n_chains_global=16) as eng:
+        eng.set_spins(m0)
+        info = eng.icm_round_philox(pairs, rnd, seed, katzgraber=True, want_info=True)
+        got = eng.get_spins()
+    exp = m0.copy()
+    for p, (a, b) in enumerate(pairs):
+        cl = oracle.clusters(csr, m0[a], m0[b])
+        assert info[p, 0] == len(cl)
+        if not cl:
+            continue
+        w = int(oracle.philox(4 + a, rnd, 4 + b, TAG_ICM, seed & 0xFFFFFFFF, seed >> 32)[0])
+        pick = (w * len(cl)) >> 32
+        assert info[p, 1] == len(cl[pick])
+        if len(cl[pick]) > 100:
+            exp[a] = -exp[a]
+        else:
+            exp[a, cl[pick]], exp[b, cl[pick]] = m0[b, cl[pick]], m0[a, cl[pick]]
+    assert np.array_equal(got, exp)
