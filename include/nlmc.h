@@ -136,6 +136,10 @@ int nlmc_icm_round_philox(nlmc_ctx *ctx, const int32_t *pairs, int n_pairs, uint
 
 /* Timing of the most recent sweep call, measured with HIP events on the context's stream. */
 int nlmc_last_timing(nlmc_ctx *ctx, float *ms_levelize, float *ms_sweep, int32_t *launches_sweep);
+/* Accumulated HIP-event timing of every sweep call since nlmc_timing_reset (one synchronisation, at read time).
+ * While accumulation is on, sweep calls do not recycle their events. */
+int nlmc_timing_reset(nlmc_ctx *ctx, int enable);
+int nlmc_timing_total(nlmc_ctx *ctx, double *ms_levelize, double *ms_sweep, int64_t *launches_sweep);
 /* Level-schedule statistics of the most recent sweep call: total levels and total spins over its orders. */
 int nlmc_last_schedule_stats(nlmc_ctx *ctx, int64_t *n_orders, int64_t *n_levels);
 

@@ -13,3 +13,4 @@ from . import lbp  # noqa: F401
 from .nmc import NMC  # noqa: F401
 from .npt import NPT  # noqa: F401
 from .apt_ICM import APT_ICM  # noqa: F401
+from . import distributed  # noqa: F401

@@ -24,7 +24,7 @@ EXPORTS = [
     "nlmc_get_spins", "nlmc_set_flags", "nlmc_energy", "nlmc_energy_dev", "nlmc_energy_scale", "nlmc_energy_of", "nlmc_sweep_stream",
     "nlmc_sweep_philox", "nlmc_plan_philox", "nlmc_pt_init", "nlmc_pt_get_slots", "nlmc_pt_set_slots",
     "nlmc_pt_apply_swap", "nlmc_pt_swap_philox", "nlmc_icm_components", "nlmc_icm_move", "nlmc_icm_get_labels", "nlmc_icm_round_philox",
-    "nlmc_last_timing", "nlmc_last_schedule_stats",
+    "nlmc_last_timing", "nlmc_timing_reset", "nlmc_timing_total", "nlmc_last_schedule_stats",
 ]
 
 
@@ -102,6 +102,10 @@ def lib():
     L.nlmc_icm_round_philox.argtypes = [_vp, _vp, _i, _u32, _u64, _i, _vp]
     L.nlmc_last_timing.restype = _i
     L.nlmc_last_timing.argtypes = [_vp, _vp, _vp, _vp]
+    L.nlmc_timing_reset.restype = _i
+    L.nlmc_timing_reset.argtypes = [_vp, _i]
+    L.nlmc_timing_total.restype = _i
+    L.nlmc_timing_total.argtypes = [_vp, _vp, _vp, _vp]
     L.nlmc_last_schedule_stats.restype = _i
     L.nlmc_last_schedule_stats.argtypes = [_vp, _vp, _vp]
     _lib = L

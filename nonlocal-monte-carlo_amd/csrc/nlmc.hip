@@ -89,6 +89,8 @@ struct nlmc_ctx {
     uint64_t plan_seed = 0;
     // PT
     int ladder_len = 0;
+    bool pt_tab_valid = false;
+    double pt_tab_temp_x = 1.0;
     std::vector<double> beta_list;
     DevBuf<double> pt_tab, pt_beta;
     DevBuf<int32_t> slot_of_chain, chain_of_slot, pt_pairs, pt_status;
@@ -97,7 +99,9 @@ struct nlmc_ctx {
     DevBuf<int32_t> icm_label, icm_info, icm_pairs;
     // timing / stats
     std::vector<hipEvent_t> events;
-    size_t ev_used = 0;
+    size_t ev_used = 0, ev_call_start = 0;
+    bool ev_accumulate = false;
+    long long launches_total = 0;
     int launches_sweep = 0;
     int64_t stat_orders = 0, stat_levels = 0;
     bool stats_pending = false;
@@ -217,7 +221,8 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
                const double *ustream_dev, const SweepOut &o)
 {
     const int R = c->n_chains, n = c->n;
-    c->ev_used = 0;
+    if (!c->ev_accumulate) c->ev_used = 0;
+    c->ev_call_start = c->ev_used;
     c->launches_sweep = 0;
     c->stat_orders = 0;
     c->stat_levels = 0;
@@ -340,6 +345,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(e2, c->stream));
         c->launches_sweep++;
+        c->launches_total++;
     }
 
     // read-out
@@ -659,14 +665,18 @@ int nlmc_sweep_philox(nlmc_ctx *c, int precision, int order_mode, int n_sweeps, 
         tcs = chain_stride ? T * 2 : 0;
         tss = sweep_stride ? 2 : 0;
     } else {
-        // ladder table refreshed here so that a temp_x change after nlmc_pt_init is honoured
-        std::vector<double> tab((size_t)c->ladder_len * 2);
-        for (int r = 0; r < c->ladder_len; ++r) {
-            tab[2 * r + 0] = -2.0 * LOG2E * c->beta_list[r];
-            tab[2 * r + 1] = -2.0 * LOG2E * (c->beta_list[r] / c->temp_x);
+        // ladder table re-uploaded only when temp_x changed since the last upload (no host sync on the hot path)
+        if (!c->pt_tab_valid || c->pt_tab_temp_x != c->temp_x) {
+            std::vector<double> tab((size_t)c->ladder_len * 2);
+            for (int r = 0; r < c->ladder_len; ++r) {
+                tab[2 * r + 0] = -2.0 * LOG2E * c->beta_list[r];
+                tab[2 * r + 1] = -2.0 * LOG2E * (c->beta_list[r] / c->temp_x);
+            }
+            HIP_TRY(c, hipMemcpyAsync(c->pt_tab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->pt_tab_valid = true;
+            c->pt_tab_temp_x = c->temp_x;
         }
-        HIP_TRY(c, hipMemcpyAsync(c->pt_tab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
         tab_dev = c->pt_tab.p;
         tcs = 2; tss = 0;
         use_slots = true;
@@ -702,7 +712,7 @@ int nlmc_last_timing(nlmc_ctx *c, float *ms_levelize, float *ms_sweep, int32_t *
     if (!c) return NLMC_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     float lev = 0.f, sw = 0.f;
-    for (size_t i = 0; i + 2 < c->ev_used + 1 && i + 2 < c->events.size() + 1 && i + 3 <= c->ev_used; i += 3) {
+    for (size_t i = c->ev_call_start; i + 3 <= c->ev_used; i += 3) {
         HIP_TRY(c, hipEventSynchronize(c->events[i + 2]));
         float a = 0.f, b = 0.f;
         HIP_TRY(c, hipEventElapsedTime(&a, c->events[i], c->events[i + 1]));
@@ -712,6 +722,34 @@ int nlmc_last_timing(nlmc_ctx *c, float *ms_levelize, float *ms_sweep, int32_t *
     if (ms_levelize) *ms_levelize = lev;
     if (ms_sweep) *ms_sweep = sw;
     if (launches_sweep) *launches_sweep = c->launches_sweep;
+    return NLMC_OK;
+}
+
+int nlmc_timing_reset(nlmc_ctx *c, int enable)
+{
+    if (!c) return NLMC_ERR_ARG;
+    c->ev_used = 0;
+    c->ev_call_start = 0;
+    c->launches_total = 0;
+    c->ev_accumulate = enable != 0;
+    return NLMC_OK;
+}
+
+int nlmc_timing_total(nlmc_ctx *c, double *ms_levelize, double *ms_sweep, int64_t *launches_sweep)
+{
+    if (!c) return NLMC_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    double lev = 0.0, sw = 0.0;
+    for (size_t i = 0; i + 3 <= c->ev_used; i += 3) {
+        HIP_TRY(c, hipEventSynchronize(c->events[i + 2]));
+        float a = 0.f, b = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&a, c->events[i], c->events[i + 1]));
+        HIP_TRY(c, hipEventElapsedTime(&b, c->events[i + 1], c->events[i + 2]));
+        lev += a; sw += b;
+    }
+    if (ms_levelize) *ms_levelize = lev;
+    if (ms_sweep) *ms_sweep = sw;
+    if (launches_sweep) *launches_sweep = c->launches_total;
     return NLMC_OK;
 }
 
@@ -741,6 +779,7 @@ int nlmc_pt_init(nlmc_ctx *c, int ladder_len, const double *beta_list)
     if (c->n_chains_global % ladder_len != 0) return fail(c, NLMC_ERR_ARG, "nlmc_pt_init: n_chains_global not a multiple of ladder_len");
     HIP_TRY(c, hipSetDevice(c->device));
     c->ladder_len = ladder_len;
+    c->pt_tab_valid = false;
     c->beta_list.assign(beta_list, beta_list + ladder_len);
     const int G = c->n_chains_global;
     HIP_TRY(c, c->pt_tab.reserve((size_t)ladder_len * 2));

@@ -1,0 +1,79 @@
+"""Replica-sharded parallel tempering across the GPUs of one node: one process per GPU (`torch.distributed`,
+backend "nccl" = RCCL over xGMI; "gloo" for CPU rehearsal with an injected engine).
+
+Sharding: the global set of chains is cut into contiguous blocks, one per rank; a swap round
+needs only the scalar energies, so the single collective is ONE all-gather of `n_local` float64 per rank and round.
+Every rank then evaluates the identical Philox-keyed swap decision on the full energy vector and updates its replica of
+the (tiny) slot table -- swaps are label exchanges, no configuration ever crosses a link.  Because every random
+number is a pure function of (seed, global chain id, sweep, spin), the trajectory is bit-identical for any number
+of ranks.
+"""
+import numpy as np
+
+
+def block_partition(n_global, world, rank):
+    """Contiguous block of chains owned by `rank` (first `n_global % world` ranks get one extra)."""
+    q, r = divmod(int(n_global), int(world))
+    count = q + (1 if rank < r else 0)
+    base = rank * q + min(rank, r)
+    return base, count
+
+
+class ShardedTempering:
+    """Drives sweep rounds + swap rounds of a sharded ladder set.
+
+    make_engine(inst, n_chains, chain_base, n_chains_global) -> object with the Engine interface used below;
+    `dist` is torch.distributed (already initialised) or None for a single process; `torch` the torch module."""
+
+    def __init__(self, make_engine, inst, beta_list, n_chains_global, seed, n_pairs, torch=None, dist=None,
+                 device=None, precision="f32"):
+        self.torch, self.dist = torch, dist
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.G = int(n_chains_global)
+        self.base, self.count = block_partition(self.G, self.world, self.rank)
+        if self.G % self.world != 0 and self.world > 1:
+            raise ValueError("all_gather_into_tensor needs equal shards: n_chains_global % world_size != 0")
+        self.seed, self.n_pairs, self.precision = int(seed), int(n_pairs), precision
+        self.eng = make_engine(inst, self.count, self.base, self.G)
+        self.eng.pt_init(np.asarray(beta_list, dtype=np.float64))
+        self.sweeps_done = 0
+        self.rounds_done = 0
+        if self.world > 1:
+            self.e_local = torch.empty(self.count, dtype=torch.float64, device=device)
+            self.e_all = torch.empty(self.G, dtype=torch.float64, device=device)
+
+    def set_spins(self, spins_global):
+        self.eng.set_spins(np.asarray(spins_global)[self.base:self.base + self.count])
+
+    def plan(self, n_sweeps):
+        self.eng.plan_philox(self.sweeps_done, n_sweeps, self.seed, precision=self.precision)
+
+    def round(self, n_sweeps, want_log=False):
+        """`n_sweeps` sweeps of every local chain at its ladder temperature, then one swap attempt round."""
+        self.eng.sweep_philox(n_sweeps, self.seed, sweep0=self.sweeps_done, beta=None, precision=self.precision)
+        self.sweeps_done += n_sweeps
+        log = None
+        if self.n_pairs > 0:
+            if self.world > 1:
+                self.eng.energy_dev(self.e_local.data_ptr())           # tracked energies -> device/host buffer
+                self.dist.all_gather_into_tensor(self.e_all, self.e_local)   # the ONE collective of the round
+                log = self.eng.pt_swap_philox(self.rounds_done, self.seed, self.n_pairs,
+                                              energies_all_dev=self.e_all.data_ptr(), want_log=want_log)
+            else:
+                log = self.eng.pt_swap_philox(self.rounds_done, self.seed, self.n_pairs, want_log=want_log)
+        self.rounds_done += 1
+        return log
+
+    def gather_spins(self):
+        """All chains' configurations on every rank (read-out only; not part of a round)."""
+        loc = self.eng.get_spins()
+        if self.world == 1:
+            return loc
+        t = self.torch.from_numpy(loc.astype(np.int8)).to(self.e_all.device)
+        out = self.torch.empty((self.G, loc.shape[1]), dtype=self.torch.int8, device=self.e_all.device)
+        self.dist.all_gather_into_tensor(out, t)
+        return out.cpu().numpy()
+
+    def close(self):
+        self.eng.close()

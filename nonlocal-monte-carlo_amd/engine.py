@@ -228,6 +228,14 @@ class Engine:
         self._ck(self._L.nlmc_last_timing(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return {"ms_levelize": a.value, "ms_sweep": b.value, "launches_sweep": c.value}
 
+    def timing_reset(self, enable=True):
+        self._ck(self._L.nlmc_timing_reset(self._ctx, int(bool(enable))))
+
+    def timing_total(self):
+        a, b, c = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
+        self._ck(self._L.nlmc_timing_total(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"ms_levelize": a.value, "ms_sweep": b.value, "launches_sweep": c.value}
+
     def last_schedule_stats(self):
         a, b = ctypes.c_int64(0), ctypes.c_int64(0)
         self._ck(self._L.nlmc_last_schedule_stats(self._ctx, ctypes.byref(a), ctypes.byref(b)))

@@ -1,0 +1,61 @@
+"""No GPU needed: the C-ABI shared object loads and exports every symbol include/nlmc.h declares; compute entry
+points fail loudly (no CPU fallback) when no HIP device is visible; the product never imports the oracle."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO, load_product
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "nlmc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nlmc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    P = load_product()
+    L = P._abi.lib()
+    decl = declared_symbols()
+    assert len(decl) >= 25
+    for name in decl:
+        assert hasattr(L, name), name
+    assert sorted(P._abi.EXPORTS) == decl
+    assert L.nlmc_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_device():
+    P = load_product()
+    if P.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        P.Engine(np.array([[0.0, 1.0], [1.0, 0.0]]), np.zeros(2), 1)
+
+
+def test_argument_validation_happens_before_any_device_work():
+    P = load_product()
+    import ctypes
+    L = P._abi.lib()
+    h = ctypes.c_void_p()
+    rp = np.array([0, 1, 3], dtype=np.int32)          # rowptr[n] != nnz
+    ci = np.array([1, 0], dtype=np.int32)
+    v = np.array([1.0, 1.0])
+    rc = L.nlmc_create(ctypes.byref(h), 0, None, 2, 2, P._abi.ptr(rp), P._abi.ptr(ci), P._abi.ptr(v),
+                       P._abi.ptr(np.zeros(2)), 1, 0, 1)
+    assert rc == P._abi.ERR_ARG and b"rowptr" in L.nlmc_last_error(None)
+    with pytest.raises(ValueError, match="symmetric"):
+        P.Engine(np.array([[0.0, 1.0], [2.0, 0.0]]), np.zeros(2), 1)
+    with pytest.raises(ValueError):
+        P.Instance(np.zeros((2, 3)), np.zeros(2))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "nonlocal-monte-carlo_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
+                assert "oracle/" not in src or f.endswith((".h", ".hip", ".py")) and "import" not in src.split("oracle/")[0][-20:]

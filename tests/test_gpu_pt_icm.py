@@ -10,36 +10,7 @@ LOG2E = 1.4426950408889634
 TAG_SWAP, TAG_PAIR, TAG_ICM = 3, 4, 5
 
 
-def expected_swap_round(E, slot_of_chain, betas, ladder_len, n_pairs, rnd, seed):
-    """Sequential restatement of k_pt_swap: pair selection (NPT/npt.py:514-533 law) + Metropolis test."""
-    lo, hi = seed & 0xFFFFFFFF, seed >> 32
-    G = len(E)
-    slots = slot_of_chain.copy()
-    pairs_all, acc_all = [], []
-    for g in range(G // ladder_len):
-        chain_of_slot = np.empty(ladder_len, dtype=int)
-        for c in range(g * ladder_len, (g + 1) * ladder_len):
-            chain_of_slot[slots[c]] = c
-        avail = list(range(ladder_len - 1))
-        sel = []
-        for p in range(n_pairs):
-            r = int(oracle.philox(p, rnd, g, TAG_PAIR, lo, hi)[0])
-            idx = (r * len(avail)) >> 32
-            i = avail[idx]
-            sel.append(i)
-            avail = [q for q in avail if abs(q - i) > 1]
-        for p, i in enumerate(sel):
-            ca, cb = chain_of_slot[i], chain_of_slot[i + 1]
-            w = oracle.philox(p, rnd, g, TAG_SWAP, lo, hi)
-            u = ((int(w[0]) >> 5) * 67108864.0 + (int(w[1]) >> 6)) / 9007199254740992.0
-            z = ((betas[i + 1] - betas[i]) * (E[cb] - E[ca])) * LOG2E
-            acc = u < oracle.lib().nlo_exp2_f64(z)
-            if acc:
-                slots[ca], slots[cb] = i + 1, i
-                chain_of_slot[i], chain_of_slot[i + 1] = cb, ca
-            pairs_all.append((i, i + 1))
-            acc_all.append(int(acc))
-    return slots, np.array(pairs_all).reshape(G // ladder_len, n_pairs, 2), np.array(acc_all).reshape(G // ladder_len, n_pairs)
+from oracle.pt import swap_round as expected_swap_round  # noqa: E402
 
 
 def test_pt_swap_rounds_match_restatement(product):
