@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libnlmc_hip.so")
+LIB_PATH = os.environ.get("NLMC_LIB") or os.path.join(_PKG, "lib", "libnlmc_hip.so")   # NLMC_LIB: diagnostic builds
 SRC_DIR = os.path.join(_PKG, "csrc")
 
 OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4

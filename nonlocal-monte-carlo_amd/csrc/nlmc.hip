@@ -51,7 +51,7 @@ struct nlmc_ctx {
     DevBuf<float> h32;
     DevBuf<int8_t> spins, best;
     DevBuf<uint8_t> flags;
-    DevBuf<long long> efix, emin, etrace;
+    DevBuf<long long> efix, emin, etrace, dbg;
     DevBuf<int32_t> argmin;
     DevBuf<double> energy, tab, ustream, etrace_d;
     DevBuf<uint32_t> keys;
@@ -70,7 +70,7 @@ struct nlmc_ctx {
             if ((e = nlev.reserve(orders)) != hipSuccess) return e;
             if (mode == 1) {
                 if ((e = head32.reserve(orders * n)) != hipSuccess) return e;
-                if ((e = ell32.reserve(orders * n * NLMC_ELL_W)) != hipSuccess) return e;
+                if ((e = ell32.reserve(orders * n * NLMC_ELL_W32)) != hipSuccess) return e;
             } else if (mode == 2) {
                 if ((e = headh64.reserve(orders * n)) != hipSuccess) return e;
                 if ((e = ellc64.reserve(orders * n * NLMC_ELL_W)) != hipSuccess) return e;
@@ -249,7 +249,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
                         (uint64_t)sweep0 + (uint64_t)n_sweeps <= (uint64_t)c->plan_sweep0 + (uint64_t)c->plan_count;
     // window size: keep the schedule scratch under ~256 MiB
     const size_t per_sweep_orders = per_chain ? (size_t)R : 1;
-    const size_t item_bytes = ell_mode == 1 ? 8 + 8 + 8 * NLMC_ELL_W : (ell_mode == 2 ? 8 + 8 + 12 * NLMC_ELL_W : 8);
+    const size_t item_bytes = ell_mode == 1 ? 8 + 8 + 8 * NLMC_ELL_W32 : (ell_mode == 2 ? 8 + 8 + 12 * NLMC_ELL_W : 8);
     const size_t bytes_per_sweep = per_sweep_orders * ((size_t)n * item_bytes + (size_t)(n + 1) * 4 + 4);
     int W = n_sweeps;
     if (!cached) {
@@ -307,7 +307,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         a.ord2 = sc.order.p + o0 * n;
         a.lvl_off = sc.lvl_off.p + o0 * (size_t)(n + 1);
         a.nlev = sc.nlev.p + o0;
-        if (ell_mode == 1) { a.ell32 = sc.ell32.p + o0 * (size_t)n * NLMC_ELL_W; a.head32 = sc.head32.p + o0 * n; }
+        if (ell_mode == 1) { a.ell32 = sc.ell32.p + o0 * (size_t)n * NLMC_ELL_W32; a.head32 = sc.head32.p + o0 * n; }
         if (ell_mode == 2) {
             a.ellc64 = sc.ellc64.p + o0 * (size_t)n * NLMC_ELL_W;
             a.ellv64 = sc.ellv64.p + o0 * (size_t)n * NLMC_ELL_W;
@@ -331,6 +331,10 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         a.emin = want_min ? c->emin.p : nullptr;
         a.argmin = c->argmin.p;
         a.best = (want_min && o.out_argmin_state) ? c->best.p : nullptr;
+#ifdef NLMC_STAMPS
+        HIP_TRY(c, c->dbg.reserve((size_t)R * 16 * 8));
+        a.dbg = c->dbg.p;
+#endif
         a.lds_flags_off = lds_flags_off; a.lds_u_off = lds_u_off; a.lds_loff_off = lds_loff_off; a.lds_red_off = lds_red_off;
         if (stream_mode)
             hipLaunchKernelGGL(k_sweep_stream, dim3(R), dim3(nt), lds, c->stream, a);
@@ -493,6 +497,17 @@ void nlmc_destroy(nlmc_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
+#ifdef NLMC_STAMPS
+    if (const char *fn = getenv("NLMC_STAMP_FILE")) {      // diagnostic build: dump the last launch's per-wave cycle sums
+        if (c->dbg.p) {
+            std::vector<long long> hbuf((size_t)c->n_chains * 16 * 8);
+            if (hipMemcpy(hbuf.data(), c->dbg.p, hbuf.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                if (FILE *f = fopen(fn, "wb")) { fwrite(hbuf.data(), sizeof(long long), hbuf.size(), f); fclose(f); }
+            }
+        }
+    }
+    c->dbg.release();
+#endif
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     c->rowptr.release(); c->col.release(); c->val64.release(); c->h64.release(); c->edge32.release(); c->h32.release();
     c->spins.release(); c->best.release(); c->flags.release(); c->efix.release(); c->emin.release(); c->etrace.release();
@@ -861,7 +876,7 @@ int nlmc_pt_swap_philox(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs,
     a.escale = c->escale;
     a.slot_of_chain = c->slot_of_chain.p; a.chain_of_slot = c->chain_of_slot.p;
     a.out_pairs = c->pt_pairs.p; a.out_acc = c->pt_acc.p; a.status = c->pt_status.p;
-    hipLaunchKernelGGL(k_pt_swap, dim3(nl), dim3(64), (size_t)L, c->stream, a);
+    hipLaunchKernelGGL(k_pt_swap, dim3(nl), dim3(64), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     if (out_pairs || out_accepted) {
         int32_t st = 0;

@@ -42,13 +42,15 @@ struct LevelizeArgs {
     int32_t *nlev;        // [n_orders]
     // optional packed per-order schedule in ELL form (slot-major, position-minor) so that the sweep kernel's
     // loads are fully coalesced: lane i of a level reads slot q at [(o*8+q)*n + i]
-    EdgeF *ell32;         // [n_orders][8][n]  first 8 entries of row k(i), zero-padded (col 0, val 0)
+    EdgeF *ell32;         // [n_orders][8][n][2]  first 16 entries of row k(i) as 8 planes of 2 entries (16 B),
+                          //                      zero-padded (col 0, val 0)
     int2 *head32;         // [n_orders][n]     { k | deg << 16, bits of (float)h_k }
     int32_t *ellc64;      // [n_orders][8][n]
     double *ellv64;       // [n_orders][8][n]
     double *headh64;      // [n_orders][n]
 };
-#define NLMC_ELL_W 8
+#define NLMC_ELL_W 8          // packed row window, fp64 path
+#define NLMC_ELL_W32 16       // packed row window, fp32 path: covers every row of a degree-6 random graph (max ~16)
 
 __device__ __forceinline__ bool precedes(uint32_t kj, int j, uint32_t kk, int k) { return kj < kk || (kj == kk && j < k); }
 
@@ -150,10 +152,12 @@ __global__ void k_levelize(LevelizeArgs a)
         if (a.ell32) {
             a.head32[(size_t)o * n + pos] = make_int2(kd, __float_as_int(a.g.h32[k]));
 #pragma unroll
-            for (int q = 0; q < NLMC_ELL_W; ++q) {
-                EdgeF ed{0, 0.0f};
-                if (q < deg) ed = a.g.edge32[rs + q];
-                a.ell32[((size_t)o * NLMC_ELL_W + q) * n + pos] = ed;
+            for (int q = 0; q < NLMC_ELL_W32; q += 2) {
+                EdgeF e0{0, 0.0f}, e1{0, 0.0f};
+                if (q < deg) e0 = a.g.edge32[rs + q];
+                if (q + 1 < deg) e1 = a.g.edge32[rs + q + 1];
+                int4 pk = make_int4(e0.col, __float_as_int(e0.val), e1.col, __float_as_int(e1.val));
+                reinterpret_cast<int4 *>(a.ell32)[((size_t)o * (NLMC_ELL_W32 / 2) + q / 2) * n + pos] = pk;
             }
         }
         if (a.ellc64) {
@@ -173,6 +177,11 @@ __global__ void k_levelize(LevelizeArgs a)
 // sweeps
 // ------------------------------------------------------------------------------------------------------
 #define NLMC_LCAP 1024          // level offsets of one sweep kept in LDS by the pipelined path
+#ifdef NLMC_STAMPS
+#define NLMC_CLK(v) { __builtin_amdgcn_sched_barrier(0); v = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define NLMC_CLK(v)
+#endif
 
 struct SweepArgs {
     CsrDev g;
@@ -183,7 +192,7 @@ struct SweepArgs {
     // schedule: ord2[o][i] = { k | deg << 16, row start }, lvl_off[o][0..nlev], nlev[o]
     const int2 *ord2;
     const int32_t *lvl_off, *nlev;
-    const EdgeF *ell32;       // packed schedule (philox kernels), see LevelizeArgs
+    const EdgeF *ell32;       // packed schedule (philox kernels), see LevelizeArgs: [o][4][n] int4 planes
     const int2 *head32;
     const int32_t *ellc64;
     const double *ellv64, *headh64;
@@ -209,10 +218,12 @@ struct SweepArgs {
     int8_t *best;             // [n_chains][n_pad] or nullptr
     // LDS carve-up (bytes from the dynamic base)
     int lds_flags_off, lds_u_off, lds_loff_off, lds_red_off;
+    long long *dbg;           // diagnostic build (-DNLMC_STAMPS) only: per-wave cycle sums [chains][16][4]
 };
 
 // ---- pieces shared by the two sweep kernels ------------------------------------------------------------
 struct ChainCtx {
+    long long *st;            // diagnostic build: per-thread stamp sums inside update_spin
     int8_t *s;
     uint8_t *fl;
     long long *red;
@@ -224,6 +235,7 @@ struct ChainCtx {
 
 __device__ __forceinline__ void chain_load(const SweepArgs &a, unsigned char *lds_raw, ChainCtx &x)
 {
+    x.st = nullptr;
     x.n = a.g.n; x.n_pad = a.g.n_pad;
     x.tid = threadIdx.x; x.nt = blockDim.x; x.c = blockIdx.x;
     x.s = reinterpret_cast<int8_t *>(lds_raw);
@@ -354,58 +366,100 @@ __global__ void k_sweep_stream(SweepArgs a)
 
 // ---- PHILOX mode (throughput) ---------------------------------------------------------------------------
 template <typename T> struct Pf;            // one schedule item: k, degree, h_k and the first 8 entries of row k
+typedef int nlmc_i4 __attribute__((ext_vector_type(4)));
+typedef int nlmc_i2 __attribute__((ext_vector_type(2)));
 template <> struct Pf<float> {
-    EdgeF ed[NLMC_ELL_W];
-    int kd;
-    float h;
-    // coalesced: consecutive lanes read consecutive positions of every slot plane
-    __device__ __forceinline__ void load(const SweepArgs &a, size_t oid, int n, int i)
+    static constexpr int W = NLMC_ELL_W32;
+    nlmc_i4 pk[W / 2];            // plane q: { col(2q), bits val(2q), col(2q+1), bits val(2q+1) }
+    nlmc_i2 hd;                   // { k | deg << 16, bits of h_k }
+    // Nine loads per item, issued by EVERY wave in every stage (idle lanes: out-of-range no-ops): a load that sits
+    // behind a branch makes hipcc's vmcnt model path-dependent and it then drains vmcnt to 0 -- i.e. waits for the
+    // prefetch it has just issued -- before every update; with a static count it emits the counted wait.
+    // (Inline-asm loads with hand-placed waits were tried: hipcc spills/copies the still-pending destination
+    // registers around the long-row tail loop, which corrupts them.)  Coalesced: consecutive lanes read consecutive
+    // positions of every plane.
+    // Per-sweep view of the packed schedule as two raw buffers (SRSRC): 32-bit offsets instead of 64-bit address
+    // arithmetic per load, and the hardware range check turns the loads of idle lanes (offset >= size) into no-ops
+    // that return 0 without touching memory.
+    struct View {
+        __amdgpu_buffer_rsrc_t ell, head;
+        int plane_bytes;
+        __device__ __forceinline__ void bind(const SweepArgs &a, size_t oid, int n)
+        {
+            const char *pe = reinterpret_cast<const char *>(a.ell32) + oid * (W / 2) * (size_t)n * 16;
+            const char *ph = reinterpret_cast<const char *>(a.head32) + oid * (size_t)n * 8;
+            plane_bytes = n * 16;
+            ell = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(pe), 0, (W / 2) * n * 16, 0x00020000);
+            head = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(ph), 0, n * 8, 0x00020000);
+        }
+    };
+    __device__ __forceinline__ void issue(const View &v, int i, bool valid)
     {
-        const int2 hd = a.head32[oid * n + i];
-        const EdgeF *__restrict__ p = a.ell32 + oid * NLMC_ELL_W * n + i;
+        const int oob = 0x7FF00000;                      // past both buffers even after adding the plane offsets
+        const int o16 = valid ? i * 16 : oob;
+        hd = __builtin_amdgcn_raw_buffer_load_b64(v.head, valid ? i * 8 : oob, 0, 0);
 #pragma unroll
-        for (int q = 0; q < NLMC_ELL_W; ++q) ed[q] = p[(size_t)q * n];
-        kd = hd.x;
-        h = __int_as_float(hd.y);
+        for (int q = 0; q < W / 2; ++q)
+            pk[q] = __builtin_amdgcn_raw_buffer_load_b128(v.ell, o16 + q * v.plane_bytes, 0, 0);
     }
-    // Declare every register of the item dead (no instruction): lets a lane-masked load land directly in these
-    // registers without a merge copy that would wait on the load right after issuing it.
-    __device__ __forceinline__ void kill()
-    {
-#pragma unroll
-        for (int q = 0; q < NLMC_ELL_W; ++q) { asm volatile("" : "=v"(ed[q].col)); asm volatile("" : "=v"(ed[q].val)); }
-        asm volatile("" : "=v"(kd));
-        asm volatile("" : "=v"(h));
-    }
-    __device__ __forceinline__ int col(int q) const { return ed[q].col; }
-    __device__ __forceinline__ float val(int q) const { return ed[q].val; }
+    __device__ __forceinline__ void wait(bool) {}
+    __device__ __forceinline__ int kd() const { return hd.x; }
+    __device__ __forceinline__ float h() const { return __int_as_float(hd.y); }
+    __device__ __forceinline__ int col(int q) const { return (q & 1) ? pk[q >> 1].z : pk[q >> 1].x; }
+    __device__ __forceinline__ float val(int q) const { return __int_as_float((q & 1) ? pk[q >> 1].w : pk[q >> 1].y); }
     static __device__ __forceinline__ void tail(const CsrDev &g, int e, int &cj, float &vj) { const EdgeF t = g.edge32[e]; cj = t.col; vj = t.val; }
 };
 template <> struct Pf<double> {
+    static constexpr int W = NLMC_ELL_W;
     int cj[NLMC_ELL_W];
     double vj[NLMC_ELL_W];
-    int kd;
-    double h;
-    __device__ __forceinline__ void load(const SweepArgs &a, size_t oid, int n, int i)
+    int kd_;
+    double h_;
+    struct View {
+        const int32_t *pc;
+        const double *pv, *ph;
+        const int2 *po;
+        int n;
+        __device__ __forceinline__ void bind(const SweepArgs &a, size_t oid, int n_)
+        {
+            n = n_;
+            pc = a.ellc64 + oid * NLMC_ELL_W * n;
+            pv = a.ellv64 + oid * NLMC_ELL_W * n;
+            ph = a.headh64 + oid * n;
+            po = a.ord2 + oid * n;
+        }
+    };
+    __device__ __forceinline__ void issue(const View &v, int i, bool valid)
     {
-        const int32_t *__restrict__ pc = a.ellc64 + oid * NLMC_ELL_W * n + i;
-        const double *__restrict__ pv = a.ellv64 + oid * NLMC_ELL_W * n + i;
+        const int ic = valid ? i : 0;
 #pragma unroll
-        for (int q = 0; q < NLMC_ELL_W; ++q) { cj[q] = pc[(size_t)q * n]; vj[q] = pv[(size_t)q * n]; }
-        kd = a.ord2[oid * n + i].x;
-        h = a.headh64[oid * n + i];
+        for (int q = 0; q < NLMC_ELL_W; ++q) { cj[q] = v.pc[(size_t)q * v.n + ic]; vj[q] = v.pv[(size_t)q * v.n + ic]; }
+        kd_ = v.po[ic].x;
+        h_ = v.ph[ic];
     }
-    __device__ __forceinline__ void kill()
-    {
-#pragma unroll
-        for (int q = 0; q < NLMC_ELL_W; ++q) { asm volatile("" : "=v"(cj[q])); asm volatile("" : "=v"(vj[q])); }
-        asm volatile("" : "=v"(kd));
-        asm volatile("" : "=v"(h));
-    }
+    __device__ __forceinline__ void wait(bool) {}
+    __device__ __forceinline__ int kd() const { return kd_; }
+    __device__ __forceinline__ double h() const { return h_; }
     __device__ __forceinline__ int col(int q) const { return cj[q]; }
     __device__ __forceinline__ double val(int q) const { return vj[q]; }
     static __device__ __forceinline__ void tail(const CsrDev &g, int e, int &c, double &v) { c = g.col[e]; v = g.val64[e]; }
 };
+
+// -(ds) * x * 2^escale as an exact integer (== llrint of the fp64 product the oracle forms): for a float x the product
+// is mantissa << shift whenever shift >= 0, which integer ops deliver without the fp64 convert/round chain.
+__device__ __forceinline__ long long fixed_delta(float xt, int ds, double esc, int escale)
+{
+    const uint32_t b = __float_as_uint(xt);
+    const int e = (int)((b >> 23) & 0xFFu);
+    const int sh = e - 150 + escale + ((ds == 2 || ds == -2) ? 1 : 0);
+    if (e != 0 && e != 255 && sh >= 0 && sh <= 38 && (ds == 2 || ds == -2 || ds == 1 || ds == -1)) {
+        const long long mag = (long long)((b & 0x7FFFFFu) | 0x800000u) << sh;
+        const bool neg = ((b >> 31) != 0u) == (ds < 0);      // sign(-ds * x)
+        return neg ? -mag : mag;
+    }
+    return __double2ll_rn(-(double)ds * (double)xt * esc);
+}
+__device__ __forceinline__ long long fixed_delta(double xt, int ds, double esc, int) { return __double2ll_rn(-(double)ds * xt * esc); }
 
 __device__ __forceinline__ float fma_rn(float a, float b, float c) { return __fmaf_rn(a, b, c); }
 __device__ __forceinline__ double fma_rn(double a, double b, double c) { return __fma_rn(a, b, c); }
@@ -416,22 +470,41 @@ template <typename T, bool DIAG>
 __device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, const T *ur, const Pf<T> &pf, size_t oid, int i,
                                             T cb0, T cb1, double esc)
 {
-    const int k = pf.kd & 0xFFFF, deg = (int)((unsigned)pf.kd >> 16);
+    const int k = pf.kd() & 0xFFFF, deg = (int)((unsigned)pf.kd() >> 16);
     const unsigned f = x.fl ? (unsigned)x.fl[k] : 0u;
     if (f >= 2u) return;                       // frozen
     int8_t *s = x.s;
-    T sj[NLMC_ELL_W];
+#ifdef NLMC_STAMPS
+    long long u0, u1, u2, u3, u4;
+    NLMC_CLK(u0)
+#endif
+    constexpr int W = Pf<T>::W;
+    T sj[8];
 #pragma unroll
-    for (int q = 0; q < NLMC_ELL_W; ++q) sj[q] = (T)s[pf.col(q)];     // all LDS reads in flight together
+    for (int q = 0; q < 8; ++q) sj[q] = (T)s[pf.col(q)];              // all LDS reads in flight together
+#ifdef NLMC_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    NLMC_CLK(u1)
+#endif
     T xs = T(0), xd = T(0);
 #pragma unroll
-    for (int q = 0; q < NLMC_ELL_W; ++q) {
+    for (int q = 0; q < 8; ++q) {
         xs = fma_rn(pf.val(q), sj[q], xs);
         if (DIAG) { const T nd = fma_rn(pf.val(q), sj[q], xd); xd = (q < deg && pf.col(q) == k) ? nd : xd; }
     }
-    if (deg > NLMC_ELL_W) {                    // rows longer than the packed window: rest from the CSR arrays
+    if (W > 8 && __ballot(deg > 8) != 0ull) {  // second half of the packed window: only waves holding a long row
+        T sk[8];
+#pragma unroll
+        for (int q = 8; q < W; ++q) sk[q - 8] = (T)s[pf.col(q)];
+#pragma unroll
+        for (int q = 8; q < W; ++q) {
+            xs = fma_rn(pf.val(q), sk[q - 8], xs);
+            if (DIAG) { const T nd = fma_rn(pf.val(q), sk[q - 8], xd); xd = (q < deg && pf.col(q) == k) ? nd : xd; }
+        }
+    }
+    if (deg > W) {                             // rows longer than the packed window: rest from the CSR arrays
         const int rs = a.ord2[oid * x.n + i].y;
-        for (int e = NLMC_ELL_W; e < deg; ++e) {
+        for (int e = W; e < deg; ++e) {
             int j; T v;
             Pf<T>::tail(a.g, rs + e, j, v);
             const T sv = (T)s[j];
@@ -439,15 +512,28 @@ __device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, con
             if (DIAG && j == k) xd = fma_rn(v, sv, xd);
         }
     }
-    const T x_true = DIAG ? ((xs - xd) + pf.h) : (xs + pf.h);
-    const T xf = xs + pf.h;
+    const T hk = pf.h();
+    const T x_true = DIAG ? ((xs - xd) + hk) : (xs + hk);
+    const T xf = xs + hk;
+#ifdef NLMC_STAMPS
+    asm volatile("" :: "v"(xf));
+    NLMC_CLK(u2)
+#endif
     const T z = (f == 1u ? cb1 : cb0) * xf;
     const int so = (int)s[k];
     const int sn = accept_up(ur[k], z) ? 1 : -1;
+#ifdef NLMC_STAMPS
+    asm volatile("" :: "v"(sn));
+    NLMC_CLK(u3)
+#endif
     if (sn != so) {
-        x.e_loc += __double2ll_rn(-(double)(sn - so) * (double)x_true * esc);
+        x.e_loc += fixed_delta(x_true, sn - so, esc, a.escale);
         s[k] = (int8_t)sn;
     }
+#ifdef NLMC_STAMPS
+    NLMC_CLK(u4)
+    if (x.st) { x.st[0] += u1 - u0; x.st[1] += u2 - u1; x.st[2] += u3 - u2; x.st[3] += u4 - u3; }
+#endif
 }
 
 // uniforms of one sweep for every spin of this chain -> LDS.  One Philox4x32-10 call serves 4 (f32) / 2 (f64) spins:
@@ -489,6 +575,12 @@ __global__ void k_sweep_philox(SweepArgs a)
     const int row = a.slot_of_chain ? a.slot_of_chain[gc] : c;
     const double esc = __longlong_as_double((long long)(1023 + a.escale) << 52);   // 2^escale
 
+#ifdef NLMC_STAMPS
+    long long st_fetch = 0, st_upd = 0, st_bar = 0, st_cnt = 0, st_fill = 0, st_epi = 0, st_wait = 0;
+    long long st_u[4] = {0, 0, 0, 0};
+    x.st = st_u;
+    const long long st_begin = (long long)__builtin_readcyclecounter();
+#endif
     for (int t = 0; t < a.n_sweeps; ++t) {
         const int oid = a.per_chain ? (c * a.n_sweeps + t) : t;
         const int32_t *__restrict__ off = a.lvl_off + (size_t)oid * (n + 1);
@@ -498,10 +590,16 @@ __global__ void k_sweep_philox(SweepArgs a)
         const uint32_t tt = a.sweep0 + (uint32_t)t;
 
         // sweep prologue: all lanes busy -- uniforms for every spin, level offsets into LDS
+#ifdef NLMC_STAMPS
+        const long long f0 = (long long)__builtin_readcyclecounter();
+#endif
         fill_uniforms(ur, n, tt, gc, a.seed_lo, a.seed_hi, tid, nt);
         const bool fast = nl < NLMC_LCAP;
         if (fast) for (int l = tid; l <= nl; l += nt) loff[l] = off[l];
         __syncthreads();
+#ifdef NLMC_STAMPS
+        st_fill += (long long)__builtin_readcyclecounter() - f0;
+#endif
 
         const size_t so = (size_t)oid;
         if (fast) {
@@ -509,26 +607,50 @@ __global__ void k_sweep_philox(SweepArgs a)
             // flight.  Their addresses depend only on the level offsets (LDS), never on spin values, and the
             // schedule was built with level_cap == blockDim.x: at most one spin per thread and level.
             Pf<T> pfa, pfb;                // ping-pong (manual 2x unroll: no register rotation)
-            bool va, vb;
+            bool va, vb, wa, wb;           // lane has an item / wave has any item (wave-uniform)
             int ia, ib;
-            auto fetch = [&](int l, Pf<T> &p, bool &valid, int &ic) {
+            typename Pf<T>::View view;
+            view.bind(a, so, n);
+            auto fetch = [&](int l, Pf<T> &p, bool &valid, bool &wave_any, int &ic) {
                 const int lc = min(l, nl - 1);
                 const int i = loff[lc] + tid;
                 valid = (l < nl) && (i < loff[lc + 1]);
-                ic = valid ? i : 0;        // idle lanes of a busy wave all read item 0 (one extra cache line)
-                // a vector-memory instruction costs the CU's address unit ~16 cycles per wave whatever its lanes
-                // do, so waves without any item in this level skip the loads altogether (wave-uniform branch)
-                if (__ballot(valid) != 0ull) p.load(a, so, n, ic);
+                ic = valid ? i : 0;
+                wave_any = __ballot(valid) != 0ull;
+                p.issue(view, i, valid);
             };
-            fetch(0, pfa, va, ia);
+            fetch(0, pfa, va, wa, ia);
+#ifdef NLMC_STAMPS
+            long long c0, c1, c2, c3;
+#endif
             for (int l = 0; l < nl; l += 2) {
-                fetch(l + 1, pfb, vb, ib);
-                if (va) update_spin<T, DIAG>(a, x, ur, pfa, so, ia, cb0, cb1, esc);
+                NLMC_CLK(c0)
+                fetch(l + 1, pfb, vb, wb, ib);
+                NLMC_CLK(c1)
+#ifdef NLMC_STAMPS
+                { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); long long cw; NLMC_CLK(cw) st_wait += cw - c1; }
+#endif
+                if (wa) { pfa.wait(wb); if (va) update_spin<T, DIAG>(a, x, ur, pfa, so, ia, cb0, cb1, esc); }
+                NLMC_CLK(c2)
                 __syncthreads();
+                NLMC_CLK(c3)
+#ifdef NLMC_STAMPS
+                st_fetch += c1 - c0; st_upd += c2 - c1; st_bar += c3 - c2; st_cnt += __ballot(va) != 0ull;
+#endif
                 if (l + 1 < nl) {
-                    fetch(l + 2, pfa, va, ia);
-                    if (vb) update_spin<T, DIAG>(a, x, ur, pfb, so, ib, cb0, cb1, esc);
+                    NLMC_CLK(c0)
+                    fetch(l + 2, pfa, va, wa, ia);
+                    NLMC_CLK(c1)
+#ifdef NLMC_STAMPS
+                    { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); long long cw; NLMC_CLK(cw) st_wait += cw - c1; }
+#endif
+                    if (wb) { pfb.wait(wa); if (vb) update_spin<T, DIAG>(a, x, ur, pfb, so, ib, cb0, cb1, esc); }
+                    NLMC_CLK(c2)
                     __syncthreads();
+                    NLMC_CLK(c3)
+#ifdef NLMC_STAMPS
+                    st_fetch += c1 - c0; st_upd += c2 - c1; st_bar += c3 - c2; st_cnt += __ballot(vb) != 0ull;
+#endif
                 }
             }
         } else {
@@ -537,14 +659,31 @@ __global__ void k_sweep_philox(SweepArgs a)
                 const int lo = off[l], hi = off[l + 1];
                 for (int i = lo + tid; i < hi; i += nt) {
                     Pf<T> pe;
-                    pe.load(a, so, n, i);
+                    typename Pf<T>::View vw;
+                    vw.bind(a, so, n);
+                    pe.issue(vw, i, true);
+                    pe.wait(false);
                     update_spin<T, DIAG>(a, x, ur, pe, so, i, cb0, cb1, esc);
                 }
                 __syncthreads();
             }
         }
+#ifdef NLMC_STAMPS
+        const long long e0 = (long long)__builtin_readcyclecounter();
+#endif
         sweep_epilogue(a, x, t);
+#ifdef NLMC_STAMPS
+        st_epi += (long long)__builtin_readcyclecounter() - e0;
+#endif
     }
+#ifdef NLMC_STAMPS
+    if (a.dbg && (tid & 63) == 0) {
+        long long *d = a.dbg + ((size_t)c * 16 + (tid >> 6)) * 8;
+        d[0] = st_fetch; d[1] = st_upd; d[2] = st_bar; d[3] = st_cnt; d[4] = st_u[0]; d[5] = st_u[1];
+        d[2] = st_u[2]; d[0] = st_u[3];
+        d[6] = (long long)__builtin_readcyclecounter() - st_begin; d[7] = st_wait;
+    }
+#endif
     chain_store(a, x);
 }
 

@@ -27,48 +27,63 @@ struct PtSwapArgs {
     int32_t *status;            // sticky: 1 = "Cannot find non-overlapping pairs."
 };
 
-// One workgroup (one wave) per ladder.  Pair selection restates select_non_overlapping_pairs (NPT/npt.py:514-533):
-// repeatedly pick uniformly among the still-available adjacent pairs (ascending list), then drop the pairs that
-// share a replica with the pick.  Acceptance: u < min(1, exp(dBeta dE)) (NPT/npt.py:668-671).
+// position of the r-th (0-based) set bit of w (r < popcount(w)): binary search on popcounts
+__device__ __forceinline__ int nth_set_bit(unsigned long long w, int r)
+{
+    int pos = 0;
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        const int c = __popcll((w >> pos) & ((1ull << sft) - 1ull));
+        if (r >= c) { r -= c; pos += sft; }
+    }
+    return pos;
+}
+
+// One wave per ladder.  Pair selection restates select_non_overlapping_pairs (NPT/npt.py:514-533): repeatedly pick
+// uniformly among the still-available adjacent pairs (ascending list), then drop the pairs that share a replica with
+// the pick.  The availability set lives in registers: lane l holds pairs [64 l, 64 l + 64) as a bit mask, the pick is
+// located with a wave prefix sum of popcounts (ladder_len <= 4096).  Acceptance: u < min(1, exp(dBeta dE))
+// (NPT/npt.py:668-671), one lane per selected pair.
 __global__ void k_pt_swap(PtSwapArgs a)
 {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    unsigned long long *avail = reinterpret_cast<unsigned long long *>(lds_raw);   // bit q = pair (q, q+1) available
-    __shared__ int ok;
-    const int L = a.ladder_len, g = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    const int npairs_all = L - 1, nw = (npairs_all + 63) / 64;
-    for (int w = tid; w < nw; w += nt) {
-        const int rem = npairs_all - w * 64;
-        avail[w] = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
-    }
-    __syncthreads();
+    const int L = a.ladder_len, g = blockIdx.x, lane = threadIdx.x;     // blockDim.x == 64
+    const int npairs_all = L - 1;
+    const int rem = npairs_all - lane * 64;
+    unsigned long long word = rem >= 64 ? ~0ull : (rem > 0 ? ((1ull << rem) - 1ull) : 0ull);
     int32_t *pairs = a.out_pairs + (size_t)g * a.n_pairs * 2;
-    if (tid == 0) {
-        int cnt = npairs_all, good = 1;
-        for (int p = 0; p < a.n_pairs; ++p) {
-            if (cnt == 0) { good = 0; break; }
-            const uint32_t r = philox4x32_10((uint32_t)p, a.round, (uint32_t)g, NLMC_TAG_PAIR, a.seed_lo, a.seed_hi).x;
-            int idx = (int)(((unsigned long long)r * (unsigned long long)cnt) >> 32);
-            int w = 0;
-            for (;; ++w) { const int pc = __popcll(avail[w]); if (idx < pc) break; idx -= pc; }
-            unsigned long long m = avail[w];
-            for (int q = 0; q < idx; ++q) m &= m - 1;          // drop the idx lowest set bits
-            const int i = w * 64 + (__ffsll((long long)m) - 1);
-            pairs[2 * p] = i;
-            pairs[2 * p + 1] = i + 1;
-            for (int q = i - 1; q <= i + 1; ++q)
-                if (q >= 0 && q < npairs_all && ((avail[q >> 6] >> (q & 63)) & 1ull)) { avail[q >> 6] &= ~(1ull << (q & 63)); --cnt; }
+    int cnt = npairs_all, good = 1;
+    for (int p = 0; p < a.n_pairs; ++p) {
+        if (cnt == 0) { good = 0; break; }
+        const uint32_t r = philox4x32_10((uint32_t)p, a.round, (uint32_t)g, NLMC_TAG_PAIR, a.seed_lo, a.seed_hi).x;
+        const int idx = (int)(((unsigned long long)r * (unsigned long long)cnt) >> 32);
+        const int pc = __popcll(word);
+        int incl = pc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+        const int before = incl - pc;
+        const bool mine = idx >= before && idx < before + pc;
+        const int owner = __ffsll((long long)__ballot(mine)) - 1;
+        const int bit = nth_set_bit(word, mine ? idx - before : 0);
+        const int i = __shfl(lane * 64 + bit, owner, 64);
+        if (lane == 0) { pairs[2 * p] = i; pairs[2 * p + 1] = i + 1; }
+        int cleared = 0;
+#pragma unroll
+        for (int q = -1; q <= 1; ++q) {
+            const int b = i + q;
+            if (b >= 0 && b < npairs_all && (b >> 6) == lane && ((word >> (b & 63)) & 1ull)) { word &= ~(1ull << (b & 63)); ++cleared; }
         }
-        ok = good;
-        if (!good) atomicExch(a.status, 1);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cleared += __shfl_xor(cleared, o, 64);
+        cnt -= cleared;
     }
-    __syncthreads();
-    if (!ok) {
-        for (int p = tid; p < a.n_pairs; p += nt) { a.out_acc[(size_t)g * a.n_pairs + p] = 0; pairs[2 * p] = pairs[2 * p + 1] = -1; }
+    if (!good) {
+        if (lane == 0) atomicExch(a.status, 1);
+        for (int p = lane; p < a.n_pairs; p += 64) { a.out_acc[(size_t)g * a.n_pairs + p] = 0; pairs[2 * p] = pairs[2 * p + 1] = -1; }
         return;
     }
+    __syncthreads();      // pairs[] written by lane 0 are read by all lanes below
     const double inv = __longlong_as_double((long long)(1023 - a.escale) << 52);
-    for (int p = tid; p < a.n_pairs; p += nt) {
+    for (int p = lane; p < a.n_pairs; p += 64) {
         const int i = pairs[2 * p];
         const int ca = a.chain_of_slot[(size_t)g * L + i], cb = a.chain_of_slot[(size_t)g * L + i + 1];
         const double Ea = a.energies ? a.energies[ca] : (double)a.efix[ca] * inv;
@@ -78,7 +93,7 @@ __global__ void k_pt_swap(PtSwapArgs a)
         const double u = uniform_from(r, 0.0);
         const double z = (dB * dE) * 1.4426950408889634;
         const bool acc = u < exp2_spec(z);
-        if (acc) {   // selected pairs are disjoint -> no two threads touch the same entries
+        if (acc) {   // selected pairs are disjoint -> no two lanes touch the same entries
             a.slot_of_chain[ca] = i + 1;
             a.slot_of_chain[cb] = i;
             a.chain_of_slot[(size_t)g * L + i] = cb;
