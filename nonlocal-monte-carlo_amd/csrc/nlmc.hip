@@ -199,7 +199,10 @@ int run_levelize(nlmc_ctx *c, int n_orders, const uint32_t *keys_in, int per_cha
     a.nlev = sc.nlev.p;
     if (ell_mode == 1) { a.ell32 = sc.ell32.p; a.head32 = sc.head32.p; }
     if (ell_mode == 2) { a.ellc64 = sc.ellc64.p; a.ellv64 = sc.ellv64.p; a.headh64 = sc.headh64.p; }
-    const size_t lds = (size_t)(c->n + 2) * 4 + (size_t)c->n * 2 + 16;
+    const size_t lds_one = (size_t)(c->n + 2) * 4 + (((size_t)c->n * 2 + 3) / 4) * 4;
+    const size_t lds_two = lds_one + (size_t)(c->n + 2) * 4;
+    a.two_sided = lds_two + 16 <= (size_t)150 * 1024;
+    const size_t lds = (a.two_sided ? lds_two : lds_one) + 16;
     { int rc = ensure_lds(c, 0, reinterpret_cast<const void *>(k_levelize), lds); if (rc) return rc; }
     hipLaunchKernelGGL(k_levelize, dim3(n_orders), dim3(level_block(c->n)), lds, c->stream, a);
     HIP_TRY(c, hipGetLastError());

@@ -37,6 +37,8 @@ struct LevelizeArgs {
     int n_sweeps;
     int chain_base;
     int level_cap;        // levels wider than this are split (any subset of an independent set is independent)
+    int two_sided;        // LDS holds a second cursor array: rows longer than 8 entries are placed at the FRONT of their
+                          // level so that only the first wave(s) of a level pay for the second half of the row window
     int2 *ord2;           // [n_orders][n]  { k | deg << 16, row start }
     int32_t *lvl_off;     // [n_orders][n+1]
     int32_t *nlev;        // [n_orders]
@@ -144,9 +146,16 @@ __global__ void k_levelize(LevelizeArgs a)
 
     // placement (intra-level order is irrelevant: same-level spins are independent)
     int2 *ord = a.ord2 + (size_t)o * n;
+    uint32_t *back = reinterpret_cast<uint32_t *>(lds_raw + (size_t)(n + 2) * 4 + (((size_t)n * 2 + 3) / 4) * 4);
+    if (a.two_sided) {
+        for (int l = tid; l < nl; l += nt) back[l] = (l + 1 < nl) ? cnt[l + 1] : (uint32_t)n;   // end of level l
+        __syncthreads();
+    }
     for (int k = tid; k < n; k += nt) {
-        const uint32_t pos = atomicAdd(&cnt[lvl[k]], 1u);
         const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
+        uint32_t pos;
+        if (a.two_sided && deg <= 8) pos = atomicSub(&back[lvl[k]], 1u) - 1u;     // short rows fill from the back
+        else pos = atomicAdd(&cnt[lvl[k]], 1u);                                  // long rows from the front
         const int kd = k | (deg << 16);
         ord[pos] = make_int2(kd, rs);
         if (a.ell32) {
@@ -479,9 +488,13 @@ __device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, con
     NLMC_CLK(u0)
 #endif
     constexpr int W = Pf<T>::W;
+    // The spins sit at LDS offset 0 (first region of the dynamic LDS, no static LDS in this kernel -- checked at
+    // kernel entry), so a column index IS the LDS address: no per-read base add.
+    typedef const int8_t __attribute__((address_space(3))) *lds_i8;
+#define NLMC_SPIN(c) ((T)(*(lds_i8)(unsigned)(c)))
     T sj[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) sj[q] = (T)s[pf.col(q)];              // all LDS reads in flight together
+    for (int q = 0; q < 8; ++q) sj[q] = NLMC_SPIN(pf.col(q));         // all LDS reads in flight together
 #ifdef NLMC_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     NLMC_CLK(u1)
@@ -495,7 +508,7 @@ __device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, con
     if (W > 8 && __ballot(deg > 8) != 0ull) {  // second half of the packed window: only waves holding a long row
         T sk[8];
 #pragma unroll
-        for (int q = 8; q < W; ++q) sk[q - 8] = (T)s[pf.col(q)];
+        for (int q = 8; q < W; ++q) sk[q - 8] = NLMC_SPIN(pf.col(q));
 #pragma unroll
         for (int q = 8; q < W; ++q) {
             xs = fma_rn(pf.val(q), sk[q - 8], xs);
@@ -568,6 +581,8 @@ __global__ void k_sweep_philox(SweepArgs a)
     extern __shared__ __align__(16) unsigned char lds_raw[];
     ChainCtx x;
     chain_load(a, lds_raw, x);
+    if ((unsigned)reinterpret_cast<size_t>(lds_raw) != 0u)   // low word of a generic LDS address = LDS offset
+        __builtin_trap();      // update_spin addresses spins as LDS offset == column index
     const int n = x.n, tid = x.tid, nt = x.nt, c = x.c;
     T *ur = reinterpret_cast<T *>(lds_raw + a.lds_u_off);
     int *loff = reinterpret_cast<int *>(lds_raw + a.lds_loff_off);

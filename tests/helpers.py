@@ -52,3 +52,20 @@ def draw_stream(R, S, N):
             perm[c, t] = np.random.permutation(N)
             u[c, t] = np.random.rand(N)
     return perm, u
+
+
+class DeviceBuffer:
+    """A float64 device buffer allocated through the HIP runtime the engine already loaded (ctypes), so that tests can
+    hand a device pointer to the C-ABI without importing torch (a second HIP runtime in the same process)."""
+
+    def __init__(self, host_array):
+        import ctypes
+        self._hip = ctypes.CDLL("libamdhip64.so")
+        self._ct = ctypes
+        a = np.ascontiguousarray(host_array, dtype=np.float64)
+        self.ptr = ctypes.c_void_p()
+        assert self._hip.hipMalloc(ctypes.byref(self.ptr), ctypes.c_size_t(a.nbytes)) == 0
+        assert self._hip.hipMemcpy(self.ptr, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(a.nbytes), 1) == 0   # H2D
+
+    def free(self):
+        self._hip.hipFree(self.ptr)

