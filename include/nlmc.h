@@ -120,6 +120,10 @@ int nlmc_pt_apply_swap(nlmc_ctx *ctx, int ladder, int slot_a, int slot_b);
  *   own current energies (single GPU).  out_pairs [n_ladders][n_pairs][2] slots, out_accepted [n_ladders][n_pairs]. */
 int nlmc_pt_swap_philox(nlmc_ctx *ctx, uint32_t round, uint64_t seed, int n_pairs, const double *energies_all_dev,
                         int32_t *out_pairs, uint8_t *out_accepted);
+/* Optional: the pair selection depends on the RNG only, so the selections of rounds [round0, round0+n_rounds) can be
+ * computed ahead of time (one wave per round and ladder).  Later nlmc_pt_swap_philox calls in that range with the same
+ * seed and n_pairs are left with the parallel acceptance test.  Results are identical with or without a plan. */
+int nlmc_pt_plan(nlmc_ctx *ctx, uint32_t round0, int n_rounds, uint64_t seed, int n_pairs);
 
 /* Houdayer iso-cluster move (NPT/apt_ICM.py:116-143, 215-246) between the current states of local chains a and
  * b: connected components of the disagreement sub-graph, pick component number `pick_index mod n_components`

@@ -93,7 +93,11 @@ struct nlmc_ctx {
     double pt_tab_temp_x = 1.0;
     std::vector<double> beta_list;
     DevBuf<double> pt_tab, pt_beta;
-    DevBuf<int32_t> slot_of_chain, chain_of_slot, pt_pairs, pt_status;
+    DevBuf<int32_t> slot_of_chain, chain_of_slot, pt_pairs, pt_status, pt_plan_pairs, pt_plan_ok;
+    bool pt_plan_valid = false;
+    uint32_t pt_plan_round0 = 0;
+    int pt_plan_rounds = 0, pt_plan_npairs = 0;
+    uint64_t pt_plan_seed = 0;
     DevBuf<uint8_t> pt_acc;
     // ICM
     DevBuf<int32_t> icm_label, icm_info, icm_pairs;
@@ -518,7 +522,7 @@ void nlmc_destroy(nlmc_ctx *c)
     c->keys.release(); c->strace.release(); c->cfg.release(); c->scratch.release(); c->plan.release();
     c->pt_tab.release(); c->pt_beta.release();
     c->slot_of_chain.release(); c->chain_of_slot.release(); c->pt_pairs.release(); c->pt_status.release();
-    c->pt_acc.release(); c->icm_label.release(); c->icm_info.release(); c->icm_pairs.release();
+    c->pt_acc.release(); c->pt_plan_pairs.release(); c->pt_plan_ok.release(); c->icm_label.release(); c->icm_info.release(); c->icm_pairs.release();
     delete c;
 }
 
@@ -798,6 +802,7 @@ int nlmc_pt_init(nlmc_ctx *c, int ladder_len, const double *beta_list)
     HIP_TRY(c, hipSetDevice(c->device));
     c->ladder_len = ladder_len;
     c->pt_tab_valid = false;
+    c->pt_plan_valid = false;
     c->beta_list.assign(beta_list, beta_list + ladder_len);
     const int G = c->n_chains_global;
     HIP_TRY(c, c->pt_tab.reserve((size_t)ladder_len * 2));
@@ -812,6 +817,29 @@ int nlmc_pt_init(nlmc_ctx *c, int ladder_len, const double *beta_list)
     HIP_TRY(c, hipMemcpy(c->chain_of_slot.p, ident.data(), sizeof(int32_t) * G, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->pt_beta.p, beta_list, sizeof(double) * ladder_len, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemset(c->pt_status.p, 0, sizeof(int32_t)));
+    return NLMC_OK;
+}
+
+int nlmc_pt_plan(nlmc_ctx *c, uint32_t round0, int n_rounds, uint64_t seed, int n_pairs)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (c->ladder_len == 0) return fail(c, NLMC_ERR_STATE, "nlmc_pt_plan: call nlmc_pt_init first");
+    const int L = c->ladder_len, nl = c->n_chains_global / L;
+    if (n_rounds < 0 || n_pairs < 0 || n_pairs > std::max(0, L - 1)) return fail(c, NLMC_ERR_ARG, "Cannot find non-overlapping pairs.");
+    if (L > 4096) return fail(c, NLMC_ERR_UNSUPPORTED, "nlmc_pt_plan: ladder_len > 4096");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->pt_plan_valid = false;
+    if (n_rounds == 0 || n_pairs == 0) return NLMC_OK;
+    HIP_TRY(c, c->pt_plan_pairs.reserve((size_t)n_rounds * nl * n_pairs * 2));
+    HIP_TRY(c, c->pt_plan_ok.reserve((size_t)n_rounds * nl));
+    PtSelectArgs a{};
+    a.ladder_len = L; a.n_pairs = n_pairs; a.n_ladders = nl; a.round0 = round0;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.plan_pairs = c->pt_plan_pairs.p; a.plan_ok = c->pt_plan_ok.p;
+    hipLaunchKernelGGL(k_pt_select, dim3(n_rounds * nl), dim3(64), 0, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    c->pt_plan_valid = true;
+    c->pt_plan_round0 = round0; c->pt_plan_rounds = n_rounds; c->pt_plan_npairs = n_pairs; c->pt_plan_seed = seed;
     return NLMC_OK;
 }
 
@@ -879,6 +907,12 @@ int nlmc_pt_swap_philox(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs,
     a.escale = c->escale;
     a.slot_of_chain = c->slot_of_chain.p; a.chain_of_slot = c->chain_of_slot.p;
     a.out_pairs = c->pt_pairs.p; a.out_acc = c->pt_acc.p; a.status = c->pt_status.p;
+    if (c->pt_plan_valid && c->pt_plan_seed == seed && c->pt_plan_npairs == n_pairs && round >= c->pt_plan_round0 &&
+        round < c->pt_plan_round0 + (uint32_t)c->pt_plan_rounds) {
+        const size_t r = round - c->pt_plan_round0;
+        a.plan_pairs = c->pt_plan_pairs.p + r * (size_t)nl * n_pairs * 2;
+        a.plan_ok = c->pt_plan_ok.p + r * (size_t)nl;
+    }
     hipLaunchKernelGGL(k_pt_swap, dim3(nl), dim3(64), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     if (out_pairs || out_accepted) {

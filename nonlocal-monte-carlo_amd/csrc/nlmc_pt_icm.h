@@ -25,6 +25,8 @@ struct PtSwapArgs {
     int32_t *out_pairs;         // [n_ladders][n_pairs][2]
     uint8_t *out_acc;           // [n_ladders][n_pairs]
     int32_t *status;            // sticky: 1 = "Cannot find non-overlapping pairs."
+    const int32_t *plan_pairs;  // this round's planned selection [n_ladders][n_pairs][2] or nullptr
+    const int32_t *plan_ok;     // [n_ladders]
 };
 
 // position of the r-th (0-based) set bit of w (r < popcount(w)): binary search on popcounts
@@ -44,17 +46,19 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long w, int r)
 // the pick.  The availability set lives in registers: lane l holds pairs [64 l, 64 l + 64) as a bit mask, the pick is
 // located with a wave prefix sum of popcounts (ladder_len <= 4096).  Acceptance: u < min(1, exp(dBeta dE))
 // (NPT/npt.py:668-671), one lane per selected pair.
-__global__ void k_pt_swap(PtSwapArgs a)
+// Pair selection of one (round, ladder) by one wave -> pairs[n_pairs][2] (slot indices), returns 0 on exhaustion.
+// The selection depends on the RNG only (never on energies or states), so whole runs can be planned ahead
+// (k_pt_select, one wave per round and ladder) and the per-round kernel is left with the parallel acceptance test.
+__device__ __forceinline__ int pt_select_pairs(int L, int n_pairs, uint32_t round, uint32_t g, uint32_t seed_lo,
+                                               uint32_t seed_hi, int32_t *pairs, int lane)
 {
-    const int L = a.ladder_len, g = blockIdx.x, lane = threadIdx.x;     // blockDim.x == 64
     const int npairs_all = L - 1;
     const int rem = npairs_all - lane * 64;
     unsigned long long word = rem >= 64 ? ~0ull : (rem > 0 ? ((1ull << rem) - 1ull) : 0ull);
-    int32_t *pairs = a.out_pairs + (size_t)g * a.n_pairs * 2;
-    int cnt = npairs_all, good = 1;
-    for (int p = 0; p < a.n_pairs; ++p) {
-        if (cnt == 0) { good = 0; break; }
-        const uint32_t r = philox4x32_10((uint32_t)p, a.round, (uint32_t)g, NLMC_TAG_PAIR, a.seed_lo, a.seed_hi).x;
+    int cnt = npairs_all;
+    for (int p = 0; p < n_pairs; ++p) {
+        if (cnt == 0) return 0;
+        const uint32_t r = philox4x32_10((uint32_t)p, round, g, NLMC_TAG_PAIR, seed_lo, seed_hi).x;
         const int idx = (int)(((unsigned long long)r * (unsigned long long)cnt) >> 32);
         const int pc = __popcll(word);
         int incl = pc;
@@ -76,12 +80,47 @@ __global__ void k_pt_swap(PtSwapArgs a)
         for (int o = 32; o > 0; o >>= 1) cleared += __shfl_xor(cleared, o, 64);
         cnt -= cleared;
     }
+    return 1;
+}
+
+struct PtSelectArgs {
+    int ladder_len, n_pairs, n_ladders;
+    uint32_t round0, seed_lo, seed_hi;
+    int32_t *plan_pairs;        // [n_rounds][n_ladders][n_pairs][2]
+    int32_t *plan_ok;           // [n_rounds][n_ladders]
+};
+
+__global__ void k_pt_select(PtSelectArgs a)      // grid = n_rounds * n_ladders, block = 64
+{
+    const int r = blockIdx.x / a.n_ladders, g = blockIdx.x % a.n_ladders, lane = threadIdx.x;
+    int32_t *pairs = a.plan_pairs + (size_t)blockIdx.x * a.n_pairs * 2;
+    const int ok = pt_select_pairs(a.ladder_len, a.n_pairs, a.round0 + (uint32_t)r, (uint32_t)g, a.seed_lo, a.seed_hi, pairs, lane);
+    if (lane == 0) a.plan_ok[blockIdx.x] = ok;
+}
+
+// One wave per ladder.  Pair selection restates select_non_overlapping_pairs (NPT/npt.py:514-533): repeatedly pick
+// uniformly among the still-available adjacent pairs (ascending list), then drop the pairs that share a replica with
+// the pick.  The availability set lives in registers: lane l holds pairs [64 l, 64 l + 64) as a bit mask, the pick is
+// located with a wave prefix sum of popcounts (ladder_len <= 4096).  Acceptance: u < min(1, exp(dBeta dE))
+// (NPT/npt.py:668-671), one lane per selected pair.
+__global__ void k_pt_swap(PtSwapArgs a)
+{
+    const int L = a.ladder_len, g = blockIdx.x, lane = threadIdx.x;     // blockDim.x == 64
+    int32_t *pairs = a.out_pairs + (size_t)g * a.n_pairs * 2;
+    int good;
+    if (a.plan_pairs) {                                                  // selection planned ahead
+        const int32_t *src = a.plan_pairs + (size_t)g * a.n_pairs * 2;
+        good = a.plan_ok[g];
+        if (good) for (int p = lane; p < 2 * a.n_pairs; p += 64) pairs[p] = src[p];
+    } else {
+        good = pt_select_pairs(L, a.n_pairs, a.round, (uint32_t)g, a.seed_lo, a.seed_hi, pairs, lane);
+    }
     if (!good) {
         if (lane == 0) atomicExch(a.status, 1);
         for (int p = lane; p < a.n_pairs; p += 64) { a.out_acc[(size_t)g * a.n_pairs + p] = 0; pairs[2 * p] = pairs[2 * p + 1] = -1; }
         return;
     }
-    __syncthreads();      // pairs[] written by lane 0 are read by all lanes below
+    __syncthreads();      // pairs[] written above are read by all lanes below
     const double inv = __longlong_as_double((long long)(1023 - a.escale) << 52);
     for (int p = lane; p < a.n_pairs; p += 64) {
         const int i = pairs[2 * p];

@@ -46,8 +46,12 @@ class ShardedTempering:
     def set_spins(self, spins_global):
         self.eng.set_spins(np.asarray(spins_global)[self.base:self.base + self.count])
 
-    def plan(self, n_sweeps):
+    def plan(self, n_sweeps, n_rounds=0):
+        """Build the level schedules of the next n_sweeps sweeps and the pair selections of the next n_rounds swap
+        rounds ahead of time (both depend on the RNG only)."""
         self.eng.plan_philox(self.sweeps_done, n_sweeps, self.seed, precision=self.precision)
+        if n_rounds > 0 and self.n_pairs > 0 and hasattr(self.eng, "pt_plan"):
+            self.eng.pt_plan(self.rounds_done, n_rounds, self.seed, self.n_pairs)
 
     def round(self, n_sweeps, want_log=False):
         """`n_sweeps` sweeps of every local chain at its ladder temperature, then one swap attempt round."""

@@ -198,6 +198,9 @@ class Engine:
                                              _abi.ptr(acc)))
         return pairs, acc
 
+    def pt_plan(self, round0, n_rounds, seed, n_pairs):
+        self._ck(self._L.nlmc_pt_plan(self._ctx, int(round0), int(n_rounds), int(seed), int(n_pairs)))
+
     # -- iso-cluster move -------------------------------------------------------------------------------
     def icm_components(self, chain_a, chain_b):
         out = ctypes.c_int32(0)

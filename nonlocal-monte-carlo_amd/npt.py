@@ -243,6 +243,8 @@ class NPT(Common):
             eng.pt_init(beta_list)
             if rounds * S > 0:
                 eng.plan_philox(self._sweep_counter, rounds * S, self.seed)
+            if self.num_swapping_pairs > 0:
+                eng.pt_plan(0, rounds, self.seed, self.num_swapping_pairs)
             pairs_log, acc_log = [], []
             last = None
             slots_last = np.arange(G, dtype=np.int32) % R

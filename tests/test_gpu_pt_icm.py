@@ -23,6 +23,7 @@ def test_pt_swap_rounds_match_restatement(product):
         eng.pt_init(betas)
         slots = eng.pt_slots()
         assert np.array_equal(slots, np.arange(G) % L)
+        eng.pt_plan(2, 3, 77, n_pairs)          # rounds 2..4 use planned selections: results must not change
         for rnd in range(6):
             eng.sweep_philox(3, 77, sweep0=3 * rnd, beta=None)
             E = eng.energy()
