@@ -14,3 +14,5 @@ from .nmc import NMC  # noqa: F401
 from .npt import NPT  # noqa: F401
 from .apt_ICM import APT_ICM  # noqa: F401
 from . import distributed  # noqa: F401
+from .apt_preprocessor import APT_preprocessor  # noqa: F401
+from . import instances  # noqa: F401

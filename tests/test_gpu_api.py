@@ -5,6 +5,7 @@ energies within 1e-10*max(1,|E|).  These tests read like the reference's own uni
 NPT/unittests/test_npt.py, NPT/unittests/test_apt_ICM.py) with numerical assertions added.
 """
 import contextlib
+import os
 import io
 import random
 
@@ -212,3 +213,57 @@ def test_known_answer_ground_states(product):
     s = (2 * np.array(tok[3:3 + 128], dtype=int) - 1).astype(np.int8)
     with product.Engine(-W, -hf, 1) as eng:
         assert abs(eng.energy_of(s[None])[0] - e_gs) < 1e-5
+
+
+def test_apt_preprocessor_run(product, tmp_path, monkeypatch):
+    """NPT/unittests/test_apt_preprocessor.py with numbers: beta / sigma lists equal the reference's."""
+    g = golden("apt_preprocessor_pmj16")
+    J = sp.csr_matrix((g["data"], g["indices"], g["indptr"]), shape=(int(g["N"]),) * 2)
+    monkeypatch.chdir(tmp_path)
+    obj = product.APT_preprocessor(J, g["h"].reshape(-1, 1).copy())
+    np.random.seed(int(g["seed"]))
+    with quiet():
+        beta, sigma = obj.run(num_sweeps_MCMC=int(g["num_sweeps_MCMC"]), num_sweeps_read=int(g["num_sweeps_read"]),
+                              num_rng=int(g["num_rng"]), beta_start=float(g["beta_start"]), alpha=float(g["alpha"]),
+                              sigma_E_val=float(g["sigma_E_val"]), beta_max=float(g["beta_max"]), use_hash_table=0,
+                              num_cores=1)
+    assert isinstance(beta, list) and isinstance(sigma, list)
+    assert os.path.exists("beta_list_python.npy") and os.path.exists("sigma_list_python.npy")
+    assert np.allclose(beta, g["beta"], rtol=1e-9, atol=0)
+    assert np.allclose(sigma, g["sigma"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(np.load("beta_list_python.npy"), g["beta"], rtol=1e-9)
+    obj2 = product.APT_preprocessor(J, g["h"].reshape(-1, 1).copy())
+    with pytest.raises(ValueError):                       # NPT/unittests/test_apt_preprocessor.py: negative sweeps
+        obj2.run(num_sweeps_MCMC=-100, num_sweeps_read=10, num_rng=2)
+
+
+def test_npt_philox_device_resident_on_dcl_instance(product):
+    """Throughput path end to end on a bundled instance with a known answer (DCL C8/00, min_energy in 00_sol.txt):
+    32-rung ladder, label-exchange swaps on the device; deterministic for a fixed seed."""
+    from conftest import GOLDEN
+    inst_dir = os.path.join(GOLDEN, "instances")
+    W, h = product.instances.txt_to_A_DCL(os.path.join(inst_dir, "DCL_C8__00.txt"))
+    sol = dict(line.split() for line in open(os.path.join(inst_dir, "DCL_C8__00_sol.txt")) if len(line.split()) == 2)
+    e_gs = float(sol["min_energy"])
+    J = -W                                            # NMC/examples/DCL_example.py: J = -W, h = -h
+    nf = abs(J).max()
+    R = 32
+    betas = np.geomspace(0.2, 6.0, R)
+    obj = product.NPT(J, -h.reshape(-1), rng="philox", seed=11)
+    with quiet():
+        M, Energy = obj.run(betas, R, [False] * R, num_sweeps_MCMC=3000, num_sweeps_read=3000, num_swap_attempts=100,
+                            num_swapping_pairs=10)
+    N = J.shape[0]
+    assert M.shape == (N * R, 30) and Energy.shape == (R,)
+    assert set(np.unique(M)) <= {-1.0, 1.0}
+    best = Energy.min() * nf
+    # the file prints couplings with 5 decimals (-0.14286 for -1/7), so energies carry ~1e-5 relative rounding
+    assert best >= e_gs - 1e-5 * abs(e_gs) - 1e-9     # nothing can beat the known optimum
+    assert best <= 0.97 * e_gs, (best, e_gs)          # and the ladder gets within 3 % of it in 3000 sweeps (it finds it)
+    assert obj.swap_accepted.mean() > 0.05
+    # same seed -> same bits
+    obj2 = product.NPT(J, -h.reshape(-1), rng="philox", seed=11)
+    with quiet():
+        M2, E2 = obj2.run(betas, R, [False] * R, num_sweeps_MCMC=3000, num_sweeps_read=3000, num_swap_attempts=100,
+                          num_swapping_pairs=10)
+    assert np.array_equal(M, M2) and np.array_equal(Energy, E2)
