@@ -59,7 +59,7 @@ struct nlmc_ctx {
     // schedule scratch (per call) and plan cache (persistent)
     struct Sched {            // one set of level-schedule buffers (per-call scratch, or the persistent plan)
         DevBuf<int2> order, head32;
-        DevBuf<int32_t> lvl_off, nlev, ellc64;
+        DevBuf<int32_t> lvl_off, nlev, hi_max, ellc64;
         DevBuf<EdgeF> ell32;
         DevBuf<double> ellv64, headh64;
         hipError_t reserve(size_t orders, size_t n, int mode /*0 none, 1 f32, 2 f64*/)
@@ -68,6 +68,7 @@ struct nlmc_ctx {
             if ((e = order.reserve(orders * n)) != hipSuccess) return e;
             if ((e = lvl_off.reserve(orders * (n + 1))) != hipSuccess) return e;
             if ((e = nlev.reserve(orders)) != hipSuccess) return e;
+            if ((e = hi_max.reserve(orders)) != hipSuccess) return e;
             if (mode == 1) {
                 if ((e = head32.reserve(orders * n)) != hipSuccess) return e;
                 if ((e = ell32.reserve(orders * n * NLMC_ELL_W32)) != hipSuccess) return e;
@@ -78,7 +79,7 @@ struct nlmc_ctx {
             }
             return hipSuccess;
         }
-        void release() { order.release(); head32.release(); lvl_off.release(); nlev.release(); ellc64.release(); ell32.release(); ellv64.release(); headh64.release(); }
+        void release() { order.release(); head32.release(); lvl_off.release(); nlev.release(); hi_max.release(); ellc64.release(); ell32.release(); ellv64.release(); headh64.release(); }
     };
     Sched scratch, plan;
     int plan_precision = 0;
@@ -201,6 +202,7 @@ int run_levelize(nlmc_ctx *c, int n_orders, const uint32_t *keys_in, int per_cha
     a.ord2 = sc.order.p;
     a.lvl_off = sc.lvl_off.p;
     a.nlev = sc.nlev.p;
+    a.hi_max = sc.hi_max.p;
     if (ell_mode == 1) { a.ell32 = sc.ell32.p; a.head32 = sc.head32.p; }
     if (ell_mode == 2) { a.ellc64 = sc.ellc64.p; a.ellv64 = sc.ellv64.p; a.headh64 = sc.headh64.p; }
     const size_t lds_one = (size_t)(c->n + 2) * 4 + (((size_t)c->n * 2 + 3) / 4) * 4;
@@ -314,6 +316,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         a.ord2 = sc.order.p + o0 * n;
         a.lvl_off = sc.lvl_off.p + o0 * (size_t)(n + 1);
         a.nlev = sc.nlev.p + o0;
+        a.hi_max = sc.hi_max.p + o0;
         if (ell_mode == 1) { a.ell32 = sc.ell32.p + o0 * (size_t)n * NLMC_ELL_W32; a.head32 = sc.head32.p + o0 * n; }
         if (ell_mode == 2) {
             a.ellc64 = sc.ellc64.p + o0 * (size_t)n * NLMC_ELL_W;

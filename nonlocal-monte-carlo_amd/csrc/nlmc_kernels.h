@@ -42,6 +42,7 @@ struct LevelizeArgs {
     int2 *ord2;           // [n_orders][n]  { k | deg << 16, row start }
     int32_t *lvl_off;     // [n_orders][n+1]
     int32_t *nlev;        // [n_orders]
+    int32_t *hi_max;      // [n_orders] largest number of long rows (> 8 entries) at the front of any level
     // optional packed per-order schedule in ELL form (slot-major, position-minor) so that the sweep kernel's
     // loads are fully coalesced: lane i of a level reads slot q at [(o*8+q)*n + i]
     EdgeF *ell32;         // [n_orders][8][n][2]  first 16 entries of row k(i) as 8 planes of 2 entries (16 B),
@@ -52,7 +53,9 @@ struct LevelizeArgs {
     double *headh64;      // [n_orders][n]
 };
 #define NLMC_ELL_W 8          // packed row window, fp64 path
+#ifndef NLMC_ELL_W32
 #define NLMC_ELL_W32 16       // packed row window, fp32 path: covers every row of a degree-6 random graph (max ~16)
+#endif
 
 __device__ __forceinline__ bool precedes(uint32_t kj, int j, uint32_t kk, int k) { return kj < kk || (kj == kk && j < k); }
 
@@ -147,10 +150,24 @@ __global__ void k_levelize(LevelizeArgs a)
     // placement (intra-level order is irrelevant: same-level spins are independent)
     int2 *ord = a.ord2 + (size_t)o * n;
     uint32_t *back = reinterpret_cast<uint32_t *>(lds_raw + (size_t)(n + 2) * 4 + (((size_t)n * 2 + 3) / 4) * 4);
+    __shared__ int sh_himax;
+    if (tid == 0) sh_himax = 0;
     if (a.two_sided) {
+        // long rows per level (they go to the FRONT of their level): the sweep kernel lets only the waves that can
+        // hold one issue the loads of the second half of the row window
+        for (int l = tid; l < nl; l += nt) back[l] = 0u;
+        __syncthreads();
+        for (int k = tid; k < n; k += nt)
+            if (a.g.rowptr[k + 1] - a.g.rowptr[k] > 8) atomicAdd(&back[lvl[k]], 1u);
+        __syncthreads();
+        int hm = 0;
+        for (int l = tid; l < nl; l += nt) hm = max(hm, (int)back[l]);
+        if (hm) atomicMax(&sh_himax, hm);
+        __syncthreads();
         for (int l = tid; l < nl; l += nt) back[l] = (l + 1 < nl) ? cnt[l + 1] : (uint32_t)n;   // end of level l
         __syncthreads();
     }
+    if (tid == 0) a.hi_max[o] = a.two_sided ? sh_himax : n;
     for (int k = tid; k < n; k += nt) {
         const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
         uint32_t pos;
@@ -200,7 +217,7 @@ struct SweepArgs {
     double temp_x;
     // schedule: ord2[o][i] = { k | deg << 16, row start }, lvl_off[o][0..nlev], nlev[o]
     const int2 *ord2;
-    const int32_t *lvl_off, *nlev;
+    const int32_t *lvl_off, *nlev, *hi_max;
     const EdgeF *ell32;       // packed schedule (philox kernels), see LevelizeArgs: [o][4][n] int4 planes
     const int2 *head32;
     const int32_t *ellc64;
@@ -402,13 +419,14 @@ template <> struct Pf<float> {
             head = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(ph), 0, n * 8, 0x00020000);
         }
     };
+    template <bool TAIL>
     __device__ __forceinline__ void issue(const View &v, int i, bool valid)
     {
         const int oob = 0x7FF00000;                      // past both buffers even after adding the plane offsets
         const int o16 = valid ? i * 16 : oob;
         hd = __builtin_amdgcn_raw_buffer_load_b64(v.head, valid ? i * 8 : oob, 0, 0);
 #pragma unroll
-        for (int q = 0; q < W / 2; ++q)
+        for (int q = 0; q < (TAIL ? W / 2 : 4); ++q)
             pk[q] = __builtin_amdgcn_raw_buffer_load_b128(v.ell, o16 + q * v.plane_bytes, 0, 0);
     }
     __device__ __forceinline__ void wait(bool) {}
@@ -438,6 +456,7 @@ template <> struct Pf<double> {
             po = a.ord2 + oid * n;
         }
     };
+    template <bool TAIL>
     __device__ __forceinline__ void issue(const View &v, int i, bool valid)
     {
         const int ic = valid ? i : 0;
@@ -475,7 +494,7 @@ __device__ __forceinline__ double fma_rn(double a, double b, double c) { return 
 
 // Heat-bath update of one spin from a prefetched schedule item.  J*s is exact (s = +-1), so fma(J, s, x) == x + J*s;
 // the zero-padded slots add +-0 and leave x unchanged, which keeps the oracle's row-order sum bit for bit.
-template <typename T, bool DIAG>
+template <typename T, bool DIAG, bool TAIL>
 __device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, const T *ur, const Pf<T> &pf, size_t oid, int i,
                                             T cb0, T cb1, double esc)
 {
@@ -505,7 +524,7 @@ __device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, con
         xs = fma_rn(pf.val(q), sj[q], xs);
         if (DIAG) { const T nd = fma_rn(pf.val(q), sj[q], xd); xd = (q < deg && pf.col(q) == k) ? nd : xd; }
     }
-    if (W > 8 && __ballot(deg > 8) != 0ull) {  // second half of the packed window: only waves holding a long row
+    if (TAIL && W > 8 && __ballot(deg > 8) != 0ull) {  // second half of the packed window: only waves holding a long row
         T sk[8];
 #pragma unroll
         for (int q = 8; q < W; ++q) sk[q - 8] = NLMC_SPIN(pf.col(q));
@@ -545,7 +564,7 @@ __device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, con
     }
 #ifdef NLMC_STAMPS
     NLMC_CLK(u4)
-    if (x.st) { x.st[0] += u1 - u0; x.st[1] += u2 - u1; x.st[2] += u3 - u2; x.st[3] += u4 - u3; }
+    if (x.st) { x.st[0] += u1 - u0; x.st[1] += u2 - u1; x.st[2] += u3 - u2; x.st[3] += u4 - u3; x.st[4] += 1; }
 #endif
 }
 
@@ -575,6 +594,41 @@ __device__ __forceinline__ void fill_uniforms(double *ur, int n, uint32_t tt, ui
     }
 }
 
+// The pipelined level loop of one sweep (see k_sweep_philox).  TAIL: this wave may hold rows longer than 8 entries and
+// therefore also loads / folds the second half of the 16-entry row window.
+template <typename T, bool DIAG, bool TAIL>
+__device__ __forceinline__ void run_levels(const SweepArgs &a, ChainCtx &x, const T *ur, const int *loff, size_t so, int nl,
+                                           T cb0, T cb1, double esc)
+{
+    // software pipeline over levels: while level l is computed, the schedule items of level l+1 are in flight.
+    // Their addresses depend only on the level offsets (LDS), never on spin values, and the schedule was built with
+    // level_cap == blockDim.x: at most one spin per thread and level.
+    const int n = x.n, tid = x.tid;
+    Pf<T> pfa, pfb;                // ping-pong (manual 2x unroll: no register rotation)
+    bool va, vb;                   // lane has an item in the level held by pfa / pfb
+    int ia, ib;
+    typename Pf<T>::View view;
+    view.bind(a, so, n);
+    auto fetch = [&](int l, Pf<T> &p, bool &valid, int &ic) {
+        const int lc = min(l, nl - 1);
+        const int i = loff[lc] + tid;
+        valid = (l < nl) && (i < loff[lc + 1]);
+        ic = valid ? i : 0;
+        p.template issue<TAIL>(view, i, valid);      // idle lanes: out-of-range no-ops
+    };
+    fetch(0, pfa, va, ia);
+    for (int l = 0; l < nl; l += 2) {
+        fetch(l + 1, pfb, vb, ib);
+        if (va) update_spin<T, DIAG, TAIL>(a, x, ur, pfa, so, ia, cb0, cb1, esc);
+        __syncthreads();
+        if (l + 1 < nl) {
+            fetch(l + 2, pfa, va, ia);
+            if (vb) update_spin<T, DIAG, TAIL>(a, x, ur, pfb, so, ib, cb0, cb1, esc);
+            __syncthreads();
+        }
+    }
+}
+
 template <typename T, bool DIAG>
 __global__ void k_sweep_philox(SweepArgs a)
 {
@@ -591,8 +645,8 @@ __global__ void k_sweep_philox(SweepArgs a)
     const double esc = __longlong_as_double((long long)(1023 + a.escale) << 52);   // 2^escale
 
 #ifdef NLMC_STAMPS
-    long long st_fetch = 0, st_upd = 0, st_bar = 0, st_cnt = 0, st_fill = 0, st_epi = 0, st_wait = 0;
-    long long st_u[4] = {0, 0, 0, 0};
+    long long st_fill = 0, st_epi = 0;
+    long long st_u[5] = {0, 0, 0, 0, 0};      // update_spin: lds-gather, field, decide, energy+write, calls
     x.st = st_u;
     const long long st_begin = (long long)__builtin_readcyclecounter();
 #endif
@@ -618,56 +672,13 @@ __global__ void k_sweep_philox(SweepArgs a)
 
         const size_t so = (size_t)oid;
         if (fast) {
-            // software pipeline over levels: while level l is computed, the schedule items of level l+1 are in
-            // flight.  Their addresses depend only on the level offsets (LDS), never on spin values, and the
-            // schedule was built with level_cap == blockDim.x: at most one spin per thread and level.
-            Pf<T> pfa, pfb;                // ping-pong (manual 2x unroll: no register rotation)
-            bool va, vb, wa, wb;           // lane has an item / wave has any item (wave-uniform)
-            int ia, ib;
-            typename Pf<T>::View view;
-            view.bind(a, so, n);
-            auto fetch = [&](int l, Pf<T> &p, bool &valid, bool &wave_any, int &ic) {
-                const int lc = min(l, nl - 1);
-                const int i = loff[lc] + tid;
-                valid = (l < nl) && (i < loff[lc + 1]);
-                ic = valid ? i : 0;
-                wave_any = __ballot(valid) != 0ull;
-                p.issue(view, i, valid);
-            };
-            fetch(0, pfa, va, wa, ia);
-#ifdef NLMC_STAMPS
-            long long c0, c1, c2, c3;
-#endif
-            for (int l = 0; l < nl; l += 2) {
-                NLMC_CLK(c0)
-                fetch(l + 1, pfb, vb, wb, ib);
-                NLMC_CLK(c1)
-#ifdef NLMC_STAMPS
-                { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); long long cw; NLMC_CLK(cw) st_wait += cw - c1; }
-#endif
-                if (wa) { pfa.wait(wb); if (va) update_spin<T, DIAG>(a, x, ur, pfa, so, ia, cb0, cb1, esc); }
-                NLMC_CLK(c2)
-                __syncthreads();
-                NLMC_CLK(c3)
-#ifdef NLMC_STAMPS
-                st_fetch += c1 - c0; st_upd += c2 - c1; st_bar += c3 - c2; st_cnt += __ballot(va) != 0ull;
-#endif
-                if (l + 1 < nl) {
-                    NLMC_CLK(c0)
-                    fetch(l + 2, pfa, va, wa, ia);
-                    NLMC_CLK(c1)
-#ifdef NLMC_STAMPS
-                    { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); long long cw; NLMC_CLK(cw) st_wait += cw - c1; }
-#endif
-                    if (wb) { pfb.wait(wa); if (vb) update_spin<T, DIAG>(a, x, ur, pfb, so, ib, cb0, cb1, esc); }
-                    NLMC_CLK(c2)
-                    __syncthreads();
-                    NLMC_CLK(c3)
-#ifdef NLMC_STAMPS
-                    st_fetch += c1 - c0; st_upd += c2 - c1; st_bar += c3 - c2; st_cnt += __ballot(vb) != 0ull;
-#endif
-                }
-            }
+            // Rows longer than 8 entries sit at the front of their level (k_levelize), at most hi_max of them: only the
+            // waves whose lanes can hold one run the variant that also prefetches the second half of the row window.
+            // Two copies of the level loop, chosen per wave and sweep, keep the number of loads per stage STATIC in
+            // each copy (so hipcc emits counted vmcnt waits); both copies execute the same nl barriers.
+            const bool role_long = (Pf<T>::W > 8) && ((tid & ~63) < a.hi_max[oid]);
+            if (role_long) run_levels<T, DIAG, true>(a, x, ur, loff, so, nl, cb0, cb1, esc);
+            else run_levels<T, DIAG, false>(a, x, ur, loff, so, nl, cb0, cb1, esc);
         } else {
             // very deep schedules (dense graphs): plain level loop
             for (int l = 0; l < nl; ++l) {
@@ -676,9 +687,9 @@ __global__ void k_sweep_philox(SweepArgs a)
                     Pf<T> pe;
                     typename Pf<T>::View vw;
                     vw.bind(a, so, n);
-                    pe.issue(vw, i, true);
+                    pe.template issue<true>(vw, i, true);
                     pe.wait(false);
-                    update_spin<T, DIAG>(a, x, ur, pe, so, i, cb0, cb1, esc);
+                    update_spin<T, DIAG, true>(a, x, ur, pe, so, i, cb0, cb1, esc);
                 }
                 __syncthreads();
             }
@@ -694,9 +705,8 @@ __global__ void k_sweep_philox(SweepArgs a)
 #ifdef NLMC_STAMPS
     if (a.dbg && (tid & 63) == 0) {
         long long *d = a.dbg + ((size_t)c * 16 + (tid >> 6)) * 8;
-        d[0] = st_fetch; d[1] = st_upd; d[2] = st_bar; d[3] = st_cnt; d[4] = st_u[0]; d[5] = st_u[1];
-        d[2] = st_u[2]; d[0] = st_u[3];
-        d[6] = (long long)__builtin_readcyclecounter() - st_begin; d[7] = st_wait;
+        d[0] = st_u[0]; d[1] = st_u[1]; d[2] = st_u[2]; d[3] = st_u[3]; d[4] = st_u[4]; d[5] = st_fill;
+        d[6] = (long long)__builtin_readcyclecounter() - st_begin; d[7] = st_epi;
     }
 #endif
     chain_store(a, x);

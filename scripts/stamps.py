@@ -16,8 +16,10 @@ for r in range(3):
 eng.energy()
 eng.close()
 d = np.fromfile(os.environ["NLMC_STAMP_FILE"], dtype=np.int64).reshape(R, 16, 8)
-print("inside update_spin, s_memtime cycles per ACTIVE level (median over chains), lane 0 of each wave:")
-for w in (0, 1, 4, 8, 12, 15):
-    al = np.maximum(d[:, w, 3], 1)
-    f = lambda j: np.median(d[:, w, j] / al)
-    print(f" wave {w:2d}: lds-gather {f(4):7.0f}  field-fma {f(5):7.0f}  decide(exp2,ur,s[k]) {f(2):7.0f}  energy+write {f(0):7.0f}   update total {f(1):7.0f}")
+print("inside update_spin, s_memtime cycles per call (median over chains), lane 0 of each wave; sweep totals per wave:")
+for w in (0, 1, 3, 4, 8, 12, 15):
+    calls = np.maximum(d[:, w, 4], 1)
+    f = lambda j: np.median(d[:, w, j] / calls)
+    print(f" wave {w:2d}: lds-gather {f(0):6.0f}  field {f(1):6.0f}  decide {f(2):6.0f}  energy+write {f(3):6.0f}  | calls/sweep "
+          f"{np.median(d[:, w, 4]) / S:5.1f}  fill {np.median(d[:, w, 5]) / S:6.0f}  epilogue {np.median(d[:, w, 7]) / S:5.0f}  "
+          f"kernel cycles/sweep {np.median(d[:, w, 6]) / S:8.0f}")
