@@ -616,8 +616,23 @@ __device__ __forceinline__ void run_levels(const SweepArgs &a, ChainCtx &x, cons
         ic = valid ? i : 0;
         p.template issue<TAIL>(view, i, valid);      // idle lanes: out-of-range no-ops
     };
+    // Items fill the lanes of a level from 0, so wave w is idle in every level narrower than 64 w + 1; level widths
+    // shrink with depth, hence each wave has a LAST level with work.  Past it the wave only keeps the barrier count
+    // (second loop): no loads, no instructions -- a vector-memory instruction occupies the CU's address unit for
+    // ~11 cycles per wave even when every lane is out of range, and half of all wave-levels are idle ones.
+    int n_live = 0;
+    {
+        const int wbase = tid & ~63;
+        for (int l0 = 0; l0 < nl; l0 += 64) {
+            const int l = l0 + (tid & 63);
+            const bool has = (l < nl) && (loff[l + 1] - loff[l] > wbase);
+            const unsigned long long m = __ballot(has);
+            if (m) n_live = l0 + 64 - __clzll((long long)m);
+        }
+    }
     fetch(0, pfa, va, ia);
-    for (int l = 0; l < nl; l += 2) {
+    int l = 0;
+    for (; l < n_live; l += 2) {
         fetch(l + 1, pfb, vb, ib);
         if (va) update_spin<T, DIAG, TAIL>(a, x, ur, pfa, so, ia, cb0, cb1, esc);
         __syncthreads();
@@ -627,6 +642,8 @@ __device__ __forceinline__ void run_levels(const SweepArgs &a, ChainCtx &x, cons
             __syncthreads();
         }
     }
+    l = min(l, nl);
+    for (; l < nl; ++l) __syncthreads();       // retired: this wave has no item in any remaining level
 }
 
 template <typename T, bool DIAG>
