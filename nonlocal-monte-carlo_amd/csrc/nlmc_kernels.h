@@ -473,21 +473,21 @@ template <> struct Pf<double> {
     static __device__ __forceinline__ void tail(const CsrDev &g, int e, int &c, double &v) { c = g.col[e]; v = g.val64[e]; }
 };
 
-// -(ds) * x * 2^escale as an exact integer (== llrint of the fp64 product the oracle forms): for a float x the product
-// is mantissa << shift whenever shift >= 0, which integer ops deliver without the fp64 convert/round chain.
-__device__ __forceinline__ long long fixed_delta(float xt, int ds, double esc, int escale)
+// -(ds) * x * 2^escale as an exact integer (== llrint of the fp64 product the oracle forms).  For a float x and
+// ds = +-2 the product is mantissa << shift whenever 0 <= shift <= 38: integer ops, branch-free; `slow` flags the
+// lanes (denormal / tiny / huge x) that need the fp64 formula instead.
+__device__ __forceinline__ long long fixed_delta_fast(float xt, int ds, int escale, bool &slow)
 {
     const uint32_t b = __float_as_uint(xt);
     const int e = (int)((b >> 23) & 0xFFu);
-    const int sh = e - 150 + escale + ((ds == 2 || ds == -2) ? 1 : 0);
-    if (e != 0 && e != 255 && sh >= 0 && sh <= 38 && (ds == 2 || ds == -2 || ds == 1 || ds == -1)) {
-        const long long mag = (long long)((b & 0x7FFFFFu) | 0x800000u) << sh;
-        const bool neg = ((b >> 31) != 0u) == (ds < 0);      // sign(-ds * x)
-        return neg ? -mag : mag;
-    }
-    return __double2ll_rn(-(double)ds * (double)xt * esc);
+    const int sh = e - 149 + escale;                                   // (e - 150) + escale + 1  (|ds| == 2)
+    const bool ok = (e != 0) & (e != 255) & (sh >= 0) & (sh <= 38);
+    const long long mag = (long long)((b & 0x7FFFFFu) | 0x800000u) << (sh & 63);
+    const bool neg = ((b >> 31) != 0u) == (ds < 0);                     // sign(-ds * x)
+    slow = (ds != 0) & !ok;
+    return (ds != 0 && ok) ? (neg ? -mag : mag) : 0ll;
 }
-__device__ __forceinline__ long long fixed_delta(double xt, int ds, double esc, int) { return __double2ll_rn(-(double)ds * xt * esc); }
+__device__ __forceinline__ long long fixed_delta_slow(double xt, int ds, double esc) { return __double2ll_rn(-(double)ds * xt * esc); }
 
 __device__ __forceinline__ float fma_rn(float a, float b, float c) { return __fmaf_rn(a, b, c); }
 __device__ __forceinline__ double fma_rn(double a, double b, double c) { return __fma_rn(a, b, c); }
@@ -502,6 +502,8 @@ __device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, con
     const unsigned f = x.fl ? (unsigned)x.fl[k] : 0u;
     if (f >= 2u) return;                       // frozen
     int8_t *s = x.s;
+    const T uk = ur[k];                        // issued up front with the gathers: off the dependent chain
+    const int so = (int)s[k];
 #ifdef NLMC_STAMPS
     long long u0, u1, u2, u3, u4;
     NLMC_CLK(u0)
@@ -552,16 +554,22 @@ __device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, con
     NLMC_CLK(u2)
 #endif
     const T z = (f == 1u ? cb1 : cb0) * xf;
-    const int so = (int)s[k];
-    const int sn = accept_up(ur[k], z) ? 1 : -1;
+    const int sn = accept_up(uk, z) ? 1 : -1;
 #ifdef NLMC_STAMPS
     asm volatile("" :: "v"(sn));
     NLMC_CLK(u3)
 #endif
-    if (sn != so) {
-        x.e_loc += fixed_delta(x_true, sn - so, esc, a.escale);
-        s[k] = (int8_t)sn;
+    // straight-line tail: branches cost a wave far more than the handful of integer ops they would skip
+    const int ds = sn - so;                    // 0 or +-2 (spins are +-1 in this mode)
+    if constexpr (sizeof(T) == 4) {
+        bool slow;
+        long long d = fixed_delta_fast(x_true, ds, a.escale, slow);
+        if (__ballot(slow) != 0ull) { if (slow) d = fixed_delta_slow((double)x_true, ds, esc); }   // practically never
+        x.e_loc += d;
+    } else {
+        if (ds != 0) x.e_loc += fixed_delta_slow((double)x_true, ds, esc);
     }
+    s[k] = (int8_t)sn;
 #ifdef NLMC_STAMPS
     NLMC_CLK(u4)
     if (x.st) { x.st[0] += u1 - u0; x.st[1] += u2 - u1; x.st[2] += u3 - u2; x.st[3] += u4 - u3; x.st[4] += 1; }
@@ -609,12 +617,14 @@ __device__ __forceinline__ void run_levels(const SweepArgs &a, ChainCtx &x, cons
     int ia, ib;
     typename Pf<T>::View view;
     view.bind(a, so, n);
+    int lo_next = loff[0], hi_next = loff[min(1, nl)];      // offsets of the level the next fetch will load
     auto fetch = [&](int l, Pf<T> &p, bool &valid, int &ic) {
-        const int lc = min(l, nl - 1);
-        const int i = loff[lc] + tid;
-        valid = (l < nl) && (i < loff[lc + 1]);
+        const int i = lo_next + tid;
+        valid = (l < nl) && (i < hi_next);
         ic = valid ? i : 0;
         p.template issue<TAIL>(view, i, valid);      // idle lanes: out-of-range no-ops
+        lo_next = hi_next;                           // roll: the LDS read for level l+1 is consumed a stage later
+        hi_next = loff[min(l + 2, nl)];
     };
     // Items fill the lanes of a level from 0, so wave w is idle in every level narrower than 64 w + 1; level widths
     // shrink with depth, hence each wave has a LAST level with work.  Past it the wave only keeps the barrier count

@@ -39,7 +39,8 @@ class ShardedTempering:
         self.eng.pt_init(np.asarray(beta_list, dtype=np.float64))
         self.sweeps_done = 0
         self.rounds_done = 0
-        if self.world > 1:
+        self.collective = dist is not None          # also with a single rank: the launcher path stays exercised
+        if self.collective:
             self.e_local = torch.empty(self.count, dtype=torch.float64, device=device)
             self.e_all = torch.empty(self.G, dtype=torch.float64, device=device)
 
@@ -59,7 +60,7 @@ class ShardedTempering:
         self.sweeps_done += n_sweeps
         log = None
         if self.n_pairs > 0:
-            if self.world > 1:
+            if self.collective:
                 self.eng.energy_dev(self.e_local.data_ptr())           # tracked energies -> device/host buffer
                 self.dist.all_gather_into_tensor(self.e_all, self.e_local)   # the ONE collective of the round
                 log = self.eng.pt_swap_philox(self.rounds_done, self.seed, self.n_pairs,
@@ -72,7 +73,7 @@ class ShardedTempering:
     def gather_spins(self):
         """All chains' configurations on every rank (read-out only; not part of a round)."""
         loc = self.eng.get_spins()
-        if self.world == 1:
+        if not self.collective:
             return loc
         t = self.torch.from_numpy(loc.astype(np.int8)).to(self.e_all.device)
         out = self.torch.empty((self.G, loc.shape[1]), dtype=self.torch.int8, device=self.e_all.device)
