@@ -98,6 +98,8 @@ class APT_ICM(SweepMixin):
         R, K, N = num_replicas, self.num_subreplicas, inst.n
         S = self.num_sweeps_MCMC_per_swap
         beta_list = np.asarray(beta_list, dtype=np.float64)
+        if self.rng == "philox" and icm_feedback:
+            return self._run_device_resident(inst, beta_list, plot)
         numpy_mode = self.rng == "numpy"
         host_rng = None if numpy_mode else np.random.default_rng(self.seed)
         all_pairs = [(i, i + 1) for i in range(1, R)]
@@ -178,6 +180,71 @@ class APT_ICM(SweepMixin):
             eng_icm.close()
         self.swap_pairs = np.array(log_pairs, dtype=np.int32).reshape(-1, 2)
         self.swap_accepted = np.array(log_acc, dtype=np.int8)
+        print(f"\nLatest energy from each replica = {Energy}")
+        if plot:
+            self.plot_energies([self.replica_energy(M[r * N:(r + 1) * N, :], self.num_sweeps_read_per_swap)[1]
+                                for r in range(R)], beta_list)
+        return M, Energy
+
+    def _run_device_resident(self, inst, beta_list, plot):
+        """Throughput path (rng="philox", icm_feedback=True): every (sub-replica, replica) chain lives in ONE context,
+        laid out sub-replica-major so that each sub-replica's beta ladder is a block of consecutive chains.  Per round:
+        batched sweeps at the ladder temperatures -> iso-cluster moves between randomly paired sub-replicas of every
+        replica, acting on the CURRENT states (k_icm_components / k_icm_move, picks drawn on the device) -> label-
+        exchange swaps decided on the device for every sub-replica ladder.  Configurations never leave HBM until the
+        last round's trace is read out."""
+        R, K, N = self.num_replicas, self.num_subreplicas, inst.n
+        S, rounds = self.num_sweeps_MCMC_per_swap, int(self.num_swap_attempts)
+        G = K * R                                       # chain id = j * R + slot-holder index
+        host_rng = np.random.default_rng(self.seed)
+        eng = Engine(inst, None, G, device=self._cache.device)
+        try:
+            eng.set_spins(np.sign(2 * host_rng.random((G, N)) - 1).astype(np.int8))
+            eng.pt_init(beta_list)
+            if rounds * S > 0:
+                eng.plan_philox(self._sweep_counter, rounds * S, self.seed)
+            if self.num_swapping_pairs > 0 and rounds > 0:
+                eng.pt_plan(0, rounds, self.seed, self.num_swapping_pairs)
+            last, slots_last = None, np.arange(G, dtype=np.int32) % R
+            acc_log, icm_sizes = [], []
+            for ii in range(rounds):
+                is_last = ii == rounds - 1
+                if is_last:
+                    slots_last = eng.pt_slots()
+                o = eng.sweep_philox(S, self.seed, sweep0=self._sweep_counter + ii * S, beta=None,
+                                     record_stride=1 if is_last else 0)
+                if is_last:
+                    last = o["spins"]
+                # Houdayer: for every temperature slot pair up the K sub-replicas that currently hold it
+                slots = eng.pt_slots()
+                holder = np.empty((K, R), dtype=np.int64)              # holder[j, r] = chain of ladder j at slot r
+                for j in range(K):
+                    holder[j, slots[j * R:(j + 1) * R]] = j * R + np.arange(R)
+                pairs = []
+                for r in range(R):
+                    sh = host_rng.permutation(K)
+                    pairs += [(holder[sh[2 * p], r], holder[sh[2 * p + 1], r]) for p in range(K // 2)]
+                info = eng.icm_round_philox(np.array(pairs, dtype=np.int32), ii, self.seed, self.useKatzgraber, want_info=True)
+                icm_sizes.append(info[:, 1].copy())
+                if self.num_swapping_pairs > 0:
+                    _, a = eng.pt_swap_philox(ii, self.seed, self.num_swapping_pairs, want_log=True)
+                    acc_log.append(a)
+            self._sweep_counter += rounds * S
+            M = np.zeros((N * R, S * K))
+            Energy = np.zeros(R)
+            if last is not None and S > 0:
+                for j in range(K):
+                    for c in range(R):
+                        r = int(slots_last[j * R + c])
+                        M[r * N:(r + 1) * N, j * S:(j + 1) * S] = last[j * R + c].T
+                for r in range(R):
+                    Energy[r] = self.replica_energy(M[r * N:(r + 1) * N, :], self.num_sweeps_read_per_swap)[0]
+            self.final_energies = eng.energy()
+            self.final_slots = eng.pt_slots()
+            self.swap_accepted = np.concatenate([a.reshape(-1) for a in acc_log]).astype(np.int8) if acc_log else np.zeros(0, np.int8)
+            self.icm_cluster_sizes = np.concatenate(icm_sizes) if icm_sizes else np.zeros(0, np.int32)
+        finally:
+            eng.close()
         print(f"\nLatest energy from each replica = {Energy}")
         if plot:
             self.plot_energies([self.replica_energy(M[r * N:(r + 1) * N, :], self.num_sweeps_read_per_swap)[1]

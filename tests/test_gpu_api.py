@@ -267,3 +267,32 @@ def test_npt_philox_device_resident_on_dcl_instance(product):
         M2, E2 = obj2.run(betas, R, [False] * R, num_sweeps_MCMC=3000, num_sweeps_read=3000, num_swap_attempts=100,
                           num_swapping_pairs=10)
     assert np.array_equal(M, M2) and np.array_equal(Energy, E2)
+
+
+def test_apt_icm_philox_device_resident(product):
+    """rng="philox", icm_feedback=True: sweeps, iso-cluster moves and swaps all decided on the device.  Checks shape
+    contract, determinism, that the cluster moves actually fire, and that the ladder finds the Wishart ground state."""
+    import os
+    from conftest import GOLDEN
+    inst_dir = os.path.join(GOLDEN, "instances")
+    gs = {l.split()[0]: float(l.split()[1]) for l in open(os.path.join(inst_dir, "wishart_N10_a0.50__gs_energies.txt"))}
+    fn = "wishart_planting_N_10_alpha_0.50_inst_2.txt"
+    W, h = product.instances.txt_to_A_wishart(os.path.join(inst_dir, "wishart_N10_a0.50__" + fn))
+    J = (-W).toarray()
+    nf = np.max(np.abs(J))
+    betas = np.linspace(0.3, 3.0, 6)
+
+    def go():
+        obj = product.APT_ICM(J / nf, np.zeros(10), rng="philox", seed=77)
+        with quiet():
+            M, E = obj.run(betas, num_replicas=6, num_sweeps_MCMC=400, num_sweeps_read=400, num_swap_attempts=40,
+                           num_swapping_pairs=2, icm_feedback=True)
+        return obj, M, E
+    obj, M, E = go()
+    assert M.shape == (10 * 6, 10 * 10) and E.shape == (6,)
+    assert set(np.unique(M)) <= {-1.0, 1.0}
+    assert abs(E.min() * nf - gs[fn]) < 1e-9
+    assert obj.icm_cluster_sizes.max() > 0 and obj.swap_accepted.sum() > 0
+    assert sorted(obj.final_slots[:6]) == list(range(6))
+    _, M2, E2 = go()
+    assert np.array_equal(M, M2) and np.array_equal(E, E2)

@@ -124,3 +124,39 @@ def test_c2_size_nmc_phases_batched_restarts(product):
         assert np.array_equal(fin[c], s_fin)
         am = int(np.argmin(tr))
         assert o["argmin"][c] == am and np.array_equal(o["argmin_state"][c], M[am])
+
+
+def test_c5_size_icm_round(product):
+    """C5: N = 10^4, 256 chains = 128 sub-replica pairs, one batched iso-cluster round on the device; two pairs are
+    re-derived with the oracle's BFS (component count, picked size, resulting states), all energies re-synchronised."""
+    N, R = 10_000, 256
+    J, h = make_instance(N)
+    csr = oracle.Csr(J)
+    m0 = init_spins(R, N)
+    with product.Engine(J, h, R) as eng:
+        eng.set_spins(m0)
+        eng.sweep_philox(3, 5, beta=1.5)
+        before = eng.get_spins()
+        pairs = np.arange(R, dtype=np.int32).reshape(-1, 2)
+        info = eng.icm_round_philox(pairs, 9, 4242, katzgraber=True, want_info=True)
+        after = eng.get_spins()
+        E = eng.energy()
+    for p in (0, 127):
+        a, b = pairs[p]
+        cl = oracle.clusters(csr, before[a], before[b])
+        assert info[p, 0] == len(cl)
+        w = int(oracle.philox(int(a), 9, int(b), 5, 4242 & 0xFFFFFFFF, 4242 >> 32)[0])
+        pick = (w * len(cl)) >> 32
+        assert info[p, 1] == len(cl[pick])
+        ea, eb = before[a].copy(), before[b].copy()
+        if len(cl[pick]) > N // 2:
+            ea = -ea
+        else:
+            ea[cl[pick]], eb[cl[pick]] = before[b][cl[pick]], before[a][cl[pick]]
+        assert np.array_equal(after[a], ea) and np.array_equal(after[b], eb)
+        assert E[a] == oracle.energy(csr, h, ea) and E[b] == oracle.energy(csr, h, eb)
+    # Houdayer's move conserves the total energy of a pair when it exchanges a cluster (no global flip)
+    with product.Engine(J, h, R) as eng:
+        Eb = eng.energy_of(before)
+    swapped = info[:, 1] <= N // 2
+    assert np.allclose((E[0::2] + E[1::2])[swapped], (Eb[0::2] + Eb[1::2])[swapped], rtol=0, atol=1e-9)
