@@ -274,10 +274,14 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
     int cur = c->n_pad * (c->has_flags ? 2 : 1);
     cur = (cur + 15) / 16 * 16;
     const int lds_u_off = cur;
-    if (!stream_mode) cur += f64 ? ((n + 1) / 2 * 2) * 8 : ((n + 3) / 4 * 4) * 4;
-    cur = (cur + 15) / 16 * 16;
+    const int u_bytes = stream_mode ? 0 : ((f64 ? ((n + 1) / 2 * 2) * 8 : ((n + 3) / 4 * 4) * 4) + 15) / 16 * 16;
+    // second copy of the per-sweep uniforms / level offsets when it fits: lets the idle waves prepare sweep t+1 while
+    // wave 0 runs the narrow tail of sweep t
+    const bool dbuf = !stream_mode && (size_t)cur + 2 * (size_t)u_bytes + 2 * NLMC_LCAP * 4 + 32 <= (size_t)150 * 1024 &&
+                      !getenv("NLMC_NO_DBUF");
+    cur += u_bytes * (dbuf ? 2 : 1);
     const int lds_loff_off = cur;
-    if (!stream_mode) cur += NLMC_LCAP * 4;
+    if (!stream_mode) cur += NLMC_LCAP * 4 * (dbuf ? 2 : 1);
     const int lds_red_off = cur;
     const size_t lds = (size_t)cur + 16;
     const void *kfun = stream_mode ? reinterpret_cast<const void *>(k_sweep_stream)
@@ -342,9 +346,12 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         a.argmin = c->argmin.p;
         a.best = (want_min && o.out_argmin_state) ? c->best.p : nullptr;
 #ifdef NLMC_STAMPS
-        HIP_TRY(c, c->dbg.reserve((size_t)R * 16 * 8));
+        HIP_TRY(c, c->dbg.reserve((size_t)R * 16 * 8 + 96));
+        HIP_TRY(c, hipMemsetAsync(c->dbg.p, 0, ((size_t)R * 16 * 8 + 96) * sizeof(long long), c->stream));
         a.dbg = c->dbg.p;
 #endif
+        a.lds_u_stride = dbuf ? u_bytes : 0;
+        a.lds_loff_stride = dbuf ? NLMC_LCAP * 4 : 0;
         a.lds_flags_off = lds_flags_off; a.lds_u_off = lds_u_off; a.lds_loff_off = lds_loff_off; a.lds_red_off = lds_red_off;
         if (stream_mode)
             hipLaunchKernelGGL(k_sweep_stream, dim3(R), dim3(nt), lds, c->stream, a);
@@ -510,7 +517,7 @@ void nlmc_destroy(nlmc_ctx *c)
 #ifdef NLMC_STAMPS
     if (const char *fn = getenv("NLMC_STAMP_FILE")) {      // diagnostic build: dump the last launch's per-wave cycle sums
         if (c->dbg.p) {
-            std::vector<long long> hbuf((size_t)c->n_chains * 16 * 8);
+            std::vector<long long> hbuf((size_t)c->n_chains * 16 * 8 + 96);
             if (hipMemcpy(hbuf.data(), c->dbg.p, hbuf.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
                 if (FILE *f = fopen(fn, "wb")) { fwrite(hbuf.data(), sizeof(long long), hbuf.size(), f); fclose(f); }
             }

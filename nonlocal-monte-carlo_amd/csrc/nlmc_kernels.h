@@ -244,12 +244,14 @@ struct SweepArgs {
     int8_t *best;             // [n_chains][n_pad] or nullptr
     // LDS carve-up (bytes from the dynamic base)
     int lds_flags_off, lds_u_off, lds_loff_off, lds_red_off;
+    int lds_u_stride, lds_loff_stride;   // bytes between the two copies (0: single-buffered)
     long long *dbg;           // diagnostic build (-DNLMC_STAMPS) only: per-wave cycle sums [chains][16][4]
 };
 
 // ---- pieces shared by the two sweep kernels ------------------------------------------------------------
 struct ChainCtx {
     long long *st;            // diagnostic build: per-thread stamp sums inside update_spin
+    long long *lvl_t;         // diagnostic build: per-level barrier-to-barrier cycles [48] + widths [48] (thread 0)
     int8_t *s;
     uint8_t *fl;
     long long *red;
@@ -262,6 +264,7 @@ struct ChainCtx {
 __device__ __forceinline__ void chain_load(const SweepArgs &a, unsigned char *lds_raw, ChainCtx &x)
 {
     x.st = nullptr;
+    x.lvl_t = nullptr;
     x.n = a.g.n; x.n_pad = a.g.n_pad;
     x.tid = threadIdx.x; x.nt = blockDim.x; x.c = blockIdx.x;
     x.s = reinterpret_cast<int8_t *>(lds_raw);
@@ -426,8 +429,8 @@ template <> struct Pf<float> {
         const int o16 = valid ? i * 16 : oob;
         hd = __builtin_amdgcn_raw_buffer_load_b64(v.head, valid ? i * 8 : oob, 0, 0);
 #pragma unroll
-        for (int q = 0; q < (TAIL ? W / 2 : 4); ++q)
-            pk[q] = __builtin_amdgcn_raw_buffer_load_b128(v.ell, o16 + q * v.plane_bytes, 0, 0);
+        for (int q = 0; q < (TAIL ? W / 2 : 4); ++q)   // plane offset rides in the scalar offset operand: no VALU add
+            pk[q] = __builtin_amdgcn_raw_buffer_load_b128(v.ell, o16, q * v.plane_bytes, 0);
     }
     __device__ __forceinline__ void wait(bool) {}
     __device__ __forceinline__ int kd() const { return hd.x; }
@@ -606,8 +609,11 @@ __device__ __forceinline__ void fill_uniforms(double *ur, int n, uint32_t tt, ui
 // therefore also loads / folds the second half of the 16-entry row window.
 template <typename T, bool DIAG, bool TAIL>
 __device__ __forceinline__ void run_levels(const SweepArgs &a, ChainCtx &x, const T *ur, const int *loff, size_t so, int nl,
-                                           T cb0, T cb1, double esc)
+                                           int n_bar, T cb0, T cb1, double esc)
 {
+    // n_bar: levels [0, n_bar) end with a workgroup barrier; levels [n_bar, nl) are at most one wave wide and belong
+    // to wave 0 alone, which runs them back to back (LDS executes one wave's accesses in order, so its own writes are
+    // visible to its own later reads) while the other waves already prepare the next sweep (k_sweep_philox).
     // software pipeline over levels: while level l is computed, the schedule items of level l+1 are in flight.
     // Their addresses depend only on the level offsets (LDS), never on spin values, and the schedule was built with
     // level_cap == blockDim.x: at most one spin per thread and level.
@@ -639,21 +645,30 @@ __device__ __forceinline__ void run_levels(const SweepArgs &a, ChainCtx &x, cons
             const unsigned long long m = __ballot(has);
             if (m) n_live = l0 + 64 - __clzll((long long)m);
         }
+        n_live = (wbase == 0) ? nl : min(n_live, n_bar);
     }
     fetch(0, pfa, va, ia);
     int l = 0;
+#ifdef NLMC_STAMPS
+    long long lt0; NLMC_CLK(lt0)
+#define NLMC_LVL_STAMP(lv) if (x.lvl_t && tid == 0 && (lv) < 48) { long long lt1; NLMC_CLK(lt1) x.lvl_t[lv] += lt1 - lt0; x.lvl_t[48 + (lv)] = loff[(lv) + 1] - loff[lv]; lt0 = lt1; }
+#else
+#define NLMC_LVL_STAMP(lv)
+#endif
     for (; l < n_live; l += 2) {
         fetch(l + 1, pfb, vb, ib);
         if (va) update_spin<T, DIAG, TAIL>(a, x, ur, pfa, so, ia, cb0, cb1, esc);
-        __syncthreads();
+        if (l < n_bar) __syncthreads();
+        NLMC_LVL_STAMP(l)
         if (l + 1 < nl) {
             fetch(l + 2, pfa, va, ia);
             if (vb) update_spin<T, DIAG, TAIL>(a, x, ur, pfb, so, ib, cb0, cb1, esc);
-            __syncthreads();
+            if (l + 1 < n_bar) __syncthreads();
+            NLMC_LVL_STAMP(l + 1)
         }
     }
-    l = min(l, nl);
-    for (; l < nl; ++l) __syncthreads();       // retired: this wave has no item in any remaining level
+    l = min(l, n_bar);
+    for (; l < n_bar; ++l) __syncthreads();    // retired: this wave has no item in any remaining barrier level
 }
 
 template <typename T, bool DIAG>
@@ -675,8 +690,13 @@ __global__ void k_sweep_philox(SweepArgs a)
     long long st_fill = 0, st_epi = 0;
     long long st_u[5] = {0, 0, 0, 0, 0};      // update_spin: lds-gather, field, decide, energy+write, calls
     x.st = st_u;
+    x.lvl_t = (a.dbg && c == 0) ? a.dbg + (size_t)gridDim.x * 16 * 8 : nullptr;
     const long long st_begin = (long long)__builtin_readcyclecounter();
 #endif
+    T *const ur0 = ur;
+    int *const loff0 = loff;
+    const bool dbuf = a.lds_u_stride != 0;
+    bool prefilled = false;
     for (int t = 0; t < a.n_sweeps; ++t) {
         const int oid = a.per_chain ? (c * a.n_sweeps + t) : t;
         const int32_t *__restrict__ off = a.lvl_off + (size_t)oid * (n + 1);
@@ -684,28 +704,61 @@ __global__ void k_sweep_philox(SweepArgs a)
         const T cb0 = (T)a.tab[(size_t)row * a.tab_cs + (size_t)t * a.tab_ss];
         const T cb1 = (T)a.tab[(size_t)row * a.tab_cs + (size_t)t * a.tab_ss + 1];
         const uint32_t tt = a.sweep0 + (uint32_t)t;
+        const int pb = dbuf ? (t & 1) : 0;
+        ur = reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(ur0) + (size_t)pb * a.lds_u_stride);
+        loff = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(loff0) + (size_t)pb * a.lds_loff_stride);
+        const bool fast = nl < NLMC_LCAP;
 
-        // sweep prologue: all lanes busy -- uniforms for every spin, level offsets into LDS
+        // sweep prologue (first sweep of a launch, or whenever the previous sweep could not prepare it):
+        // uniforms for every spin (all lanes busy), level offsets into LDS
 #ifdef NLMC_STAMPS
         const long long f0 = (long long)__builtin_readcyclecounter();
 #endif
-        fill_uniforms(ur, n, tt, gc, a.seed_lo, a.seed_hi, tid, nt);
-        const bool fast = nl < NLMC_LCAP;
-        if (fast) for (int l = tid; l <= nl; l += nt) loff[l] = off[l];
-        __syncthreads();
+        if (!prefilled) {
+            fill_uniforms(ur, n, tt, gc, a.seed_lo, a.seed_hi, tid, nt);
+            if (fast) for (int l = tid; l <= nl; l += nt) loff[l] = off[l];
+            __syncthreads();
+        }
+        prefilled = false;
 #ifdef NLMC_STAMPS
         st_fill += (long long)__builtin_readcyclecounter() - f0;
 #endif
 
         const size_t so = (size_t)oid;
         if (fast) {
+            // levels that need a barrier: everything up to the last level wider than one wave
+            int n_bar = 0;
+            for (int l0 = 0; l0 < nl; l0 += 64) {
+                const int l = l0 + (tid & 63);
+                const unsigned long long m = __ballot((l < nl) && (loff[l + 1] - loff[l] > 64));
+                if (m) n_bar = l0 + 64 - __clzll((long long)m);
+            }
             // Rows longer than 8 entries sit at the front of their level (k_levelize), at most hi_max of them: only the
             // waves whose lanes can hold one run the variant that also prefetches the second half of the row window.
             // Two copies of the level loop, chosen per wave and sweep, keep the number of loads per stage STATIC in
-            // each copy (so hipcc emits counted vmcnt waits); both copies execute the same nl barriers.
+            // each copy (so hipcc emits counted vmcnt waits); both copies execute the same n_bar barriers.
             const bool role_long = (Pf<T>::W > 8) && ((tid & ~63) < a.hi_max[oid]);
-            if (role_long) run_levels<T, DIAG, true>(a, x, ur, loff, so, nl, cb0, cb1, esc);
-            else run_levels<T, DIAG, false>(a, x, ur, loff, so, nl, cb0, cb1, esc);
+            if (role_long) run_levels<T, DIAG, true>(a, x, ur, loff, so, nl, n_bar, cb0, cb1, esc);
+            else run_levels<T, DIAG, false>(a, x, ur, loff, so, nl, n_bar, cb0, cb1, esc);
+
+            // While wave 0 finishes the narrow tail of this sweep, the other waves prepare the next one in the second
+            // set of LDS buffers: its uniforms (the Philox work of a whole sweep) and its level offsets.
+            if (dbuf && t + 1 < a.n_sweeps) {
+                const int oid_n = a.per_chain ? (c * a.n_sweeps + t + 1) : (t + 1);
+                const int nl_n = a.nlev[oid_n];
+                const bool wave0_busy = n_bar < nl;
+                if (nl_n < NLMC_LCAP && (!wave0_busy || nt > 64)) {
+                    const int hid = wave0_busy ? tid - 64 : tid, hcnt = wave0_busy ? nt - 64 : nt;
+                    if (hid >= 0) {
+                        T *ur_n = reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(ur0) + (size_t)(pb ^ 1) * a.lds_u_stride);
+                        int *loff_n = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(loff0) + (size_t)(pb ^ 1) * a.lds_loff_stride);
+                        const int32_t *__restrict__ off_n = a.lvl_off + (size_t)oid_n * (n + 1);
+                        fill_uniforms(ur_n, n, tt + 1u, gc, a.seed_lo, a.seed_hi, hid, hcnt);
+                        for (int l = hid; l <= nl_n; l += hcnt) loff_n[l] = off_n[l];
+                    }
+                    prefilled = true;
+                }
+            }
         } else {
             // very deep schedules (dense graphs): plain level loop
             for (int l = 0; l < nl; ++l) {
@@ -724,6 +777,7 @@ __global__ void k_sweep_philox(SweepArgs a)
 #ifdef NLMC_STAMPS
         const long long e0 = (long long)__builtin_readcyclecounter();
 #endif
+        __syncthreads();        // the solo tail of wave 0 and the next sweep's preparation are complete
         sweep_epilogue(a, x, t);
 #ifdef NLMC_STAMPS
         st_epi += (long long)__builtin_readcyclecounter() - e0;

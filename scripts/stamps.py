@@ -15,7 +15,11 @@ for r in range(3):
     eng.sweep_philox(S, 42, sweep0=S * r, beta=tab)
 eng.energy()
 eng.close()
-d = np.fromfile(os.environ["NLMC_STAMP_FILE"], dtype=np.int64).reshape(R, 16, 8)
+raw = np.fromfile(os.environ["NLMC_STAMP_FILE"], dtype=np.int64)
+d = raw[:R * 16 * 8].reshape(R, 16, 8)
+lv = raw[R * 16 * 8:]
+print("chain 0, wave 0: barrier-to-barrier cycles per level (mean over the launch's sweeps) vs level width:")
+print("  " + "  ".join(f"{int(lv[48 + i])}:{lv[i] / S:.0f}" for i in range(48) if lv[48 + i] > 0))
 print("inside update_spin, s_memtime cycles per call (median over chains), lane 0 of each wave; sweep totals per wave:")
 for w in (0, 1, 3, 4, 8, 12, 15):
     calls = np.maximum(d[:, w, 4], 1)
