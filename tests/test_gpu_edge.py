@@ -1,0 +1,121 @@
+"""Edge cases of the sweep path: degenerate graphs, diagonal couplings, deep (dense) schedules, rows longer than the
+packed window, size limits, zero-length calls -- HIP path vs the sequential oracle, bit for bit."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+from helpers import init_spins, draw_stream, make_instance
+
+pytestmark = pytest.mark.gpu
+
+
+def check_philox(product, J, h, R=3, S=5, precision="f32", beta=1.1, seed=321):
+    csr = oracle.Csr(J)
+    n = csr.n
+    m0 = init_spins(R, n)
+    with product.Engine(J, h, R) as eng:
+        eng.set_spins(m0)
+        E0 = eng.energy()
+        esc = eng.energy_scale
+        o = eng.sweep_philox(S, seed, beta=beta, precision=precision, record_stride=1, want_energy=True)
+        Eend = eng.energy()
+    for c in range(R):
+        cb = np.tile(np.array(oracle.cb_pair(beta, 1.0, precision == "f64")), (S, 1))
+        M, s_fin, tr = oracle.sweeps_philox(csr, h, m0[c], cb, seed, c, escale=esc, use_f64=precision == "f64",
+                                            efix0=int(np.rint(E0[c] * 2.0 ** esc)))
+        assert np.array_equal(o["spins"][c], M)
+        assert np.array_equal(o["energy"][c], tr * 2.0 ** -esc)
+        assert abs(Eend[c] - oracle.energy(csr, h, s_fin)) <= 1e-9 * max(1.0, abs(Eend[c]))
+    return o
+
+
+def test_single_spin_and_isolated_vertices(product):
+    check_philox(product, sp.csr_matrix((1, 1)), np.array([0.7]), R=2, S=4)
+    J = sp.lil_matrix((9, 9))
+    J[0, 1] = J[1, 0] = -1.0
+    J[4, 7] = J[7, 4] = 0.5                       # spins 2,3,5,6,8 have no neighbour at all
+    check_philox(product, J.tocsr(), np.linspace(-1, 1, 9), S=6)
+    check_philox(product, J.tocsr(), np.linspace(-1, 1, 9), S=6, precision="f64")
+
+
+def test_diagonal_couplings(product):
+    """J_kk != 0 (the reference never forbids it): the field includes the diagonal term like J.dot(m) does, the
+    energy bookkeeping does not double count it."""
+    J, h = make_instance(120, seed=2, with_h=True, gaussian=True)
+    J = (J + sp.diags(np.linspace(-0.5, 0.5, 120))).tocsr()
+    check_philox(product, J, h)
+    check_philox(product, J, h, precision="f64")
+    csr = oracle.Csr(J)
+    m0 = init_spins(1, 120)
+    np.random.seed(3)
+    perm, u = draw_stream(1, 6, 120)
+    with product.Engine(J, h, 1) as eng:
+        eng.set_spins(m0)
+        o = eng.sweep_stream(perm, u, 0.9, record_stride=1, want_energy=True)
+    M, _ = oracle.sweeps_stream(csr, h, m0[0].astype(float), np.full(6, 0.9), perm[0], u[0])
+    assert np.array_equal(o["spins"][0], M)
+    E = np.array([oracle.energy(csr, h, M[t]) for t in range(6)])
+    assert np.all(np.abs(o["energy"][0] - E) <= 1e-10 * np.maximum(1, np.abs(E)))
+
+
+def test_dense_graph_deep_schedule_and_long_rows(product):
+    """Complete graph: every level holds one spin (n levels), every row has n-1 > 16 entries (CSR tail path)."""
+    r = np.random.default_rng(0)
+    n = 48
+    A = np.triu(r.standard_normal((n, n)), 1)
+    check_philox(product, A + A.T, r.standard_normal(n) * 0.2, S=4)
+    check_philox(product, A + A.T, r.standard_normal(n) * 0.2, S=3, precision="f64")
+    n = 1100                                       # more levels than the LDS offset table holds: plain level loop
+    A = np.triu(np.where(r.random((n, n)) < 0.5, 1.0, -1.0), 1)
+    check_philox(product, A + A.T, np.zeros(n), R=1, S=2, beta=0.01)
+
+
+def test_degree_between_8_and_16_and_above(product):
+    """Star-like hubs: rows of 9..16 entries use the second half of the packed window, longer ones the CSR tail."""
+    n = 300
+    J = sp.lil_matrix((n, n))
+    r = np.random.default_rng(5)
+    for hub, deg in ((0, 9), (1, 12), (2, 16), (3, 17), (4, 40)):
+        for j in r.choice(np.arange(10, n), size=deg, replace=False):
+            w = float(r.choice([-1.0, 1.0]) * r.random())
+            J[hub, j] = w
+            J[j, hub] = w
+    check_philox(product, J.tocsr(), r.standard_normal(n) * 0.1, S=6)
+
+
+def test_zero_sweeps_and_record_stride(product):
+    J, h = make_instance(64, seed=1)
+    m0 = init_spins(2, 64)
+    with product.Engine(J, h, 2) as eng:
+        eng.set_spins(m0)
+        o = eng.sweep_philox(0, 1, beta=1.0, record_stride=1, want_energy=True)
+        assert o["spins"].shape == (2, 0, 64) and o["energy"].shape == (2, 0)
+        assert np.array_equal(eng.get_spins(), m0)
+        full = eng.sweep_philox(7, 9, beta=1.0, record_stride=1)["spins"]
+        eng.set_spins(m0)
+        strided = eng.sweep_philox(7, 9, beta=1.0, record_stride=3)["spins"]
+        assert strided.shape == (2, 3, 64) and np.array_equal(strided, full[:, ::3])     # M[:, ::M_skip]
+
+
+def test_size_limits(product):
+    n = product._abi.MAX_N
+    r = np.random.default_rng(1)
+    i = np.arange(n)
+    w = r.choice([-1.0, 1.0], n)
+    J = sp.coo_matrix((np.concatenate([w, w]), (np.concatenate([i, (i + 1) % n]), np.concatenate([(i + 1) % n, i]))),
+                      shape=(n, n)).tocsr()          # ring of the largest supported size
+    csr = oracle.Csr(J)
+    m0 = init_spins(1, n)
+    with product.Engine(J, np.zeros(n), 1) as eng:
+        eng.set_spins(m0)
+        E0 = eng.energy()
+        o = eng.sweep_philox(2, 4, beta=0.7, record_stride=1)
+        cb = np.tile(np.array(oracle.cb_pair(0.7)), (2, 1))
+        M, _, _ = oracle.sweeps_philox(csr, np.zeros(n), m0[0], cb, 4, 0, escale=eng.energy_scale,
+                                       efix0=int(np.rint(E0[0] * 2.0 ** eng.energy_scale)))
+        assert np.array_equal(o["spins"][0], M)
+        with pytest.raises(NotImplementedError):      # fp64 uniforms of that many spins do not fit in LDS
+            eng.sweep_philox(1, 4, beta=0.7, precision="f64")
+    with pytest.raises(NotImplementedError):
+        product.Engine(sp.identity(n + 1, format="csr") * 0.0 + sp.eye(n + 1, k=1) + sp.eye(n + 1, k=-1), np.zeros(n + 1), 1)
