@@ -394,22 +394,24 @@ __global__ void k_sweep_stream(SweepArgs a)
 }
 
 // ---- PHILOX mode (throughput) ---------------------------------------------------------------------------
-template <typename T> struct Pf;            // one schedule item: k, degree, h_k and the first 8 entries of row k
+template <typename T> struct Pf;            // one schedule item: k, degree, h_k and the packed window of row k
 typedef int nlmc_i4 __attribute__((ext_vector_type(4)));
 typedef int nlmc_i2 __attribute__((ext_vector_type(2)));
 template <> struct Pf<float> {
     static constexpr int W = NLMC_ELL_W32;
     nlmc_i4 pk[W / 2];            // plane q: { col(2q), bits val(2q), col(2q+1), bits val(2q+1) }
     nlmc_i2 hd;                   // { k | deg << 16, bits of h_k }
-    // Nine loads per item, issued by EVERY wave in every stage (idle lanes: out-of-range no-ops): a load that sits
-    // behind a branch makes hipcc's vmcnt model path-dependent and it then drains vmcnt to 0 -- i.e. waits for the
-    // prefetch it has just issued -- before every update; with a static count it emits the counted wait.
-    // (Inline-asm loads with hand-placed waits were tried: hipcc spills/copies the still-pending destination
-    // registers around the long-row tail loop, which corrupts them.)  Coalesced: consecutive lanes read consecutive
-    // positions of every plane.
-    // Per-sweep view of the packed schedule as two raw buffers (SRSRC): 32-bit offsets instead of 64-bit address
-    // arithmetic per load, and the hardware range check turns the loads of idle lanes (offset >= size) into no-ops
-    // that return 0 without touching memory.
+    // The loads of one item (head + 4 planes, or + 8 planes in waves that may hold rows longer than 8 entries) are
+    // issued unconditionally inside a pipeline stage: a load behind a branch makes hipcc's vmcnt model
+    // path-dependent, and it then drains vmcnt to 0 -- i.e. waits for the prefetch it has just issued -- before every
+    // update; with a static count per loop copy it emits the counted wait.  Different load counts therefore live in
+    // separate copies of the level loop (run_levels<TAIL>), and a wave without further work leaves the loop instead
+    // of branching around its loads.  (Inline-asm loads with hand-placed waits were tried: hipcc copies the
+    // still-pending destination registers around the long-row tail loop, which corrupts them.)
+    // The schedule is read through two raw-buffer descriptors (SRSRC): 32-bit offsets instead of 64-bit address
+    // arithmetic, the plane offset in the scalar-offset operand, and the hardware range check turns the loads of idle
+    // lanes (offset >= size) into no-ops that return 0 without touching memory.  Coalesced: consecutive lanes read
+    // consecutive positions of every plane.
     struct View {
         __amdgpu_buffer_rsrc_t ell, head;
         int plane_bytes;
@@ -432,7 +434,6 @@ template <> struct Pf<float> {
         for (int q = 0; q < (TAIL ? W / 2 : 4); ++q)   // plane offset rides in the scalar offset operand: no VALU add
             pk[q] = __builtin_amdgcn_raw_buffer_load_b128(v.ell, o16, q * v.plane_bytes, 0);
     }
-    __device__ __forceinline__ void wait(bool) {}
     __device__ __forceinline__ int kd() const { return hd.x; }
     __device__ __forceinline__ float h() const { return __int_as_float(hd.y); }
     __device__ __forceinline__ int col(int q) const { return (q & 1) ? pk[q >> 1].z : pk[q >> 1].x; }
@@ -468,7 +469,6 @@ template <> struct Pf<double> {
         kd_ = v.po[ic].x;
         h_ = v.ph[ic];
     }
-    __device__ __forceinline__ void wait(bool) {}
     __device__ __forceinline__ int kd() const { return kd_; }
     __device__ __forceinline__ double h() const { return h_; }
     __device__ __forceinline__ int col(int q) const { return cj[q]; }
@@ -515,7 +515,7 @@ __device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, con
     // The spins sit at LDS offset 0 (first region of the dynamic LDS, no static LDS in this kernel -- checked at
     // kernel entry), so a column index IS the LDS address: no per-read base add.
     typedef const int8_t __attribute__((address_space(3))) *lds_i8;
-#define NLMC_SPIN(c) ((T)(*(lds_i8)(unsigned)(c)))
+#define NLMC_SPIN(c) ((T)(*(lds_i8)(uintptr_t)(unsigned)(c)))
     T sj[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) sj[q] = NLMC_SPIN(pf.col(q));         // all LDS reads in flight together
@@ -768,7 +768,6 @@ __global__ void k_sweep_philox(SweepArgs a)
                     typename Pf<T>::View vw;
                     vw.bind(a, so, n);
                     pe.template issue<true>(vw, i, true);
-                    pe.wait(false);
                     update_spin<T, DIAG, true>(a, x, ur, pe, so, i, cb0, cb1, esc);
                 }
                 __syncthreads();
