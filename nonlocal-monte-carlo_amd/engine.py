@@ -134,12 +134,40 @@ class Engine:
         o["argmin_state"] = np.empty((R, n), np.int8) if want_state else None
         return o
 
+    STREAM_CHUNK_BYTES = 384 << 20      # staged permutation + uniforms + schedule per C-ABI call
+
     def sweep_stream(self, perm, u, beta, record_stride=0, want_energy=False, want_min=False, want_state=False):
-        """Reference-stream sweeps (NMC/nmc.py:28-91).  perm,u: [R,S,N]; beta: scalar or [R,S] table."""
+        """Reference-stream sweeps (NMC/nmc.py:28-91).  perm,u: [R,S,N]; beta: scalar or [R,S] table.
+        Long runs are cut into several C-ABI calls so that the staged stream stays bounded; the pieces are stitched
+        back together (trace, energies, first-argmin bookkeeping) exactly as one call would return them."""
         R, n = self.n_chains, self.n
-        perm = _abi.as_c(perm, np.int32).reshape(R, -1, n)
+        perm = np.asarray(perm).reshape(R, -1, n)
         S = perm.shape[1]
-        u = _abi.as_c(u, np.float64).reshape(R, S, n)
+        u = np.asarray(u).reshape(R, S, n)
+        per_sweep = R * n * 36                         # 12 B of stream + ~24 B of per-chain schedule per spin
+        chunk = max(1, self.STREAM_CHUNK_BYTES // max(1, per_sweep))
+        if record_stride > 1:
+            chunk = max(record_stride, chunk // record_stride * record_stride)
+        if S > chunk:
+            b = np.asarray(beta, dtype=np.float64)
+            outs = []
+            for t0 in range(0, S, chunk):
+                t1 = min(S, t0 + chunk)
+                outs.append(self.sweep_stream(perm[:, t0:t1], u[:, t0:t1], b if b.ndim == 0 else b[:, t0:t1], record_stride,
+                                              want_energy, want_min, want_state))
+            o = {"spins": np.concatenate([p["spins"] for p in outs], axis=1) if record_stride else None,
+                 "energy": np.concatenate([p["energy"] for p in outs], axis=1) if want_energy else None,
+                 "min_energy": None, "argmin": None, "argmin_state": None}
+            if want_min:
+                mins = np.stack([p["min_energy"] for p in outs])           # [chunks, R]
+                first = np.argmin(mins, axis=0)                            # np.argmin: first chunk holding the minimum
+                o["min_energy"] = mins[first, np.arange(R)]
+                o["argmin"] = np.array([outs[first[r]]["argmin"][r] + first[r] * chunk for r in range(R)], dtype=np.int32)
+                if want_state:
+                    o["argmin_state"] = np.stack([outs[first[r]]["argmin_state"][r] for r in range(R)])
+            return o
+        perm = _abi.as_c(perm, np.int32)
+        u = _abi.as_c(u, np.float64)
         tab, cs, ss = _beta_table(beta, R, S)
         o = self._outputs(S, record_stride, want_energy, want_min, want_state)
         self._ck(self._L.nlmc_sweep_stream(self._ctx, S, _abi.ptr(perm), _abi.ptr(u), _abi.ptr(tab), cs, ss,

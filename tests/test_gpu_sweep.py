@@ -197,3 +197,21 @@ def test_stream_mode_nmc_phase_flags_match_reference_golden(product):
                 got.append(o["spins"][0])
                 m = o["argmin_state"][0].copy()
     assert np.array_equal(np.concatenate(got), g["M_overall"])
+
+
+def test_stream_mode_chunked_calls_equal_one_call(product):
+    """Engine.sweep_stream cuts long runs into several C-ABI calls; traces, energies and argmin are stitched exactly."""
+    J, h = make_instance(150, seed=8, with_h=True, gaussian=True)
+    R, S, N = 3, 23, 150
+    m0 = init_spins(R, N)
+    np.random.seed(11)
+    perm, u = draw_stream(R, S, N)
+    betas = np.repeat(np.array([0.4, 1.0, 2.2])[:, None], S, axis=1)
+    with product.Engine(J, h, R) as eng:
+        eng.set_spins(m0)
+        one = eng.sweep_stream(perm, u, betas, record_stride=1, want_energy=True, want_min=True, want_state=True)
+        eng.set_spins(m0)
+        eng.STREAM_CHUNK_BYTES = R * N * 36 * 5          # 5 sweeps per call
+        many = eng.sweep_stream(perm, u, betas, record_stride=1, want_energy=True, want_min=True, want_state=True)
+    for k in ("spins", "energy", "min_energy", "argmin", "argmin_state"):
+        assert np.array_equal(one[k], many[k]), k
