@@ -98,8 +98,11 @@ class SweepMixin:
             perm, u = hostlogic.draw_legacy_stream(num_sweeps, n)
             return eng.sweep_stream(perm[None], u[None], np.asarray(beta_run)[None, :], record_stride=1 if record else 0,
                                     want_energy=True, want_min=True, want_state=True)
+        # single-chain API calls return energy traces: fp64 fields keep them exact to rounding (the fp32 path is the
+        # batched throughput path); very large instances only fit the fp32 layout in LDS
         o = eng.sweep_philox(num_sweeps, self.seed, sweep0=self._sweep_counter, beta=np.asarray(beta_run)[None, :],
-                             record_stride=1 if record else 0, want_energy=True, want_min=True, want_state=True)
+                             precision="f64" if n <= 12000 else "f32", record_stride=1 if record else 0,
+                             want_energy=True, want_min=True, want_state=True)
         self._sweep_counter += num_sweeps
         return o
 

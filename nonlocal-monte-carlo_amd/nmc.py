@@ -8,6 +8,7 @@ import numpy as np
 
 from . import hostlogic
 from .base import Common
+from .lbp import lbp_convexified
 
 
 class NMC(Common):
@@ -43,6 +44,71 @@ class NMC(Common):
             self.plot_results(M_overall, energy_overall, all_clusters, M_skip, num_NMC_cycles, full_update_frequency,
                               num_sweeps_per_NMC_phase)
         return M_overall, energy_overall, min_energy
+
+    # ------------------------------------------------------------------------------------------------
+    def run_restarts(self, num_restarts, num_sweeps_initial=int(1e4), num_sweeps_per_NMC_phase=int(1e4), num_NMC_cycles=10,
+                     full_update_frequency=1, temp_x=20, global_beta=2.5, lambda_start=0.5, lambda_end=0.01,
+                     lambda_reduction_factor=0.9, threshold_initial=0.999999, threshold_cutoff=0.99999,
+                     max_iterations=100, tolerance=np.finfo(float).eps, all_clusters=None):
+        """Throughput extension (not in the reference): `num_restarts` independent NMC runs of run()'s algorithm batched
+        in ONE context -- anneal, then per cycle the three phases (NMC/nmc.py:365-433), every phase one launch over all
+        restarts with per-restart cluster flags, the argmin-energy state of each phase handed to the next on the
+        device side of the C-ABI.  Device RNG (philox) whatever `rng` says.  `all_clusters`: one index array used by
+        every restart and cycle (skips the host-side backbone inference), or None to infer clusters per restart and
+        cycle like run() does.  Returns (min_energy [R], best_state [R, N] int8, energy_of_phase_minima [R, phases])."""
+        norm_factor = np.max(np.abs(self.J))
+        self.J = self.J / norm_factor
+        self.h = self.h / norm_factor
+        inst = self._cache.instance(self.J, self.h)
+        R, N = int(num_restarts), inst.n
+        S0, S = int(num_sweeps_initial), int(num_sweeps_per_NMC_phase)
+        eng = self._cache.engine(self.J, self.h, R)
+        graph = self._graph(inst) if all_clusters is None else None
+        epsilon = graph.epsilon(inst.h) if all_clusters is None else None
+        m = np.sign(2 * np.random.default_rng(self.seed).random((R, N)) - 1).astype(np.int8)
+        sweep0 = self._sweep_counter
+        best_e = np.full(R, np.inf)
+        best_s = m.copy()
+        trail = []
+
+        def launch(state, n_sweeps, beta_tab, flags):
+            nonlocal sweep0, best_e, best_s
+            eng.set_spins(state)
+            eng.set_flags(flags, temp_x)
+            o = eng.sweep_philox(n_sweeps, self.seed, sweep0=sweep0, beta=beta_tab, want_min=True, want_state=True)
+            sweep0 += n_sweeps
+            better = o["min_energy"] < best_e
+            best_e = np.where(better, o["min_energy"], best_e)
+            best_s[better] = o["argmin_state"][better]
+            trail.append(o["min_energy"].copy())
+            return o["argmin_state"].copy()
+
+        if S0 > 0:
+            sched = hostlogic.beta_schedule(S0, global_beta, True, 1, 0)
+            m = launch(m, S0, np.repeat(sched[None, :], R, axis=0), None)
+        m_star = m.copy()
+        flat = np.full((R, S), float(global_beta)) if S > 0 else None
+        for cycle in range(num_NMC_cycles):
+            if S == 0:
+                break
+            if all_clusters is None:
+                cls = []
+                for r in range(R):
+                    cl = lbp_convexified(inst, lambda_start, lambda_end, lambda_reduction_factor, m_star[r].astype(float),
+                                         epsilon, tolerance, max_iterations, threshold_initial, threshold_cutoff,
+                                         global_beta, graph=graph)
+                    cls.append(np.concatenate(cl).astype(int) if cl else np.array([], dtype=int))
+            else:
+                cls = [np.asarray(all_clusters, dtype=int)] * R
+            m = launch(m, S, flat, np.stack([hostlogic.phase_flags(N, m[r], cls[r], "C") for r in range(R)]))
+            m = launch(m, S, flat, np.stack([hostlogic.phase_flags(N, m[r], cls[r], "NC") for r in range(R)]))
+            if cycle % full_update_frequency == 0:
+                m = launch(m, S, flat, None)
+                m_star = m.copy()
+        eng.set_flags(None)
+        self._sweep_counter = sweep0
+        # the running minima were tracked incrementally from fp32 fields; report the fp64 energies of the kept states
+        return eng.energy_of(best_s), best_s, np.stack(trail, axis=1) if trail else np.zeros((R, 0))
 
     def plot_results(self, M_overall, energy_overall, all_clusters, M_skip, num_NMC_cycles, full_update_frequency,
                      num_sweeps_per_NMC_phase):

@@ -296,3 +296,41 @@ def test_apt_icm_philox_device_resident(product):
     assert sorted(obj.final_slots[:6]) == list(range(6))
     _, M2, E2 = go()
     assert np.array_equal(M, M2) and np.array_equal(E, E2)
+
+
+def test_nmc_run_restarts_batched(product):
+    """C2-style use: many NMC restarts in one context (device RNG), fixed cluster set.  Every phase equals the oracle's
+    sequential spec per chain (with the phase flags), and the hand-off uses each chain's argmin state."""
+    import oracle
+    from helpers import make_instance
+    N, R, S0, S = 200, 6, 12, 8
+    J, h = make_instance(N, seed=17, with_h=True)
+    cl = np.arange(10)
+    obj = product.NMC(J, h, rng="philox", seed=2024)
+    best_e, best_s, trail = obj.run_restarts(R, num_sweeps_initial=S0, num_sweeps_per_NMC_phase=S, num_NMC_cycles=2,
+                                             full_update_frequency=1, temp_x=20, global_beta=3.0, all_clusters=cl)
+    assert best_e.shape == (R,) and best_s.shape == (R, N) and trail.shape == (R, 1 + 2 * 3)
+    assert np.allclose(best_e, trail.min(axis=1), rtol=1e-6)      # tracked (fp32 fields) vs exact fp64 energies
+    csr = oracle.Csr(J)                                   # max|J| = 1: run_restarts' normalisation is the identity
+    with product.Engine(J, h, 1) as eng:
+        esc = eng.energy_scale
+        assert np.array_equal(eng.energy_of(best_s), best_e)
+    m = np.sign(2 * np.random.default_rng(2024).random((R, N)) - 1).astype(np.int8)
+    for c in (0, R - 1):
+        s = m[c].copy()
+        t0 = 0
+        mins = []
+        sched = product.hostlogic.beta_schedule(S0, 3.0, True, 1, 0)
+        phases = [(S0, np.array([oracle.cb_pair(b, 20.0) for b in sched]), "ALL")]
+        for cyc in range(2):
+            phases += [(S, np.tile(np.array(oracle.cb_pair(3.0, 20.0)), (S, 1)), k) for k in ("C", "NC", "ALL")]
+        for (ns, cb, kind) in phases:
+            fl = product.hostlogic.phase_flags(N, s, cl, kind)
+            E0 = oracle.energy(csr, h, s)
+            M, _, tr = oracle.sweeps_philox(csr, h, s, cb, 2024, c, sweep0=t0, flags=None if kind == "ALL" else fl,
+                                            escale=esc, efix0=int(np.rint(E0 * 2.0 ** esc)))
+            t0 += ns
+            am = int(np.argmin(tr))
+            mins.append(tr[am] * 2.0 ** -esc)
+            s = M[am].copy()
+        assert np.allclose(trail[c], mins, rtol=0, atol=1e-9)
