@@ -179,7 +179,7 @@ int launch_energy_self(nlmc_ctx *c, double *dev_out)
     a.efix = c->efix.p;
     a.escale = c->escale;
     if (c->n_chains > 0)
-        hipLaunchKernelGGL(k_energy, dim3(c->n_chains), dim3(256), (size_t)c->n_pad, c->stream, a);
+        hipLaunchKernelGGL(k_energy, dim3(c->n_chains), dim3(c->n >= 4096 ? 1024 : 256), (size_t)c->n_pad, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return NLMC_OK;
 }
@@ -612,7 +612,7 @@ int nlmc_energy_of(nlmc_ctx *c, const int8_t *spins, int64_t count, double *out)
         HIP_TRY(c, hipMemcpyAsync(c->cfg.p, spins + b * c->n, (size_t)m * c->n, hipMemcpyHostToDevice, c->stream));
         EnergyArgs a{};
         a.g = c->g; a.spins = c->cfg.p; a.stride = c->n; a.out = c->etrace_d.p; a.efix = nullptr; a.escale = c->escale;
-        hipLaunchKernelGGL(k_energy, dim3((unsigned)m), dim3(256), (size_t)c->n_pad, c->stream, a);
+        hipLaunchKernelGGL(k_energy, dim3((unsigned)m), dim3(c->n >= 4096 ? 1024 : 256), (size_t)c->n_pad, c->stream, a);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipMemcpyAsync(out + b, c->etrace_d.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -950,7 +950,7 @@ static int icm_launch_components(nlmc_ctx *c, const int32_t *pairs_dev, int n_pa
     a.g = c->g; a.spins = c->spins.p; a.pairs = pairs_dev; a.label = c->icm_label.p; a.info = c->icm_info.p;
     const size_t lds = (size_t)c->n * 4 + 16;
     { int rc = ensure_lds(c, 1, reinterpret_cast<const void *>(k_icm_components), lds); if (rc) return rc; }
-    hipLaunchKernelGGL(k_icm_components, dim3(n_pairs), dim3(256), lds, c->stream, a);
+    hipLaunchKernelGGL(k_icm_components, dim3(n_pairs), dim3(c->n >= 4096 ? 1024 : 256), lds, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return NLMC_OK;
 }
@@ -999,7 +999,7 @@ static int icm_apply(nlmc_ctx *c, int n_pairs, const int64_t *pick_dev_or_null, 
     m.pick_host = pick_host; m.use_philox = philox; m.round = round;
     m.seed_lo = (uint32_t)seed; m.seed_hi = (uint32_t)(seed >> 32); m.katz = katz; m.chain_base = c->chain_base;
     (void)pick_dev_or_null;
-    hipLaunchKernelGGL(k_icm_move, dim3(n_pairs), dim3(256), 0, c->stream, m);
+    hipLaunchKernelGGL(k_icm_move, dim3(n_pairs), dim3(c->n >= 4096 ? 1024 : 256), 0, c->stream, m);
     HIP_TRY(c, hipGetLastError());
     return NLMC_OK;
 }

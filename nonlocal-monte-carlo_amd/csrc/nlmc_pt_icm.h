@@ -153,9 +153,19 @@ struct IcmArgs {
     int32_t *info;            // [n_pairs][2]  {n_components, picked size}
 };
 
-// Connected components of the sub-graph induced by {k : s_a[k] s_b[k] = -1} (NPT/apt_ICM.py:116-143) by min-label
-// propagation with pointer jumping in LDS.  A component's label is its smallest member, so ascending labels
-// reproduce the reference's list order.
+// Connected components of the sub-graph induced by {k : s_a[k] s_b[k] = -1} (NPT/apt_ICM.py:116-143): union-find in
+// LDS.  lab[k] always points to a member of k's component with an index <= k; roots are hooked onto SMALLER roots
+// (atomicMin), so the final root of a component is its smallest member and ascending labels reproduce the
+// reference's list order.  A handful of hook rounds with path compression replace the O(diameter) rounds of plain
+// label propagation.
+__device__ __forceinline__ int icm_find(int32_t *lab, int k)
+{
+    int r = lab[k];
+    while (true) { const int up = lab[r]; if (up == r) break; r = up; }
+    lab[k] = r;                                        // path compression (benign race: any value written is an ancestor)
+    return r;
+}
+
 __global__ void k_icm_components(IcmArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -170,23 +180,27 @@ __global__ void k_icm_components(IcmArgs a)
     for (int it = 0; it <= n; ++it) {
         int changed = 0;
         for (int k = tid; k < n; k += nt) {
-            const int cur = lab[k];
-            if (cur == INT_MAX) continue;
-            int m = cur;
+            if (lab[k] == INT_MAX) continue;
+            int rk = icm_find(lab, k);
             for (int e = a.g.rowptr[k]; e < a.g.rowptr[k + 1]; ++e) {
-                if (a.g.val64[e] == 0.0) continue;
-                const int lj = lab[a.g.col[e]];
-                if (lj < m) m = lj;
+                const EdgeF ed = a.g.edge32[e];
+                if (ed.val == 0.0f && a.g.val64[e] == 0.0) continue;       // `val != 0` test, NPT/apt_ICM.py:129
+                if (lab[ed.col] == INT_MAX) continue;
+                const int rj = icm_find(lab, ed.col);
+                if (rj < rk) { atomicMin(&lab[rk], rj); rk = rj; changed = 1; }
+                else if (rk < rj) { atomicMin(&lab[rj], rk); changed = 1; }
             }
-            const int hop = lab[m];          // pointer jumping: lab[m] <= m is a member of the same component
-            if (hop < m) m = hop;
-            if (m < cur) { lab[k] = m; changed = 1; }
         }
         if (!__syncthreads_or(changed)) break;
     }
     int cnt = 0;
     int32_t *out = a.label + (size_t)p * n;
-    for (int k = tid; k < n; k += nt) { const int l = lab[k]; out[k] = l; cnt += (l == k); }
+    for (int k = tid; k < n; k += nt) {
+        int l = lab[k];
+        if (l != INT_MAX) l = icm_find(lab, k);
+        out[k] = l;
+        cnt += (l == k);
+    }
     if (cnt) atomicAdd(&nroots, cnt);
     __syncthreads();
     if (tid == 0) { a.info[2 * p] = nroots; a.info[2 * p + 1] = 0; }

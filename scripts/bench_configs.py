@@ -1,0 +1,92 @@
+"""Throughput of the other BASELINE.json configurations on one GPU (not the bench.py headline).
+ C2  NMC phases, N=1e3, 64 restarts, fixed cluster set (first 5 % of the spins), 1e4 sweeps in total
+ C3  NPT, N=1e3, 32 betas x 8 restarts = 256 chains, 1e4 sweeps, 100 swap rounds, 10 pairs per ladder and round
+ C5  APT + iso-cluster moves, N=1e4, 32 betas x 8 sub-replicas = 256 chains, 100 rounds x 10 sweeps, 4 ICM pairs per beta
+"""
+import os, sys, time, json
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+from conftest import load_product
+from helpers import make_instance, init_spins
+P = load_product()
+
+
+def timed(fn):
+    t0 = time.perf_counter(); r = fn(); return time.perf_counter() - t0, r
+
+
+def c2():
+    N, R, S_phase, cycles = 1000, 64, 333, 10             # 3 phases x 10 cycles x 333 = 9990 sweeps (+ 10 anneal)
+    J, h = make_instance(N)
+    eng = P.Engine(J, h, R)
+    m = init_spins(R, N)
+    cl = np.arange(N // 20)
+    eng.set_spins(m); eng.sweep_philox(10, 1, beta=3.0)     # warm-up
+    def run():
+        nonlocal m
+        sw = 10
+        for c in range(cycles):
+            for kind in ("C", "NC", "ALL"):
+                fl = None if kind == "ALL" else np.stack([P.hostlogic.phase_flags(N, m[r], cl, kind) for r in range(R)])
+                eng.set_spins(m); eng.set_flags(fl, 20.0)
+                o = eng.sweep_philox(S_phase, 7, sweep0=sw, beta=3.0, want_min=True, want_state=True)
+                sw += S_phase; m = o["argmin_state"]
+        return sw - 10
+    dt, sweeps = timed(run)
+    eng.close()
+    return {"config": "C2 NMC phases N=1e3 x 64 restarts", "sweeps": sweeps, "seconds": dt, "updates_per_s": R * N * sweeps / dt}
+
+
+def c3():
+    N, L, NL, S, rounds, pairs = 1000, 32, 8, 100, 100, 10
+    J, h = make_instance(N)
+    G = L * NL
+    eng = P.Engine(J, h, G)
+    eng.set_spins(init_spins(G, N)); eng.pt_init(np.geomspace(0.1, 3.0, L))
+    eng.plan_philox(0, S * (rounds + 1), 3); eng.pt_plan(0, rounds + 1, 3, pairs)
+    eng.sweep_philox(S, 3, sweep0=0, beta=None); eng.pt_swap_philox(0, 3, pairs, want_log=False); eng.energy()
+    def run():
+        for r in range(1, rounds + 1):
+            eng.sweep_philox(S, 3, sweep0=r * S, beta=None)
+            eng.pt_swap_philox(r, 3, pairs, want_log=False)
+        return eng.energy()
+    dt, E = timed(run)
+    eng.close()
+    return {"config": "C3 NPT N=1e3, 32 betas x 8 restarts", "sweeps": S * rounds, "seconds": dt,
+            "updates_per_s": G * N * S * rounds / dt, "min_energy": float(E.min())}
+
+
+def c5():
+    N, R, K, S, rounds = 10_000, 32, 8, 10, 100
+    J, h = make_instance(N)
+    G = R * K
+    eng = P.Engine(J, h, G)
+    eng.set_spins(init_spins(G, N)); eng.pt_init(np.geomspace(0.05, 4.0, R))
+    eng.plan_philox(0, S * (rounds + 1), 5); eng.pt_plan(0, rounds + 1, 5, 10)
+    rng = np.random.default_rng(0)
+    def one(r):
+        eng.sweep_philox(S, 5, sweep0=r * S, beta=None)
+        slots = eng.pt_slots()
+        holder = np.empty((K, R), dtype=np.int64)
+        for j in range(K):
+            holder[j, slots[j * R:(j + 1) * R]] = j * R + np.arange(R)
+        pairs = []
+        for rr in range(R):
+            sh = rng.permutation(K)
+            pairs += [(holder[sh[2 * p], rr], holder[sh[2 * p + 1], rr]) for p in range(K // 2)]
+        eng.icm_round_philox(np.array(pairs, dtype=np.int32), r, 5, True)
+        eng.pt_swap_philox(r, 5, 10, want_log=False)
+    one(0); eng.energy()
+    def run():
+        for r in range(1, rounds + 1):
+            one(r)
+        return eng.energy()
+    dt, E = timed(run)
+    eng.close()
+    return {"config": "C5 APT+ICM N=1e4, 32 betas x 8 sub-replicas", "sweeps": S * rounds, "seconds": dt,
+            "updates_per_s": G * N * S * rounds / dt, "min_energy": float(E.min())}
+
+
+if __name__ == "__main__":
+    for f in (c2, c3, c5):
+        print(json.dumps(f()), flush=True)
