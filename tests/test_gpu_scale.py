@@ -160,3 +160,26 @@ def test_c5_size_icm_round(product):
         Eb = eng.energy_of(before)
     swapped = info[:, 1] <= N // 2
     assert np.allclose((E[0::2] + E[1::2])[swapped], (Eb[0::2] + Eb[1::2])[swapped], rtol=0, atol=1e-9)
+
+
+def test_c4_size_determinism_race_screen(product):
+    """Same seed twice at the bench size (256 x 10^4 spins, 30 sweeps across 3 launches): identical bits.  Any missing
+    barrier / LDS ordering problem in the pipelined level loop would show up here as run-to-run differences."""
+    N, R = 10_000, 256
+    J, h = make_instance(N)
+    betas = np.geomspace(0.05, 4.0, R)
+    m0 = init_spins(R, N)
+    outs = []
+    for rep in range(2):
+        with product.Engine(J, h, R) as eng:
+            eng.set_spins(m0)
+            eng.pt_init(betas)
+            if rep == 1:
+                eng.plan_philox(0, 30, 99)            # planned vs unplanned schedules must not matter either
+            for r in range(3):
+                eng.sweep_philox(10, 99, sweep0=10 * r, beta=None)
+                eng.pt_swap_philox(r, 99, 77, want_log=False)
+            outs.append((eng.get_spins(), eng.energy(), eng.pt_slots()))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2])
