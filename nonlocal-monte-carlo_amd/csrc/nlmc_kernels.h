@@ -567,7 +567,10 @@ __device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, con
     if constexpr (sizeof(T) == 4) {
         bool slow;
         long long d = fixed_delta_fast(x_true, ds, a.escale, slow);
-        if (__ballot(slow) != 0ull) { if (slow) d = fixed_delta_slow((double)x_true, ds, esc); }   // practically never
+        if (__ballot(slow) != 0ull) {          // practically never; the empty volatile asm keeps hipcc from
+            asm volatile("" ::: "memory");     // if-converting this block into an always-executed fp64 sequence
+            if (slow) d = fixed_delta_slow((double)x_true, ds, esc);
+        }
         x.e_loc += d;
     } else {
         if (ds != 0) x.e_loc += fixed_delta_slow((double)x_true, ds, esc);
