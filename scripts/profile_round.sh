@@ -1,0 +1,20 @@
+#!/bin/bash
+# (stats pass = the default bench command; PMC passes use a shorter run of the same workload)
+# Profiling pass of one round on the GPU box:  bash scripts/profile_round.sh <tag>   (run through gpurun)
+set -e
+TAG=${1:-r01_x}
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+B="python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats" -o s -- python3 $REPO/bench.py > "$OUT/stats.log" 2>&1
+timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o f -- $B > "$OUT/fetch.log" 2>&1
+timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o w -- $B > "$OUT/write.log" 2>&1
+timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d "$OUT/sq1" -o q -- $B > "$OUT/sq1.log" 2>&1
+timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -d "$OUT/sq2" -o q -- $B > "$OUT/sq2.log" 2>&1
+timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES -d "$OUT/sq3" -o q -- $B > "$OUT/sq3.log" 2>&1
+python3 "$REPO/scripts/summarize_prof.py" "$TAG" "$OUT/stats" "$OUT/fetch" "$OUT/write" "$OUT/sq1" "$OUT/sq2" "$OUT/sq3"
+cp "$REPO"/profiles/${TAG}_* "$OUT"/
+python3 "$REPO/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
+tail -1 "$OUT/bench.json"

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Collect rocprofv3 outputs of one profiling round into the small CSVs kept under profiles/.
+
+    python scripts/summarize_prof.py <tag> <stats_dir> <fetch_dir> <write_dir> [<sq_dir> ...]
+
+<stats_dir>: rocprofv3 --kernel-trace --stats;  <fetch_dir>/<write_dir>: separate --pmc FETCH_SIZE / WRITE_SIZE passes;
+<sq_dir>: optional further --pmc passes.  Units and the gfx950 read correction follow MI355X_MICROARCH.md (HBM section).
+"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+KERNEL = "k_sweep_philox"
+
+
+def find(d, suffix):
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    if not hits:
+        raise SystemExit(f"no *{suffix} under {d}")
+    return hits[-1]
+
+
+def counters(d):
+    acc, n = defaultdict(float), defaultdict(int)
+    with open(find(d, "counter_collection.csv")) as f:
+        for row in csv.DictReader(f):
+            if KERNEL in row["Kernel_Name"]:
+                acc[row["Counter_Name"]] += float(row["Counter_Value"])
+                n[row["Counter_Name"]] += 1
+    return {k: (n[k], acc[k] / n[k]) for k in acc}
+
+
+def main():
+    tag, stats_dir, fetch_dir, write_dir, *sq_dirs = sys.argv[1:]
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+    with open(find(stats_dir, "kernel_stats.csv")) as f, open(os.path.join(out, f"{tag}_bench_n1_kernel_stats.csv"), "w") as g:
+        g.write(f.read())
+    fs, ws = counters(fetch_dir)["FETCH_SIZE"], counters(write_dir)["WRITE_SIZE"]
+    hbm = int(round((2.0 * fs[1] + ws[1]) * 1024))
+    with open(os.path.join(out, f"{tag}_sweep_hbm_traffic_pmc.csv"), "w") as g:
+        g.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE  and (separate pass)  --pmc WRITE_SIZE  -- python3 bench.py "
+                "--steps 20 --warmup 3 --no-cpu-baseline\n"
+                "# per launch of k_sweep_philox<float,false> (256 chains x 1e4 spins x 10 sweeps); counter unit = KiB\n"
+                "# gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of wide coalesced reads -> "
+                "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024\n"
+                "counter,n_launches,mean_per_launch\n"
+                f"FETCH_SIZE,{fs[0]},{fs[1]:.1f}\nWRITE_SIZE,{ws[0]},{ws[1]:.1f}\n"
+                f"# hbm_bytes_per_launch,{hbm}\n# algorithmic_bytes_per_launch,{256 * 10_000 * 10 * 63}\n")
+    if sq_dirs:
+        with open(os.path.join(out, f"{tag}_sweep_pmc_summary.csv"), "w") as g:
+            g.write("# rocprofv3 --kernel-trace --pmc <counters, one pass per line group> -- python3 bench.py --steps 20 "
+                    "--warmup 3 --no-cpu-baseline\n# k_sweep_philox<float,false>, per launch (256 chains x 1e4 spins x 10 sweeps)\n"
+                    "counter,mean_per_launch\n")
+            for d in sq_dirs:
+                for k, (_, v) in sorted(counters(d).items()):
+                    g.write(f"{k},{v:.6g}\n")
+    print("hbm_bytes_per_launch", hbm)
+
+
+if __name__ == "__main__":
+    main()
