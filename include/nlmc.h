@@ -138,6 +138,33 @@ int nlmc_icm_get_labels(nlmc_ctx *ctx, int32_t *out /*[n]*/);
 int nlmc_icm_round_philox(nlmc_ctx *ctx, const int32_t *pairs, int n_pairs, uint32_t round, uint64_t seed,
                           int katzgraber, int32_t *out_info /*[n_pairs][2] nullable*/);
 
+/* Convexified loopy belief propagation (backbone inference), batched: replaces the lambda loop of LBP_convexified
+ * (NMC/nmc.py:126-160) together with LoopyBeliefPropagation (NMC/nmc.py:168-228) for n_problems seeds m_star on the
+ * context's (J, h).  Host arrays in, host arrays out; messages stay on the device.
+ *   h_lambda = h + lambda * m_star * epsilon; messages start at h_msgs = 0, u_msgs = J * m_star (NMC/nmc.py:128-129) and
+ *   are carried from one lambda to the next; each lambda iterates until both relative max-norm changes are below
+ *   `tolerance` or max_iterations is reached.  Exhausting the iterations at the first lambda sets status 1 (the
+ *   reference raises ValueError there); at a later lambda the previous marginals are kept and the loop stops.
+ *   lambdas: the host-computed list (lambda *= factor until < lambda_end or round(lambda, 6) == 0).
+ *   sat: clip bound of atanh_saturated (tanh(19.06) - eps, NMC/nmc.py:230-255).
+ * out_mag [n_problems][n]: marginals after the last processed lambda; out_mag_all (nullable)
+ * [n_problems][n_lambdas][n]: one row per processed lambda; out_n_lambdas [n_problems]; out_iters
+ * [n_problems][n_lambdas]: last iteration index per lambda; out_status [n_problems].
+ * fp64, row sums in ascending neighbour order: equal to the reference to rounding, not bit for bit.
+ * NLMC_ERR_ARG when the sparsity pattern of J is not symmetric. */
+int nlmc_lbp_convexified(nlmc_ctx *ctx, int n_problems, const double *m_star, const double *epsilon, const double *lambdas,
+                         int n_lambdas, double beta, double tolerance, int max_iterations, double sat,
+                         double *out_mag, double *out_mag_all, int32_t *out_n_lambdas, int32_t *out_iters,
+                         int32_t *out_status);
+
+/* Cluster growth of find_clusters (NMC/nmc.py:257-318) on the CSR neighbour lists -- host-side graph logic (no context,
+ * no device work; irregular and sequential by definition: seeds are served in ascending order and claim exclusively).
+ * out_members: clusters concatenated in creation order (capacity members_capacity >= n suffices when J has no
+ * diagonal), out_sizes [<= n], out_n_clusters.  Errors are reported through nlmc_last_error(NULL). */
+int nlmc_find_clusters(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals, const double *mag,
+                       double threshold_initial, double threshold_cutoff, double threshold_step, int32_t *out_members,
+                       int64_t members_capacity, int32_t *out_sizes, int32_t *out_n_clusters);
+
 /* Timing of the most recent sweep call, measured with HIP events on the context's stream. */
 int nlmc_last_timing(nlmc_ctx *ctx, float *ms_levelize, float *ms_sweep, int32_t *launches_sweep);
 /* Accumulated HIP-event timing of every sweep call since nlmc_timing_reset (one synchronisation, at read time).

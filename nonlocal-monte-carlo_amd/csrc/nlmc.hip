@@ -2,6 +2,8 @@
 #include "../../include/nlmc.h"
 #include "nlmc_kernels.h"
 #include "nlmc_pt_icm.h"
+#include "nlmc_lbp.h"
+#include "nlmc_host.h"
 
 #include <algorithm>
 #include <climits>
@@ -102,6 +104,10 @@ struct nlmc_ctx {
     DevBuf<uint8_t> pt_acc;
     // ICM
     DevBuf<int32_t> icm_label, icm_info, icm_pairs;
+    // loopy BP (edge graph built on first use)
+    bool lbp_graph_ready = false;
+    DevBuf<int32_t> lbp_src, lbp_rev, lbp_flag, lbp_out_i;
+    DevBuf<double> lbp_tJ, lbp_eps, lbp_ms, lbp_lams, lbp_w0, lbp_w1, lbp_hm, lbp_tot, lbp_mag, lbp_mag_all;
     // timing / stats
     std::vector<hipEvent_t> events;
     size_t ev_used = 0, ev_call_start = 0;
@@ -530,6 +536,9 @@ void nlmc_destroy(nlmc_ctx *c)
     c->spins.release(); c->best.release(); c->flags.release(); c->efix.release(); c->emin.release(); c->etrace.release();
     c->argmin.release(); c->energy.release(); c->tab.release(); c->ustream.release(); c->etrace_d.release();
     c->keys.release(); c->strace.release(); c->cfg.release(); c->scratch.release(); c->plan.release();
+    c->lbp_src.release(); c->lbp_rev.release(); c->lbp_flag.release(); c->lbp_out_i.release(); c->lbp_tJ.release();
+    c->lbp_eps.release(); c->lbp_ms.release(); c->lbp_lams.release(); c->lbp_w0.release(); c->lbp_w1.release();
+    c->lbp_hm.release(); c->lbp_tot.release(); c->lbp_mag.release(); c->lbp_mag_all.release();
     c->pt_tab.release(); c->pt_beta.release();
     c->slot_of_chain.release(); c->chain_of_slot.release(); c->pt_pairs.release(); c->pt_status.release();
     c->pt_acc.release(); c->pt_plan_pairs.release(); c->pt_plan_ok.release(); c->icm_label.release(); c->icm_info.release(); c->icm_pairs.release();
@@ -1054,6 +1063,96 @@ int nlmc_icm_round_philox(nlmc_ctx *c, const int32_t *pairs, int n_pairs, uint32
         HIP_TRY(c, hipMemcpyAsync(out_info, c->icm_info.p, sizeof(int32_t) * 2 * n_pairs, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    return NLMC_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// convexified loopy belief propagation (backbone inference), batched over problems
+// ------------------------------------------------------------------------------------------------------
+int nlmc_lbp_convexified(nlmc_ctx *c, int n_problems, const double *m_star, const double *epsilon, const double *lambdas,
+                         int n_lambdas, double beta, double tolerance, int max_iterations, double sat,
+                         double *out_mag, double *out_mag_all, int32_t *out_n_lambdas, int32_t *out_iters,
+                         int32_t *out_status)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (n_problems < 1 || n_lambdas < 1 || !m_star || !epsilon || !lambdas || !out_mag || !out_n_lambdas || !out_iters ||
+        !out_status || max_iterations < 0 || !(beta != 0.0))
+        return fail(c, NLMC_ERR_ARG, "nlmc_lbp_convexified: bad sizes or NULL arrays");
+    if (c->nnz > (int64_t)INT_MAX / 2) return fail(c, NLMC_ERR_UNSUPPORTED, "nlmc_lbp_convexified: nnz too large");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int n = c->n, nnz = (int)c->nnz;
+    const size_t P = (size_t)n_problems, E = (size_t)std::max(nnz, 1);
+    if (!c->lbp_graph_ready) {
+        HIP_TRY(c, c->lbp_src.reserve(E));
+        HIP_TRY(c, c->lbp_rev.reserve(E));
+        HIP_TRY(c, c->lbp_flag.reserve(1));
+        HIP_TRY(c, hipMemsetAsync(c->lbp_flag.p, 0, sizeof(int32_t), c->stream));
+        hipLaunchKernelGGL(k_lbp_src, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->rowptr.p, c->lbp_src.p);
+        HIP_TRY(c, hipGetLastError());
+        if (nnz > 0) {
+            hipLaunchKernelGGL(k_lbp_rev, dim3((nnz + 255) / 256), dim3(256), 0, c->stream, nnz, c->rowptr.p, c->col.p,
+                               c->lbp_src.p, c->lbp_rev.p, c->lbp_flag.p);
+            HIP_TRY(c, hipGetLastError());
+        }
+        int32_t flag = 0;
+        HIP_TRY(c, hipMemcpyAsync(&flag, c->lbp_flag.p, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (flag) return fail(c, NLMC_ERR_ARG, "LBP needs a structurally symmetric J");
+        c->lbp_graph_ready = true;
+    }
+    HIP_TRY(c, c->lbp_tJ.reserve(E));
+    HIP_TRY(c, c->lbp_eps.reserve((size_t)n));
+    HIP_TRY(c, c->lbp_ms.reserve(P * n));
+    HIP_TRY(c, c->lbp_lams.reserve((size_t)n_lambdas));
+    HIP_TRY(c, c->lbp_w0.reserve(P * E));
+    HIP_TRY(c, c->lbp_w1.reserve(P * E));
+    HIP_TRY(c, c->lbp_hm.reserve(P * E));
+    HIP_TRY(c, c->lbp_tot.reserve(P * n));
+    HIP_TRY(c, c->lbp_mag.reserve(P * n));
+    HIP_TRY(c, c->lbp_out_i.reserve(P * (2 + (size_t)n_lambdas)));
+    if (out_mag_all) HIP_TRY(c, c->lbp_mag_all.reserve(P * (size_t)n_lambdas * n));
+    HIP_TRY(c, hipMemcpyAsync(c->lbp_eps.p, epsilon, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->lbp_ms.p, m_star, sizeof(double) * P * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->lbp_lams.p, lambdas, sizeof(double) * n_lambdas, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->lbp_mag.p, 0, sizeof(double) * P * n, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->lbp_out_i.p, 0, sizeof(int32_t) * P * (2 + (size_t)n_lambdas), c->stream));
+    if (nnz > 0) {
+        hipLaunchKernelGGL(k_lbp_tanhJ, dim3((nnz + 255) / 256), dim3(256), 0, c->stream, nnz, c->val64.p, beta, c->lbp_tJ.p);
+        HIP_TRY(c, hipGetLastError());
+    }
+    LbpArgs a{};
+    a.n = n; a.nnz = nnz; a.n_lams = n_lambdas; a.max_iter = max_iterations;
+    a.rowptr = c->rowptr.p; a.col = c->col.p; a.src = c->lbp_src.p; a.rev = c->lbp_rev.p;
+    a.val = c->val64.p; a.tJ = c->lbp_tJ.p; a.h = c->h64.p; a.eps = c->lbp_eps.p; a.m_star = c->lbp_ms.p; a.lams = c->lbp_lams.p;
+    a.beta = beta; a.inv_beta = 1.0 / beta; a.tol = tolerance; a.sat = sat;
+    a.w0 = c->lbp_w0.p; a.w1 = c->lbp_w1.p; a.hm = c->lbp_hm.p; a.tot = c->lbp_tot.p; a.mag = c->lbp_mag.p;
+    a.mag_all = out_mag_all ? c->lbp_mag_all.p : nullptr;
+    a.out_nlam = c->lbp_out_i.p; a.out_status = c->lbp_out_i.p + P; a.out_iters = c->lbp_out_i.p + 2 * P;
+    hipLaunchKernelGGL(k_lbp, dim3(n_problems), dim3(NLMC_LBP_THREADS), 0, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    std::vector<int32_t> oi(P * (2 + (size_t)n_lambdas));
+    HIP_TRY(c, hipMemcpyAsync(oi.data(), c->lbp_out_i.p, sizeof(int32_t) * oi.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out_mag, c->lbp_mag.p, sizeof(double) * P * n, hipMemcpyDeviceToHost, c->stream));
+    if (out_mag_all)
+        HIP_TRY(c, hipMemcpyAsync(out_mag_all, c->lbp_mag_all.p, sizeof(double) * P * (size_t)n_lambdas * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::memcpy(out_n_lambdas, oi.data(), sizeof(int32_t) * P);
+    std::memcpy(out_status, oi.data() + P, sizeof(int32_t) * P);
+    std::memcpy(out_iters, oi.data() + 2 * P, sizeof(int32_t) * P * (size_t)n_lambdas);
+    return NLMC_OK;
+}
+
+int nlmc_find_clusters(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals, const double *mag,
+                       double threshold_initial, double threshold_cutoff, double threshold_step, int32_t *out_members,
+                       int64_t members_capacity, int32_t *out_sizes, int32_t *out_n_clusters)
+{
+    if (n < 1 || !rowptr || !mag || !out_members || !out_sizes || !out_n_clusters || (rowptr[n] > 0 && (!colidx || !vals)))
+        return fail(nullptr, NLMC_ERR_ARG, "nlmc_find_clusters: bad sizes or NULL arrays");
+    if (!(threshold_step > 0.0)) return fail(nullptr, NLMC_ERR_ARG, "nlmc_find_clusters: threshold_step must be > 0");
+    if (host_find_clusters(n, rowptr, colidx, vals, mag, threshold_initial, threshold_cutoff, threshold_step, out_members,
+                           members_capacity, out_sizes, out_n_clusters) != 0)
+        return fail(nullptr, NLMC_ERR_ARG, "nlmc_find_clusters: out_members too small");
     return NLMC_OK;
 }
 

@@ -1,0 +1,59 @@
+// nlmc_host.h -- host-side graph logic exported through the same C-ABI (no device work).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+// Cluster growth of find_clusters (NMC/nmc.py:257-318) on CSR neighbour lists.
+// Seeds = {|mag| >= thr_init} in ascending order; a seed not yet claimed opens a cluster and claims its unclaimed seed
+// neighbours (ascending); then, for thr = thr_init - step, thr - step, ... while thr > thr_cut, every cluster in turn
+// claims the unclaimed neighbours of its members with |mag| >= thr (ascending).  Neighbour = stored entry with J != 0.
+static int host_find_clusters(int n, const int32_t *rowptr, const int32_t *col, const double *val, const double *mag,
+                              double thr_init, double thr_cut, double thr_step, int32_t *out_members,
+                              int64_t members_cap, int32_t *out_sizes, int32_t *out_n_clusters)
+{
+    std::vector<uint8_t> in_cluster((size_t)n, 0), seed((size_t)n, 0);
+    std::vector<std::vector<int32_t>> clusters;
+    for (int k = 0; k < n; ++k) seed[k] = std::fabs(mag[k]) >= thr_init;
+    std::vector<int32_t> nb;
+    auto neighbours = [&](const std::vector<int32_t> &nodes) {
+        nb.clear();
+        for (int32_t k : nodes)
+            for (int e = rowptr[k]; e < rowptr[k + 1]; ++e)
+                if (val[e] != 0.0) nb.push_back(col[e]);
+        std::sort(nb.begin(), nb.end());
+        nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
+    };
+    std::vector<int32_t> one(1);
+    for (int s = 0; s < n; ++s) {
+        if (!seed[s] || in_cluster[s]) continue;
+        one[0] = s;
+        neighbours(one);
+        std::vector<int32_t> c;
+        c.push_back(s);
+        for (int32_t v : nb)
+            if (!in_cluster[v] && seed[v]) c.push_back(v);
+        for (int32_t v : c) in_cluster[v] = 1;
+        clusters.push_back(std::move(c));
+    }
+    double thr = thr_init - thr_step;
+    while (thr > thr_cut) {
+        for (auto &c : clusters) {
+            neighbours(c);
+            const size_t before = c.size();
+            for (int32_t v : nb)
+                if (!in_cluster[v] && std::fabs(mag[v]) >= thr) c.push_back(v);
+            for (size_t i = before; i < c.size(); ++i) in_cluster[c[i]] = 1;
+        }
+        thr -= thr_step;
+    }
+    int64_t at = 0;
+    for (size_t i = 0; i < clusters.size(); ++i) {
+        if (at + (int64_t)clusters[i].size() > members_cap) return -1;
+        for (int32_t v : clusters[i]) out_members[at++] = v;
+        out_sizes[i] = (int32_t)clusters[i].size();
+    }
+    *out_n_clusters = (int32_t)clusters.size();
+    return 0;
+}

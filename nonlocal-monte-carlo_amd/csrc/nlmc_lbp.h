@@ -1,0 +1,165 @@
+// nlmc_lbp.h -- convexified loopy belief propagation on the edge list (gfx950), SURVEY.md section 8 row f-1.
+//
+// Reference: NMC/nmc.py:93-228 (== NPT/npt.py:129-265).  The reference keeps dense N x N message matrices; here every
+// stored CSR entry e = (i -> j) of row i carries
+//     w[e]  = u_msgs[j, i]   the message INCOMING to i from j (so a node's total is a contiguous row sum)
+//     hm[e] = h_msgs[i, j]   the cavity field of i without j
+// One 1024-thread workgroup per problem (one m_star); all lambdas of LBP_convexified run inside one launch; Jacobi
+// iteration with ping-pong message buffers in global memory (L2 resident: 2 * nnz doubles per problem).
+// Arithmetic: fp64 in the reference's operation order, row sums sequential in ascending neighbour index (the
+// reference's `total` uses NumPy's pairwise association and NumPy's own tanh/arctanh, so results agree to rounding,
+// not bit for bit -- the bit-exact path is the host restatement in lbp.py; tolerance stated in tests/test_gpu_lbp.py).
+#pragma once
+#include "nlmc_kernels.h"
+
+#define NLMC_LBP_THREADS 1024
+
+struct LbpArgs {
+    int n, nnz, n_lams, max_iter;
+    const int32_t *rowptr, *col, *src, *rev;
+    const double *val;          // [nnz] normalised J
+    const double *tJ;           // [nnz] tanh(beta J)
+    const double *h;            // [n]
+    const double *eps;          // [n]  |h| + sum_j |J_ij|            (NMC/nmc.py:353)
+    const double *m_star;       // [P][n]
+    const double *lams;         // [n_lams]
+    double beta, inv_beta, tol, sat;   // sat = tanh(19.06) - eps: clip bound of atanh_saturated (NMC/nmc.py:230-255)
+    double *w0, *w1, *hm;       // [P][nnz]
+    double *tot;                // [P][n]
+    double *mag;                // [P][n]   final marginals
+    double *mag_all;            // [P][n_lams][n] or nullptr
+    int32_t *out_nlam;          // [P] number of lambdas processed (entries of the reference's marginals dict)
+    int32_t *out_iters;         // [P][n_lams] last iteration index per lambda
+    int32_t *out_status;        // [P] 0 ok, 1 = "LBP diverged at initial lambda"
+};
+
+__global__ void k_lbp_src(int n, const int32_t *rowptr, int32_t *src)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) src[e] = i;
+}
+
+// rev[e] = position of (j -> i) in row j; flag[0] = 1 when the pattern is not symmetric
+__global__ void k_lbp_rev(int nnz, const int32_t *rowptr, const int32_t *col, const int32_t *src, int32_t *rev, int32_t *flag)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const int i = src[e], j = col[e];
+    int lo = rowptr[j], hi = rowptr[j + 1] - 1, found = -1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const int c = col[mid];
+        if (c == i) { found = mid; break; }
+        if (c < i) lo = mid + 1; else hi = mid - 1;
+    }
+    if (found < 0) { flag[0] = 1; found = e; }
+    rev[e] = found;
+}
+
+__global__ void k_lbp_tanhJ(int nnz, const double *val, double beta, double *tJ)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nnz) tJ[e] = tanh(beta * val[e]);
+}
+
+__device__ __forceinline__ double lbp_wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(NLMC_LBP_THREADS) void k_lbp(LbpArgs a)
+{
+    __shared__ double red[4][NLMC_LBP_THREADS / 64];
+    __shared__ double res[4];
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = a.n, nnz = a.nnz;
+    double *wc = a.w0 + (size_t)p * nnz, *wn = a.w1 + (size_t)p * nnz;
+    double *hm = a.hm + (size_t)p * nnz, *tot = a.tot + (size_t)p * n, *mag = a.mag + (size_t)p * n;
+    const double *ms = a.m_star + (size_t)p * n;
+
+    // h_msgs = 0, u_msgs = J * m_star.reshape(1, -1)  (NMC/nmc.py:128-129): u_msgs[j, i] = J[j, i] * m_star[i]
+    for (int e = tid; e < nnz; e += NLMC_LBP_THREADS) {
+        wc[e] = a.val[a.rev[e]] * ms[a.src[e]];
+        hm[e] = 0.0;
+    }
+    for (int i = tid; i < n; i += NLMC_LBP_THREADS) tot[i] = 0.0;
+    __syncthreads();
+
+    int n_done = 0, status = 0;
+    for (int l = 0; l < a.n_lams; ++l) {
+        const double lam = a.lams[l];
+        int it = 0;
+        for (int iter = 0; iter < a.max_iter; ++iter) {
+            it = iter;
+            double dh_n = 0.0, dh_d = 0.0, du_n = 0.0, du_d = 0.0;
+            // ---- node totals: total_i = h_lam[i] + sum_k u_msgs[k, i]   (NMC/nmc.py:199-201)
+            for (int i = tid; i < n; i += NLMC_LBP_THREADS) {
+                const int e0 = a.rowptr[i], e1 = a.rowptr[i + 1];
+                double s = 0.0;
+                int offdiag = 0;
+                for (int e = e0; e < e1; ++e) { s += wc[e]; offdiag += a.col[e] != i; }
+                const double hl = a.h[i] + lam * ms[i] * a.eps[i];
+                const double t_new = hl + s, t_old = tot[i];
+                tot[i] = t_new;
+                if (offdiag < n - 1) {         // row i of the dense h_msgs has non-edge entries, all equal to total_i
+                    dh_n = fmax(dh_n, fabs(t_new - t_old));
+                    dh_d = fmax(dh_d, fabs(t_new) + fabs(t_old));
+                }
+            }
+            __syncthreads();
+            // ---- messages: h_msgs[i, j] = total_i - u_msgs[j, i];  u_msgs[i, j] = atanh_sat(tanh(bJ) tanh(b h_msgs)) / b
+            for (int e = tid; e < nnz; e += NLMC_LBP_THREADS) {
+                const int i = a.src[e], r = a.rev[e];
+                const double h_old = hm[e];
+                const double h_new = (a.col[e] != i) ? tot[i] - wc[e] : 0.0;
+                double x = a.tJ[e] * tanh(a.beta * h_new);
+                x = fmin(fmax(x, -a.sat), a.sat);
+                const double u_new = a.inv_beta * atanh(x);
+                const double u_old = wc[r];
+                hm[e] = h_new;
+                wn[r] = u_new;
+                dh_n = fmax(dh_n, fabs(h_new - h_old));
+                dh_d = fmax(dh_d, fabs(h_new) + fabs(h_old));
+                du_n = fmax(du_n, fabs(u_new - u_old));
+                du_d = fmax(du_d, fabs(u_new) + fabs(u_old));
+            }
+            dh_n = lbp_wave_max(dh_n); dh_d = lbp_wave_max(dh_d); du_n = lbp_wave_max(du_n); du_d = lbp_wave_max(du_d);
+            if (lane == 0) { red[0][wv] = dh_n; red[1][wv] = dh_d; red[2][wv] = du_n; red[3][wv] = du_d; }
+            __syncthreads();
+            if (tid < 4) {
+                double m = red[tid][0];
+                for (int k = 1; k < NLMC_LBP_THREADS / 64; ++k) m = fmax(m, red[tid][k]);
+                res[tid] = m;
+            }
+            __syncthreads();
+            { double *t = wc; wc = wn; wn = t; }
+            // 0/0 = NaN compares false, like the reference's `du < tolerance and dh < tolerance` (NMC/nmc.py:212-213)
+            const double dh = res[0] / res[1], du = res[2] / res[3];
+            if (du < a.tol && dh < a.tol) break;
+        }
+        if (tid == 0) a.out_iters[(size_t)p * a.n_lams + l] = it;
+        const bool exhausted = (it == a.max_iter - 1);
+        if (exhausted && l == 0) { status = 1; break; }          // NMC/nmc.py:142-144
+        if (!exhausted) {
+            // magnetizations = tanh(beta (h_lam + sum_k u_msgs[k, :]))  (NMC/nmc.py:216-217), rows added in ascending k
+            for (int i = tid; i < n; i += NLMC_LBP_THREADS) {
+                double s = 0.0;
+                for (int e = a.rowptr[i]; e < a.rowptr[i + 1]; ++e) s += wc[e];
+                mag[i] = tanh(a.beta * ((a.h[i] + lam * ms[i] * a.eps[i]) + s));
+            }
+        }
+        // exhausted at a later lambda: keep the previous marginals and stop (NMC/nmc.py:145-148)
+        if (a.mag_all) {
+            double *dst = a.mag_all + ((size_t)p * a.n_lams + l) * n;
+            __syncthreads();
+            for (int i = tid; i < n; i += NLMC_LBP_THREADS) dst[i] = mag[i];
+        }
+        n_done = l + 1;
+        if (exhausted) break;
+        __syncthreads();
+    }
+    if (tid == 0) { a.out_nlam[p] = n_done; a.out_status[p] = status; }
+}

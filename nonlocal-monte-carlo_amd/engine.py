@@ -253,6 +253,24 @@ class Engine:
                                                int(bool(katzgraber)), _abi.ptr(info)))
         return info
 
+    # -- backbone inference (loopy BP on the device) -------------------------------------------------------
+    def lbp_convexified(self, m_star, epsilon, lambdas, beta, tolerance, max_iterations, sat, want_all=False):
+        """Batched lambda loop of LBP_convexified (include/nlmc.h: nlmc_lbp_convexified).  m_star [P, n] float64.
+        Returns dict(mag [P, n], n_lambdas [P], iters [P, L], status [P], mag_all [P, L, n] or None)."""
+        ms = _abi.as_c(np.atleast_2d(m_star), np.float64)
+        P, L = ms.shape[0], len(lambdas)
+        if ms.shape[1] != self.n:
+            raise ValueError("m_star must be [n_problems, n]")
+        eps = _abi.as_c(epsilon, np.float64).reshape(-1)
+        lam = _abi.as_c(lambdas, np.float64).reshape(-1)
+        mag = np.zeros((P, self.n))
+        mag_all = np.zeros((P, L, self.n)) if want_all else None
+        nl, it, st = np.zeros(P, np.int32), np.zeros((P, L), np.int32), np.zeros(P, np.int32)
+        self._ck(self._L.nlmc_lbp_convexified(self._ctx, P, _abi.ptr(ms), _abi.ptr(eps), _abi.ptr(lam), L, float(beta),
+                                              float(tolerance), int(max_iterations), float(sat), _abi.ptr(mag),
+                                              _abi.ptr(mag_all), _abi.ptr(nl), _abi.ptr(it), _abi.ptr(st)))
+        return {"mag": mag, "n_lambdas": nl, "iters": it, "status": st, "mag_all": mag_all}
+
     # -- measurement ------------------------------------------------------------------------------------
     def last_timing(self):
         a, b, c = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int32(0)

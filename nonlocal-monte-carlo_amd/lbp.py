@@ -30,6 +30,8 @@ class EdgeGraph:
         self.indptr = inst.indptr.astype(np.int64)
         self.src = np.repeat(np.arange(self.n, dtype=np.int64), np.diff(self.indptr))   # i of entry (i -> j)
         self.dst = inst.indices.astype(np.int64)                                        # j
+        self.indptr32 = np.ascontiguousarray(inst.indptr, dtype=np.int32)
+        self.dst32 = np.ascontiguousarray(inst.indices, dtype=np.int32)
         self.val = inst.data
         # rev[e] = index of (j -> i): sort entries by (dst, src); the sorted sequence enumerates (i' = dst, j' = src)
         order = np.lexsort((self.src, self.dst))
@@ -96,7 +98,24 @@ def loopy_bp(g, h, beta, state, tolerance, max_iterations):
 
 
 def find_clusters(g, mag, threshold_initial, threshold_cutoff, threshold_step):
-    """NMC/nmc.py:257-318 with CSR neighbour lists instead of dense row scans (same visiting order, same output)."""
+    """NMC/nmc.py:257-318 with CSR neighbour lists instead of dense row scans (same visiting order, same output):
+    the compiled host routine behind include/nlmc.h: nlmc_find_clusters."""
+    from . import _abi
+    L = _abi.lib()
+    mag = _abi.as_c(mag, np.float64).reshape(-1)
+    ip, ix, v = g.indptr32, g.dst32, _abi.as_c(g.val, np.float64)
+    cap = int(max(g.n, ip[-1]) + g.n)
+    members, sizes, cnt = np.zeros(cap, np.int32), np.zeros(g.n, np.int32), np.zeros(1, np.int32)
+    _abi.check(L.nlmc_find_clusters(g.n, _abi.ptr(ip), _abi.ptr(ix), _abi.ptr(v), _abi.ptr(mag), float(threshold_initial),
+                                    float(threshold_cutoff), float(threshold_step), _abi.ptr(members), cap,
+                                    _abi.ptr(sizes), _abi.ptr(cnt)))
+    k = int(cnt[0])
+    cuts = np.cumsum(sizes[:k])[:-1] if k else []
+    return [c.astype(np.int64) for c in np.split(members[:int(sizes[:k].sum())], cuts)] if k else []
+
+
+def find_clusters_py(g, mag, threshold_initial, threshold_cutoff, threshold_step):
+    """Plain NumPy statement of the same routine (cross-check of nlmc_find_clusters in tests/test_host_lbp.py)."""
     n = g.n
     amag = np.abs(mag)
     seeds = np.where(amag >= threshold_initial)[0]
@@ -128,6 +147,37 @@ def find_clusters(g, mag, threshold_initial, threshold_cutoff, threshold_step):
             in_cluster[add] = True
         thr -= threshold_step
     return clusters
+
+
+def lambda_list(lambda_start, lambda_end, lambda_reduction_factor):
+    """The lambdas the loop of NMC/nmc.py:133-160 visits when nothing cuts it short."""
+    out, lam = [], lambda_start
+    while lam >= lambda_end:
+        out.append(lam)
+        lam = lam * lambda_reduction_factor
+        if round(lam, 6) == 0:
+            break
+    return out
+
+
+def lbp_convexified_device(eng, graph, lambda_start, lambda_end, lambda_reduction_factor, m_stars, epsilon, tolerance,
+                           max_iterations, threshold_initial, threshold_cutoff, global_beta, want_marginals=False):
+    """NMC/nmc.py:93-166 for a BATCH of seeds m_stars [P, N] with the message passing on the GPU
+    (include/nlmc.h: nlmc_lbp_convexified); the cluster growth stays on the host.  Returns a list of P cluster lists
+    (and the list of P {lambda: marginals} dicts when want_marginals)."""
+    lams = lambda_list(lambda_start, lambda_end, lambda_reduction_factor)
+    ms = np.atleast_2d(np.asarray(m_stars, dtype=np.float64))
+    if not lams:                    # the reference's loop body never runs: find_clusters(None) raises TypeError there
+        raise TypeError("bad operand type for abs(): 'NoneType'")
+    o = eng.lbp_convexified(ms, epsilon, lams, global_beta, tolerance, max_iterations, _SAT - EPS, want_all=want_marginals)
+    if np.any(o["status"] != 0):
+        raise ValueError('LBP diverged at initial lambda, please try a larger lambda_start or increase '
+                         'max_iterations or beta')
+    clusters = [find_clusters(graph, o["mag"][p], threshold_initial, threshold_cutoff, 0.01) for p in range(ms.shape[0])]
+    if not want_marginals:
+        return clusters
+    margs = [{lams[l]: o["mag_all"][p, l].copy() for l in range(int(o["n_lambdas"][p]))} for p in range(ms.shape[0])]
+    return clusters, margs
 
 
 def lbp_convexified(inst, lambda_start, lambda_end, lambda_reduction_factor, m_star, epsilon, tolerance,

@@ -53,3 +53,21 @@ def test_phase_flags(P):
     assert list(P.hostlogic.phase_flags(5, m, cl, "C")) == [2, 1, 2, 1, 2]
     assert list(P.hostlogic.phase_flags(5, m, cl, "NC")) == [0, 3, 0, 3, 0]
     assert list(P.hostlogic.phase_flags(5, m, cl, "ALL")) == [0] * 5
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_find_clusters_compiled_equals_numpy_statement(P, seed):
+    """include/nlmc.h: nlmc_find_clusters (compiled host routine) against the NumPy statement of NMC/nmc.py:257-318,
+    with the threshold-lowering loop active (step 0.01 from 0.95 down to 0.80) and inactive (reference defaults)."""
+    from helpers import make_instance
+    rng = np.random.default_rng(seed)
+    n = 400
+    J, h = make_instance(n, seed=seed)
+    g = P.lbp.EdgeGraph(P.Instance(J, h))
+    mag = np.tanh(rng.normal(0, 2.0, n))
+    mag[rng.random(n) < 0.2] = 1.0                      # saturated backbone spins
+    for t0, tc in ((0.95, 0.80), (0.999999, 0.99999), (0.5, 0.1), (2.0, 1.5)):
+        a = P.lbp.find_clusters(g, mag, t0, tc, 0.01)
+        b = P.lbp.find_clusters_py(g, mag, t0, tc, 0.01)
+        assert len(a) == len(b)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))

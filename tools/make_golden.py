@@ -374,6 +374,11 @@ def gen_known_answers():
     with open(os.path.join(cdir, "groundstates_otn2d.txt")) as f, \
             open(os.path.join(dst, "chimera128__groundstate_001.txt"), "w") as g:
         g.write(f.readline())
+    c2dir = os.path.join(REF, "NMC/examples/Chimera_droplet_instances/chimera2048_spinglass_power")
+    shutil.copyfile(os.path.join(c2dir, "001.txt"), os.path.join(dst, "chimera2048__001.txt"))
+    with open(os.path.join(c2dir, "groundstates_otn2d.txt")) as f, \
+            open(os.path.join(dst, "chimera2048__groundstate_001.txt"), "w") as g:
+        g.write(f.readline())
     ddir = os.path.join(REF, "NMC/examples/DCL_instances/C8")
     for f in sorted(os.listdir(ddir))[:2]:
         shutil.copyfile(os.path.join(ddir, f), os.path.join(dst, "DCL_C8__" + f))
