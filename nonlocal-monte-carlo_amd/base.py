@@ -8,6 +8,13 @@ RNG modes
   rng="philox"            throughput mode: visiting order and uniforms are generated on the device (counter-based
                Philox4x32-10); same Markov kernel, different stream.
 
+Backbone inference (LBP_convexified inside NMC_subroutine / NMC_task)
+  lbp="host"    edge-list restatement on the host with NumPy's own summation order: marginals, stopping lambda and
+                clusters equal the reference's bit for bit (default with rng="numpy").
+  lbp="device"  the message passing runs in the HIP kernel k_lbp, batched over replicas/restarts (default with
+                rng="philox"); equal to rounding -- see tests/test_gpu_lbp.py for what that means for the lambda at
+                which the reference's loop stops.
+
 Accepted-and-ignored: `use_hash_table` / `hash_table` (a CPU memoisation trick),
 `num_cores` (the process pool is replaced by one batched launch), plotting (opt-in through plot=True).
 """
@@ -18,7 +25,8 @@ import numpy as np
 
 from . import hostlogic
 from .engine import Engine, Instance
-from .lbp import EdgeGraph, lbp_convexified, loopy_bp, atanh_saturated as _atanh_saturated, find_clusters as _find_clusters
+from .lbp import (EdgeGraph, lbp_convexified, lbp_convexified_device, loopy_bp, atanh_saturated as _atanh_saturated,
+                  find_clusters as _find_clusters)
 
 EPS = np.finfo(float).eps
 
@@ -111,10 +119,27 @@ class Common(SweepMixin):
     """Methods NMC (NMC/nmc.py) and NPT (NPT/npt.py) share line for line in the reference."""
     _variant = "nmc"
 
-    def __init__(self, J, h, rng=None, seed=None, device=0):
+    def __init__(self, J, h, rng=None, seed=None, device=0, lbp=None):
         self.J = J
         self.h = np.asarray(h).reshape(-1)
         self._init_backend(rng, seed, device)
+        self.lbp = lbp if lbp is not None else os.environ.get("NLMC_LBP", "device" if self.rng == "philox" else "host")
+        if self.lbp not in ("host", "device"):
+            raise ValueError("lbp must be 'host' or 'device'")
+
+    def _detect_clusters(self, inst, graph, epsilon, m_stars, lambda_start, lambda_end, lambda_reduction_factor, tolerance,
+                         max_iterations, threshold_initial, threshold_cutoff, global_beta):
+        """LBP_convexified for a batch of seeds m_stars [P, N] -> list of P index arrays (clusters concatenated)."""
+        ms = np.atleast_2d(np.asarray(m_stars, dtype=np.float64))
+        if self.lbp == "device":
+            eng = self._cache.engine(self.J, self.h, 1)
+            cls = lbp_convexified_device(eng, graph, lambda_start, lambda_end, lambda_reduction_factor, ms, epsilon,
+                                         tolerance, max_iterations, threshold_initial, threshold_cutoff, global_beta)
+        else:
+            cls = [lbp_convexified(inst, lambda_start, lambda_end, lambda_reduction_factor, ms[p].copy(), epsilon,
+                                   tolerance, max_iterations, threshold_initial, threshold_cutoff, global_beta, graph=graph)
+                   for p in range(ms.shape[0])]
+        return [np.concatenate(cl).astype(int) if cl else np.array([], dtype=int) for cl in cls]
 
     # ------------------------------------------------------------------------------------------------
     def MCMC(self, num_sweeps, m_start, beta, J, h, anneal=False, sweeps_per_beta=1, initial_beta=0,
@@ -229,10 +254,10 @@ class Common(SweepMixin):
             return o
 
         def detect(ms):
-            cl = lbp_convexified(inst, lambda_start, lambda_end, lambda_reduction_factor, np.asarray(ms).copy(), epsilon,
-                                 tolerance, max_iterations, threshold_initial, threshold_cutoff, global_beta, graph=graph)
-            print(f"\ncluster size = {sum(len(c) for c in cl)}\n")
-            return np.concatenate(cl).astype(int) if cl else np.array([], dtype=int)
+            cl = self._detect_clusters(inst, graph, epsilon, ms, lambda_start, lambda_end, lambda_reduction_factor,
+                                       tolerance, max_iterations, threshold_initial, threshold_cutoff, global_beta)[0]
+            print(f"\ncluster size = {len(cl)}\n")
+            return cl
 
         if self._variant == "npt" and not provided:      # NPT/npt.py:397-403: LBP once per call
             all_clusters = detect(m_star)

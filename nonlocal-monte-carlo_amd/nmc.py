@@ -8,7 +8,6 @@ import numpy as np
 
 from . import hostlogic
 from .base import Common
-from .lbp import lbp_convexified
 
 
 class NMC(Common):
@@ -92,12 +91,9 @@ class NMC(Common):
             if S == 0:
                 break
             if all_clusters is None:
-                cls = []
-                for r in range(R):
-                    cl = lbp_convexified(inst, lambda_start, lambda_end, lambda_reduction_factor, m_star[r].astype(float),
-                                         epsilon, tolerance, max_iterations, threshold_initial, threshold_cutoff,
-                                         global_beta, graph=graph)
-                    cls.append(np.concatenate(cl).astype(int) if cl else np.array([], dtype=int))
+                cls = self._detect_clusters(inst, graph, epsilon, m_star.astype(float), lambda_start, lambda_end,
+                                            lambda_reduction_factor, tolerance, max_iterations, threshold_initial,
+                                            threshold_cutoff, global_beta)
             else:
                 cls = [np.asarray(all_clusters, dtype=int)] * R
             m = launch(m, S, flat, np.stack([hostlogic.phase_flags(N, m[r], cls[r], "C") for r in range(R)]))

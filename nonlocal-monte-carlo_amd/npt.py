@@ -151,13 +151,10 @@ class NPT(Common):
                         M[r * N:(r + 1) * N, :] = o["spins"][i].T
                 # --- NMC replicas: backbone per replica on the host, then the phases in lock step
                 if nm:
-                    clusters = []
-                    for r in nm:
-                        from .lbp import lbp_convexified
-                        cl = lbp_convexified(inst, lambda_start, lambda_end, lambda_reduction_factor,
-                                             m_start[r * N:(r + 1) * N, 0].copy(), epsilon, tolerance, max_iterations,
-                                             threshold_initial, threshold_cutoff, global_beta, graph=graph)
-                        clusters.append(np.concatenate(cl).astype(int) if cl else np.array([], dtype=int))
+                    clusters = self._detect_clusters(inst, graph, epsilon,
+                                                     np.stack([m_start[r * N:(r + 1) * N, 0] for r in nm]), lambda_start,
+                                                     lambda_end, lambda_reduction_factor, tolerance, max_iterations,
+                                                     threshold_initial, threshold_cutoff, global_beta)
                     m_init = np.stack([m_start[r * N:(r + 1) * N, 0] for r in nm]).astype(np.int8)
                     w = S_nmc // M_skip
                     traces = [np.zeros((N, len(phases) * w)) for _ in nm]

@@ -37,6 +37,22 @@ def c2():
     return {"config": "C2 NMC phases N=1e3 x 64 restarts", "sweeps": sweeps, "seconds": dt, "updates_per_s": R * N * sweeps / dt}
 
 
+def c2_full(lbp):
+    """C2 as NMC.run_restarts runs it: anneal, then per cycle backbone inference (LBP + cluster growth) per restart and
+    the three sweep phases -- nothing provided, so the Amdahl term of SURVEY.md 8 f-1 is inside the timed region."""
+    import contextlib, io
+    N, R, S_phase, cycles = 1000, 64, 333, 10
+    J, h = make_instance(N)
+    obj = P.NMC(J, h, rng="philox", seed=7, lbp=lbp)
+    with contextlib.redirect_stdout(io.StringIO()):
+        obj.run_restarts(2, 10, 10, 1)                     # warm-up: context, graph, kernels
+        obj = P.NMC(J, h, rng="philox", seed=7, lbp=lbp)
+        dt, (emin, _, _) = timed(lambda: obj.run_restarts(R, 10, S_phase, cycles, global_beta=3.0))
+    sweeps = 10 + 3 * cycles * S_phase
+    return {"config": f"C2 NMC.run_restarts N=1e3 x 64 restarts, backbone inference on the {lbp}", "sweeps": sweeps,
+            "seconds": dt, "updates_per_s": R * N * sweeps / dt, "min_energy": float(emin.min())}
+
+
 def c3():
     N, L, NL, S, rounds, pairs = 1000, 32, 8, 100, 100, 10
     J, h = make_instance(N)
@@ -90,3 +106,5 @@ def c5():
 if __name__ == "__main__":
     for f in (c2, c3, c5):
         print(json.dumps(f()), flush=True)
+    for mode in ("device", "host"):
+        print(json.dumps(c2_full(mode)), flush=True)
