@@ -133,8 +133,10 @@ class Common(SweepMixin):
         ms = np.atleast_2d(np.asarray(m_stars, dtype=np.float64))
         if self.lbp == "device":
             eng = self._cache.engine(self.J, self.h, 1)
-            cls = lbp_convexified_device(eng, graph, lambda_start, lambda_end, lambda_reduction_factor, ms, epsilon,
-                                         tolerance, max_iterations, threshold_initial, threshold_cutoff, global_beta)
+            return [c.astype(int) for c in
+                    lbp_convexified_device(eng, graph, lambda_start, lambda_end, lambda_reduction_factor, ms, epsilon,
+                                           tolerance, max_iterations, threshold_initial, threshold_cutoff, global_beta,
+                                           flat=True)]
         else:
             cls = [lbp_convexified(inst, lambda_start, lambda_end, lambda_reduction_factor, ms[p].copy(), epsilon,
                                    tolerance, max_iterations, threshold_initial, threshold_cutoff, global_beta, graph=graph)

@@ -102,6 +102,7 @@ struct nlmc_ctx {
     int pt_plan_rounds = 0, pt_plan_npairs = 0;
     uint64_t pt_plan_seed = 0;
     DevBuf<uint8_t> pt_acc;
+    std::vector<uint8_t> stage_in, stage_out;      // padded host staging for row copies
     // ICM
     DevBuf<int32_t> icm_label, icm_info, icm_pairs;
     // loopy BP (edge graph built on first use)
@@ -137,6 +138,12 @@ int fail(nlmc_ctx *c, int code, const std::string &msg)
         if (e__ != hipSuccess)                                                                             \
             return fail((c), NLMC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));            \
     } while (0)
+
+// [rows][n] host rows <-> [rows][n_pad] device rows.  Pitched 2-D copies from pageable memory are served row by row
+// by the runtime (~80 us per row); one linear copy through a padded staging buffer costs one transfer.
+int rows_to_device(nlmc_ctx *c, void *dst_dev, const void *src_host, int rows);
+int rows_to_host_begin(nlmc_ctx *c, const void *src_dev, int rows);               // async copy into c->stage
+void rows_to_host_finish(nlmc_ctx *c, void *dst_host, int rows);                  // after the stream was synchronised
 
 hipEvent_t next_event(nlmc_ctx *c)
 {
@@ -394,7 +401,8 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         need_sync = true;
     }
     if (o.out_argmin_state) {
-        HIP_TRY(c, hipMemcpy2DAsync(o.out_argmin_state, n, c->best.p, c->n_pad, n, R, hipMemcpyDeviceToHost, c->stream));
+        int rc = rows_to_host_begin(c, c->best.p, R);
+        if (rc) return rc;
         need_sync = true;
     }
     if (rec) {
@@ -402,10 +410,42 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         need_sync = true;
     }
     if (need_sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (o.out_argmin_state) rows_to_host_finish(c, o.out_argmin_state, R);
     const double inv = std::ldexp(1.0, -c->escale);
     if (o.out_energy) for (size_t i = 0; i < h_ll.size(); ++i) o.out_energy[i] = (double)h_ll[i] * inv;
     if (o.out_min_energy) for (int i = 0; i < R; ++i) o.out_min_energy[i] = (double)h_min[i] * inv;
     return NLMC_OK;
+}
+
+}  // namespace
+
+namespace {
+
+int rows_to_device(nlmc_ctx *c, void *dst_dev, const void *src_host, int rows)
+{
+    const size_t n = (size_t)c->n, np = (size_t)c->n_pad;
+    const void *src = src_host;
+    if (n != np) {
+        c->stage_in.assign(np * rows, 0);
+        for (int r = 0; r < rows; ++r) std::memcpy(c->stage_in.data() + r * np, (const uint8_t *)src_host + r * n, n);
+        src = c->stage_in.data();
+    }
+    HIP_TRY(c, hipMemcpyAsync(dst_dev, src, np * rows, hipMemcpyHostToDevice, c->stream));
+    if (n != np) HIP_TRY(c, hipStreamSynchronize(c->stream));      // the staging buffer is reused by the next call
+    return NLMC_OK;
+}
+
+int rows_to_host_begin(nlmc_ctx *c, const void *src_dev, int rows)
+{
+    c->stage_out.resize((size_t)c->n_pad * rows);
+    HIP_TRY(c, hipMemcpyAsync(c->stage_out.data(), src_dev, c->stage_out.size(), hipMemcpyDeviceToHost, c->stream));
+    return NLMC_OK;
+}
+
+void rows_to_host_finish(nlmc_ctx *c, void *dst_host, int rows)
+{
+    const size_t n = (size_t)c->n, np = (size_t)c->n_pad;
+    for (int r = 0; r < rows; ++r) std::memcpy((uint8_t *)dst_host + r * n, c->stage_out.data() + r * np, n);
 }
 
 }  // namespace
@@ -550,8 +590,9 @@ int nlmc_set_spins(nlmc_ctx *c, const int8_t *spins)
     if (!c || !spins) return fail(c, NLMC_ERR_ARG, "nlmc_set_spins: NULL argument");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->n_chains == 0) return NLMC_OK;
-    HIP_TRY(c, hipMemcpy2DAsync(c->spins.p, c->n_pad, spins, c->n, c->n, c->n_chains, hipMemcpyHostToDevice, c->stream));
-    int rc = launch_energy_self(c, nullptr);
+    int rc = rows_to_device(c, c->spins.p, spins, c->n_chains);
+    if (rc) return rc;
+    rc = launch_energy_self(c, nullptr);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return NLMC_OK;
@@ -562,8 +603,10 @@ int nlmc_get_spins(nlmc_ctx *c, int8_t *spins)
     if (!c || !spins) return fail(c, NLMC_ERR_ARG, "nlmc_get_spins: NULL argument");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->n_chains == 0) return NLMC_OK;
-    HIP_TRY(c, hipMemcpy2DAsync(spins, c->n, c->spins.p, c->n_pad, c->n, c->n_chains, hipMemcpyDeviceToHost, c->stream));
+    int rc = rows_to_host_begin(c, c->spins.p, c->n_chains);
+    if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    rows_to_host_finish(c, spins, c->n_chains);
     return NLMC_OK;
 }
 
@@ -576,7 +619,8 @@ int nlmc_set_flags(nlmc_ctx *c, const uint8_t *flags, double temp_x)
     for (size_t i = 0; i < (size_t)c->n_chains * c->n; ++i)
         if (flags[i] > 3) return fail(c, NLMC_ERR_ARG, "nlmc_set_flags: flag value out of range");
     if (c->n_chains > 0) {
-        HIP_TRY(c, hipMemcpy2DAsync(c->flags.p, c->n_pad, flags, c->n, c->n, c->n_chains, hipMemcpyHostToDevice, c->stream));
+        int rc = rows_to_device(c, c->flags.p, flags, c->n_chains);
+        if (rc) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     c->has_flags = true;

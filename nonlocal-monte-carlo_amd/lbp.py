@@ -97,7 +97,7 @@ def loopy_bp(g, h, beta, state, tolerance, max_iterations):
     return mag, it, (hm, u, tot)
 
 
-def find_clusters(g, mag, threshold_initial, threshold_cutoff, threshold_step):
+def find_clusters(g, mag, threshold_initial, threshold_cutoff, threshold_step, flat=False):
     """NMC/nmc.py:257-318 with CSR neighbour lists instead of dense row scans (same visiting order, same output):
     the compiled host routine behind include/nlmc.h: nlmc_find_clusters."""
     from . import _abi
@@ -110,8 +110,11 @@ def find_clusters(g, mag, threshold_initial, threshold_cutoff, threshold_step):
                                     float(threshold_cutoff), float(threshold_step), _abi.ptr(members), cap,
                                     _abi.ptr(sizes), _abi.ptr(cnt)))
     k = int(cnt[0])
-    cuts = np.cumsum(sizes[:k])[:-1] if k else []
-    return [c.astype(np.int64) for c in np.split(members[:int(sizes[:k].sum())], cuts)] if k else []
+    flat_members = members[:int(sizes[:k].sum())].astype(np.int64)
+    if flat:
+        return flat_members                    # == np.concatenate(clusters): all that NMC_subroutine consumes
+    cuts = np.cumsum(sizes[:k])
+    return [flat_members[a:b] for a, b in zip(np.concatenate([[0], cuts[:-1]]), cuts)]
 
 
 def find_clusters_py(g, mag, threshold_initial, threshold_cutoff, threshold_step):
@@ -161,10 +164,11 @@ def lambda_list(lambda_start, lambda_end, lambda_reduction_factor):
 
 
 def lbp_convexified_device(eng, graph, lambda_start, lambda_end, lambda_reduction_factor, m_stars, epsilon, tolerance,
-                           max_iterations, threshold_initial, threshold_cutoff, global_beta, want_marginals=False):
+                           max_iterations, threshold_initial, threshold_cutoff, global_beta, want_marginals=False,
+                           flat=False):
     """NMC/nmc.py:93-166 for a BATCH of seeds m_stars [P, N] with the message passing on the GPU
     (include/nlmc.h: nlmc_lbp_convexified); the cluster growth stays on the host.  Returns a list of P cluster lists
-    (and the list of P {lambda: marginals} dicts when want_marginals)."""
+    (flat=True: P concatenated index arrays) -- and the list of P {lambda: marginals} dicts when want_marginals."""
     lams = lambda_list(lambda_start, lambda_end, lambda_reduction_factor)
     ms = np.atleast_2d(np.asarray(m_stars, dtype=np.float64))
     if not lams:                    # the reference's loop body never runs: find_clusters(None) raises TypeError there
@@ -173,7 +177,8 @@ def lbp_convexified_device(eng, graph, lambda_start, lambda_end, lambda_reductio
     if np.any(o["status"] != 0):
         raise ValueError('LBP diverged at initial lambda, please try a larger lambda_start or increase '
                          'max_iterations or beta')
-    clusters = [find_clusters(graph, o["mag"][p], threshold_initial, threshold_cutoff, 0.01) for p in range(ms.shape[0])]
+    clusters = [find_clusters(graph, o["mag"][p], threshold_initial, threshold_cutoff, 0.01, flat=flat)
+                for p in range(ms.shape[0])]
     if not want_marginals:
         return clusters
     margs = [{lams[l]: o["mag_all"][p, l].copy() for l in range(int(o["n_lambdas"][p]))} for p in range(ms.shape[0])]

@@ -130,8 +130,15 @@ class NPT(Common):
         log_pairs, log_acc = [], []
         count = np.zeros(self.num_swap_attempts)
         try:
+            w = S_nmc // M_skip
+            if nm and S > 0 and len(phases) * w < S:       # NPT/npt.py:643-644: M[block] = M_nmc[:, -S:] cannot be filled
+                raise ValueError(f"could not broadcast input array from shape ({N},{len(phases) * w}) into shape ({N},{S})")
             for ii in range(self.num_swap_attempts):
                 print(f"\nRunning swap attempt = {ii + 1}")
+                # Only the LAST column of a round's block is ever read again (next start state, swap energies) -- except
+                # in the final round, whose block is what run() returns: traces are materialised there only.
+                last_round = ii == self.num_swap_attempts - 1
+                rs = 1 if last_round else 0
                 # --- draws in the reference's program order: replica by replica (NPT/npt.py:622-640 run in order)
                 streams = {}
                 if numpy_mode:
@@ -144,20 +151,24 @@ class NPT(Common):
                     btab = np.repeat(beta_list[mc][:, None], S, axis=1)
                     if numpy_mode:
                         o = eng_m.sweep_stream(np.stack([streams[r][0] for r in mc]), np.stack([streams[r][1] for r in mc]),
-                                               btab, record_stride=1)
+                                               btab, record_stride=rs)
                     else:
-                        o = eng_m.sweep_philox(S, self.seed, sweep0=self._sweep_counter, beta=btab, record_stride=1)
+                        o = eng_m.sweep_philox(S, self.seed, sweep0=self._sweep_counter, beta=btab, record_stride=rs)
+                    fin = None if last_round else eng_m.get_spins()
                     for i, r in enumerate(mc):
-                        M[r * N:(r + 1) * N, :] = o["spins"][i].T
-                # --- NMC replicas: backbone per replica on the host, then the phases in lock step
+                        if last_round:
+                            M[r * N:(r + 1) * N, :] = o["spins"][i].T
+                        else:
+                            M[r * N:(r + 1) * N, -1] = fin[i]
+                # --- NMC replicas: backbone per replica (one batch), then the phases in lock step
                 if nm:
                     clusters = self._detect_clusters(inst, graph, epsilon,
                                                      np.stack([m_start[r * N:(r + 1) * N, 0] for r in nm]), lambda_start,
                                                      lambda_end, lambda_reduction_factor, tolerance, max_iterations,
                                                      threshold_initial, threshold_cutoff, global_beta)
                     m_init = np.stack([m_start[r * N:(r + 1) * N, 0] for r in nm]).astype(np.int8)
-                    w = S_nmc // M_skip
-                    traces = [np.zeros((N, len(phases) * w)) for _ in nm]
+                    rec_n = last_round or M_skip != 1          # strided traces: keep the reference's column arithmetic
+                    traces = [np.zeros((N, len(phases) * w)) for _ in nm] if rec_n else None
                     at = 0
                     for p, kind in enumerate(phases):
                         fl = np.stack([hostlogic.phase_flags(N, m_init[i], clusters[i], kind) for i in range(len(nm))])
@@ -167,16 +178,23 @@ class NPT(Common):
                         if numpy_mode:
                             pp = np.stack([streams[r][0][p * S_nmc:(p + 1) * S_nmc] for r in nm])
                             uu = np.stack([streams[r][1][p * S_nmc:(p + 1) * S_nmc] for r in nm])
-                            o = eng_n.sweep_stream(pp, uu, btab, record_stride=1, want_min=True, want_state=True)
+                            o = eng_n.sweep_stream(pp, uu, btab, record_stride=int(rec_n), want_min=True, want_state=True)
                         else:
                             o = eng_n.sweep_philox(S_nmc, self.seed, sweep0=self._sweep_counter + S + p * S_nmc, beta=btab,
-                                                   order="per_chain", record_stride=1, want_min=True, want_state=True)
-                        for i in range(len(nm)):
-                            traces[i][:, at:at + w] = o["spins"][i].T[:, ::M_skip]
+                                                   order="per_chain", record_stride=int(rec_n), want_min=True,
+                                                   want_state=True)
+                        if rec_n:
+                            for i in range(len(nm)):
+                                traces[i][:, at:at + w] = o["spins"][i].T[:, ::M_skip]
                         at += w
                         m_init = o["argmin_state"].copy()
-                    for i, r in enumerate(nm):
-                        M[r * N:(r + 1) * N, :] = traces[i][:, -S:].copy()     # NPT/npt.py:643-644
+                    if rec_n:
+                        for i, r in enumerate(nm):
+                            M[r * N:(r + 1) * N, :] = traces[i][:, -S:].copy()     # NPT/npt.py:643-644
+                    else:
+                        fin = eng_n.get_spins()                # last trace column = state after the last phase
+                        for i, r in enumerate(nm):
+                            M[r * N:(r + 1) * N, -1] = fin[i]
                 if not numpy_mode:
                     self._sweep_counter += S + len(phases) * S_nmc
                 # --- swap step on the host, exactly as NPT/npt.py:646-680
