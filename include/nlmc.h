@@ -104,6 +104,14 @@ int nlmc_sweep_philox(nlmc_ctx *ctx, int precision, int order_mode, int n_sweeps
  * philox mode).  Later nlmc_sweep_philox calls inside that range with the same seed and precision skip their
  * schedule pass. */
 int nlmc_plan_philox(nlmc_ctx *ctx, int precision, int order_mode, uint32_t sweep0, int n_sweeps, uint64_t seed);
+/* Fused-window schedules for n_windows consecutive launches of exactly `window` sweeps each (sweeps sweep0 + w*window
+ * ...): all sweeps of a launch share one level list in which the tail of sweep t overlaps the head of sweep t+1
+ * (DESIGN.md section 3).  A later nlmc_sweep_philox call with F32, shared order, n_sweeps == window, a planned
+ * sweep0, constant beta and no per-sweep outputs (no recorded spins, energies or minima) runs on it; every other call
+ * takes the sweep-by-sweep path.  Results are bit-identical either way.  out_planned: number of windows that got a
+ * fused schedule (0 when the instance does not qualify: n outside the one-workgroup-of-1024 range, window < 3 or
+ * > 64, or the three uniform tables do not fit in LDS next to the spins). */
+int nlmc_plan_philox_fused(nlmc_ctx *ctx, uint32_t sweep0, int n_windows, int window, uint64_t seed, int32_t *out_planned);
 
 /* Replica exchange (NPT/npt.py:602-683).  Chains are grouped into ladders of ladder_len consecutive global
  * chain ids; slot r of a ladder runs at beta_list[r].  Accepted swaps exchange the beta slots of two chains

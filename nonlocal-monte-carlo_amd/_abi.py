@@ -22,7 +22,7 @@ MAX_N = 24576
 EXPORTS = [
     "nlmc_abi_version", "nlmc_device_count", "nlmc_create", "nlmc_destroy", "nlmc_last_error", "nlmc_set_spins",
     "nlmc_get_spins", "nlmc_set_flags", "nlmc_energy", "nlmc_energy_dev", "nlmc_energy_scale", "nlmc_energy_of", "nlmc_sweep_stream",
-    "nlmc_sweep_philox", "nlmc_plan_philox", "nlmc_pt_init", "nlmc_pt_get_slots", "nlmc_pt_set_slots",
+    "nlmc_sweep_philox", "nlmc_plan_philox", "nlmc_plan_philox_fused", "nlmc_pt_init", "nlmc_pt_get_slots", "nlmc_pt_set_slots",
     "nlmc_pt_apply_swap", "nlmc_pt_swap_philox", "nlmc_pt_plan", "nlmc_icm_components", "nlmc_icm_move", "nlmc_icm_get_labels", "nlmc_icm_round_philox",
     "nlmc_lbp_convexified", "nlmc_find_clusters",
     "nlmc_last_timing", "nlmc_timing_reset", "nlmc_timing_total", "nlmc_last_schedule_stats",
@@ -87,6 +87,8 @@ def lib():
     L.nlmc_sweep_philox.argtypes = [_vp, _i, _i, _i, _u32, _u64, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
     L.nlmc_plan_philox.restype = _i
     L.nlmc_plan_philox.argtypes = [_vp, _i, _i, _u32, _i, _u64]
+    L.nlmc_plan_philox_fused.restype = _i
+    L.nlmc_plan_philox_fused.argtypes = [_vp, _u32, _i, _i, _u64, _vp]
     L.nlmc_pt_init.restype = _i
     L.nlmc_pt_init.argtypes = [_vp, _i, _vp]
     L.nlmc_pt_apply_swap.restype = _i

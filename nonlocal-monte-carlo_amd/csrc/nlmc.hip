@@ -45,7 +45,7 @@ struct nlmc_ctx {
     double temp_x = 1.0;
     bool has_flags = false;
     bool has_diag = false;
-    size_t lds_opt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // dynamic-LDS opt-in already granted per kernel
+    size_t lds_opt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // dynamic-LDS opt-in already granted per kernel
 
     DevBuf<int32_t> rowptr, col;
     DevBuf<double> val64, h64;
@@ -90,6 +90,18 @@ struct nlmc_ctx {
     uint32_t plan_sweep0 = 0;
     int plan_count = 0;
     uint64_t plan_seed = 0;
+    // fused-window plan (k_levelize_fused / k_sweep_fused)
+    int max_deg = 0;
+    int stat_fused_window = -1;          // >= 0: the most recent sweep call ran this fused window
+    bool fz_valid = false;
+    uint32_t fz_sweep0 = 0;
+    int fz_windows = 0, fz_T = 0;
+    uint64_t fz_seed = 0;
+    std::vector<int32_t> fz_nlev_host;
+    DevBuf<uint16_t> fz_glv;
+    DevBuf<int2> fz_head;
+    DevBuf<EdgeF> fz_ell;
+    DevBuf<int32_t> fz_loff, fz_nlev, fz_himax, fz_send;
     // PT
     int ladder_len = 0;
     bool pt_tab_valid = false;
@@ -228,6 +240,89 @@ int run_levelize(nlmc_ctx *c, int n_orders, const uint32_t *keys_in, int per_cha
     return NLMC_OK;
 }
 
+// ---- fused-window path ------------------------------------------------------------------------------------
+constexpr int FUSED_WORKERS = 13;          // of the 16 waves of a 1024-thread workgroup; 3 waves generate uniforms
+
+// LDS of k_sweep_fused: spins | flags | 3 uniform tables | level offsets | sweep ends | reduction scratch
+struct FusedLds { int flags_off, u_off, u_bytes, loff_off, send_off, red_off; size_t total; };
+FusedLds fused_lds(int n, int n_pad, bool has_flags, int T)
+{
+    FusedLds L{};
+    L.flags_off = n_pad;
+    int cur = n_pad * (has_flags ? 2 : 1);
+    cur = (cur + 15) / 16 * 16;
+    L.u_off = cur;
+    L.u_bytes = (((n + 3) / 4 * 4) * 4 + 15) / 16 * 16;
+    cur += 3 * L.u_bytes;
+    L.loff_off = cur; cur += (NLMC_LCAP + 1) * 4;
+    cur = (cur + 15) / 16 * 16;
+    L.send_off = cur; cur += ((T + 3) / 4 * 4) * 4;
+    L.red_off = cur;
+    L.total = (size_t)cur + 16;
+    return L;
+}
+
+// Instances the fused kernels are built for: one full-size workgroup per chain, degree in 14 bits, three
+// uniform tables next to the spins in LDS (flags counted in: they may be switched on later).
+bool fused_supported(const nlmc_ctx *c, int T)
+{
+    if (getenv("NLMC_NO_FUSED")) return false;
+    if (sweep_block(c->n) != 1024 || c->max_deg > 0x3FFF || T < 3 || T > NLMC_FUSED_TMAX) return false;
+    if ((size_t)T * c->n > ((size_t)1 << 22)) return false;            // 32-bit buffer offsets of the packed planes
+    return fused_lds(c->n, c->n_pad, true, T).total <= (size_t)150 * 1024;
+}
+
+int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *tab_dev, int tab_cs, bool use_slots)
+{
+    const int R = c->n_chains, n = c->n, T = c->fz_T;
+    const size_t TN = (size_t)T * n;
+    const FusedLds L = fused_lds(c->n, c->n_pad, c->has_flags, T);
+    const void *kfun = c->has_diag ? reinterpret_cast<const void *>(k_sweep_fused<true>)
+                                   : reinterpret_cast<const void *>(k_sweep_fused<false>);
+    { int rc = ensure_lds(c, c->has_diag ? 9 : 8, kfun, L.total); if (rc) return rc; }
+    hipEvent_t e0 = next_event(c), e1 = next_event(c), e2 = next_event(c);
+    if (!e0 || !e1 || !e2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(c, hipEventRecord(e0, c->stream));
+    HIP_TRY(c, hipEventRecord(e1, c->stream));
+    SweepArgs a{};
+    a.g = c->g;
+    a.chain_base = c->chain_base;
+    a.spins = c->spins.p;
+    a.flags = c->has_flags ? c->flags.p : nullptr;
+    a.temp_x = c->temp_x;
+    a.lvl_off = c->fz_loff.p + (size_t)w * (NLMC_LCAP + 1);
+    a.nlev = c->fz_nlev.p + w;
+    a.hi_max = c->fz_himax.p + w;
+    a.ell32 = c->fz_ell.p + (size_t)w * TN * NLMC_ELL_W32;
+    a.head32 = c->fz_head.p + (size_t)w * TN;
+    a.fsend = c->fz_send.p + (size_t)w * T;
+    if (w + 1 < c->fz_windows && c->fz_nlev_host[(size_t)w + 1] > 0 && !getenv("NLMC_NO_WARM")) {
+        a.warm_head = c->fz_head.p + (size_t)(w + 1) * TN;
+        a.warm_ell = c->fz_ell.p + (size_t)(w + 1) * TN * NLMC_ELL_W32;
+    }
+    a.f_workers = FUSED_WORKERS;
+    a.n_sweeps = T;
+    a.sweep0 = sweep0;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.tab = tab_dev; a.tab_cs = tab_cs; a.tab_ss = 0;
+    a.slot_of_chain = use_slots ? c->slot_of_chain.p : nullptr;
+    a.efix = c->efix.p;
+    a.escale = c->escale;
+    a.trace_sweeps = T;
+    a.rec_stride = 1;
+    a.argmin = c->argmin.p;
+    a.lds_flags_off = L.flags_off; a.lds_u_off = L.u_off; a.lds_u_stride = L.u_bytes; a.lds_loff_off = L.loff_off;
+    a.lds_send_off = L.send_off; a.lds_red_off = L.red_off;
+    if (c->has_diag) hipLaunchKernelGGL((k_sweep_fused<true>), dim3(R), dim3(1024), L.total, c->stream, a);
+    else hipLaunchKernelGGL((k_sweep_fused<false>), dim3(R), dim3(1024), L.total, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(e2, c->stream));
+    c->launches_sweep++;
+    c->launches_total++;
+    c->stat_fused_window = w;
+    return NLMC_OK;
+}
+
 struct SweepOut {
     int record_stride;
     int8_t *out_spins;
@@ -251,6 +346,15 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
     c->stats_pending = false;
     if (R == 0 || n_sweeps == 0) return NLMC_OK;
     const bool want_min = o.out_min_energy || o.out_argmin || o.out_argmin_state;
+    c->stat_fused_window = -1;
+    // Fused-window schedule: planned ahead (nlmc_plan_philox_fused), same results, no per-sweep outputs possible
+    if (!stream_mode && precision == NLMC_F32 && order_mode == NLMC_ORDER_SHARED && !o.out_spins && !o.out_energy &&
+        !want_min && tab_ss == 0 && c->fz_valid && c->fz_seed == seed && n_sweeps == c->fz_T && sweep0 >= c->fz_sweep0 &&
+        (sweep0 - c->fz_sweep0) % (uint32_t)c->fz_T == 0 && (sweep0 - c->fz_sweep0) / (uint32_t)c->fz_T < (uint32_t)c->fz_windows &&
+        !getenv("NLMC_NO_FUSED")) {
+        const int w = (int)((sweep0 - c->fz_sweep0) / (uint32_t)c->fz_T);
+        if (c->fz_nlev_host[w] > 0) return run_fused(c, w, sweep0, seed, tab_dev, tab_cs, use_slots);
+    }
     const int rec = o.out_spins ? std::max(1, o.record_stride) : 0;
     const int n_rec = rec ? (n_sweeps + rec - 1) / rec : 0;
     if (o.out_energy) HIP_TRY(c, c->etrace.reserve((size_t)R * n_sweeps));
@@ -475,8 +579,10 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
     if (n > NLMC_MAX_N) return fail(nullptr, NLMC_ERR_UNSUPPORTED, "nlmc_create: n exceeds NLMC_MAX_N (spins are LDS-resident)");
     if (rowptr[0] != 0 || rowptr[n] != nnz) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: rowptr[0] != 0 or rowptr[n] != nnz");
     bool diag = false;
+    int max_deg = 0;
     for (int k = 0; k < n; ++k) {
         if (rowptr[k + 1] < rowptr[k]) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: rowptr not monotone");
+        max_deg = std::max(max_deg, (int)(rowptr[k + 1] - rowptr[k]));
         for (int e = rowptr[k]; e < rowptr[k + 1]; ++e) {
             if (colidx[e] < 0 || colidx[e] >= n) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: column index out of range");
             if (colidx[e] == k && vals[e] != 0.0) diag = true;
@@ -500,6 +606,7 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
     c->chain_base = chain_base;
     c->n_chains_global = n_chains_global;
     c->has_diag = diag;
+    c->max_deg = max_deg;
 
     // fixed-point scale: |E| <= sum|J|/2 + sum|h|
     double bound = 0.0;
@@ -576,6 +683,8 @@ void nlmc_destroy(nlmc_ctx *c)
     c->spins.release(); c->best.release(); c->flags.release(); c->efix.release(); c->emin.release(); c->etrace.release();
     c->argmin.release(); c->energy.release(); c->tab.release(); c->ustream.release(); c->etrace_d.release();
     c->keys.release(); c->strace.release(); c->cfg.release(); c->scratch.release(); c->plan.release();
+    c->fz_glv.release(); c->fz_head.release(); c->fz_ell.release(); c->fz_loff.release(); c->fz_nlev.release();
+    c->fz_himax.release(); c->fz_send.release();
     c->lbp_src.release(); c->lbp_rev.release(); c->lbp_flag.release(); c->lbp_out_i.release(); c->lbp_tJ.release();
     c->lbp_eps.release(); c->lbp_ms.release(); c->lbp_lams.release(); c->lbp_w0.release(); c->lbp_w1.release();
     c->lbp_hm.release(); c->lbp_tot.release(); c->lbp_mag.release(); c->lbp_mag_all.release();
@@ -792,6 +901,45 @@ int nlmc_plan_philox(nlmc_ctx *c, int precision, int order_mode, uint32_t sweep0
     return NLMC_OK;
 }
 
+int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int window, uint64_t seed, int32_t *out_planned)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (n_windows < 0 || window < 1) return fail(c, NLMC_ERR_ARG, "nlmc_plan_philox_fused: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->fz_valid = false;
+    if (out_planned) *out_planned = 0;
+    if (n_windows == 0 || !fused_supported(c, window)) return NLMC_OK;
+    const int n = c->n, T = window;
+    const size_t W = (size_t)n_windows, TN = (size_t)T * n;
+    HIP_TRY(c, c->fz_glv.reserve(W * TN));
+    HIP_TRY(c, c->fz_head.reserve(W * TN));
+    HIP_TRY(c, c->fz_ell.reserve(W * TN * NLMC_ELL_W32));
+    HIP_TRY(c, c->fz_loff.reserve(W * (NLMC_LCAP + 1)));
+    HIP_TRY(c, c->fz_nlev.reserve(W));
+    HIP_TRY(c, c->fz_himax.reserve(W));
+    HIP_TRY(c, c->fz_send.reserve(W * T));
+    FusedLevelizeArgs a{};
+    a.g = c->g;
+    a.T = T;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.sweep0 = sweep0;
+    a.level_cap = FUSED_WORKERS * 64;
+    a.glv = c->fz_glv.p; a.head = c->fz_head.p; a.ell = c->fz_ell.p; a.loff = c->fz_loff.p; a.nlev = c->fz_nlev.p;
+    a.hi_max = c->fz_himax.p; a.send = c->fz_send.p;
+    const size_t lds = (size_t)n * 4 + 2 * (size_t)((n + 1) & ~1) * 2 + 2 * (size_t)(NLMC_LCAP + 2) * 4 + 16;
+    { int rc = ensure_lds(c, 10, reinterpret_cast<const void *>(k_levelize_fused), lds); if (rc) return rc; }
+    hipLaunchKernelGGL(k_levelize_fused, dim3(n_windows), dim3(1024), lds, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    c->fz_nlev_host.assign(W, 0);
+    HIP_TRY(c, hipMemcpyAsync(c->fz_nlev_host.data(), c->fz_nlev.p, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int ok = 0;
+    for (int32_t v : c->fz_nlev_host) ok += v > 0;
+    c->fz_valid = true;
+    c->fz_sweep0 = sweep0; c->fz_windows = n_windows; c->fz_T = T; c->fz_seed = seed;
+    if (out_planned) *out_planned = ok;
+    return NLMC_OK;
+}
+
 int nlmc_last_timing(nlmc_ctx *c, float *ms_levelize, float *ms_sweep, int32_t *launches_sweep)
 {
     if (!c) return NLMC_ERR_ARG;
@@ -842,6 +990,11 @@ int nlmc_last_schedule_stats(nlmc_ctx *c, int64_t *n_orders, int64_t *n_levels)
 {
     if (!c) return NLMC_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->stat_fused_window >= 0) {       // one merged level list for fz_T sweeps
+        if (n_orders) *n_orders = c->fz_T;
+        if (n_levels) *n_levels = c->fz_nlev_host[(size_t)c->stat_fused_window];
+        return NLMC_OK;
+    }
     const int32_t *p = c->stats_pending ? c->stats_nlev_ptr : (c->plan_valid ? c->plan.nlev.p : nullptr);
     const int64_t cnt = c->stats_pending ? c->stats_nlev_count : (c->plan_valid ? c->plan_count : 0);
     int64_t lv = 0;

@@ -200,9 +200,138 @@ __global__ void k_levelize(LevelizeArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------------
+// fused-window level schedule: ONE level list for T consecutive sweeps (see k_sweep_fused)
+// ------------------------------------------------------------------------------------------------------
+#define NLMC_LCAP 1024          // level offsets of one schedule kept in LDS by the sweep kernels
+#define NLMC_FUSED_TMAX 64
+struct FusedLevelizeArgs {
+    CsrDev g;
+    int T;                    // sweeps per window
+    uint32_t seed_lo, seed_hi, sweep0;     // window w covers sweeps sweep0 + w T ... + T - 1 (shared order, group 0)
+    int level_cap;            // 64 x worker waves of k_sweep_fused
+    uint16_t *glv;            // scratch [n_windows][T][n]: level of update (t, k), 1-based
+    int2 *head;               // [n_windows][T n]   { k | deg << 16 | (t mod 3) << 30, bits of (float)h_k }
+    EdgeF *ell;               // [n_windows][8][T n][2]   row window planes, position-minor
+    int32_t *loff;            // [n_windows][NLMC_LCAP + 1] published level offsets
+    int32_t *nlev;            // [n_windows] published levels; 0 = deeper than NLMC_LCAP - 1 (caller falls back)
+    int32_t *hi_max;          // [n_windows] most rows longer than 8 entries in any level
+    int32_t *send;            // [n_windows][T] published index of the last level that holds an item of sweep t
+};
+
+// Level of update (t, k) = 1 + max over: its own update of sweep t-1; every neighbour's update of sweep t that comes
+// earlier in the order of sweep t; every other neighbour's update of sweep t-1 (its value is read, and it must not be
+// overwritten before the neighbours of sweep t-1 that read the old one are done -- they precede by the same rule);
+// and the end of sweep t-2 (at most two sweeps live per level: three uniform tables suffice).
+// LDS: key u32[n] | gA u16[n] | gB u16[n] | hist u32[LCAP + 2] | histL u32[LCAP + 2]
+__global__ void k_levelize_fused(FusedLevelizeArgs a)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int n = a.g.n, T = a.T, w = blockIdx.x;
+    uint32_t *key = reinterpret_cast<uint32_t *>(lds_raw);
+    uint16_t *gA = reinterpret_cast<uint16_t *>(lds_raw + (size_t)n * 4);
+    uint16_t *gB = gA + ((n + 1) & ~1);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(gB + ((n + 1) & ~1));
+    uint32_t *histL = hist + NLMC_LCAP + 2;
+    __shared__ int sh_lmax[NLMC_FUSED_TMAX];
+    __shared__ int sh_max, sh_fail, sh_himax, sh_nlev;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    uint16_t *gprev = gA, *gcur = gB;
+    for (int k = tid; k < n; k += nt) gprev[k] = 0;
+    for (int l = tid; l < 2 * (NLMC_LCAP + 2); l += nt) hist[l] = 0u;      // hist and histL are adjacent
+    if (tid == 0) { sh_fail = 0; sh_himax = 0; }
+    __syncthreads();
+    uint16_t *glv = a.glv + (size_t)w * T * n;
+
+    for (int t = 0; t < T; ++t) {
+        const uint32_t tt = a.sweep0 + (uint32_t)(w * T + t);
+        for (int k = tid; k < n; k += nt) {
+            key[k] = philox4x32_10((uint32_t)k, tt, 0u, NLMC_TAG_ORDER, a.seed_lo, a.seed_hi).x;
+            gcur[k] = 0;
+        }
+        if (tid == 0) sh_max = 0;
+        __syncthreads();
+        const int floor_lv = t >= 2 ? sh_lmax[t - 2] : 0;
+        for (int it = 0; it <= n; ++it) {          // chaotic relaxation to the least fixed point (values only grow)
+            int changed = 0;
+            for (int k = tid; k < n; k += nt) {
+                const uint32_t kk = key[k];
+                int m = max((int)gprev[k], floor_lv);
+                for (int e = a.g.rowptr[k]; e < a.g.rowptr[k + 1]; ++e) {
+                    const int j = a.g.col[e];
+                    if (j != k) m = max(m, precedes(key[j], j, kk, k) ? (int)gcur[j] : (int)gprev[j]);
+                }
+                m = min(m + 1, 65535);
+                if (m != (int)gcur[k]) { gcur[k] = (uint16_t)m; changed = 1; }
+            }
+            if (!__syncthreads_or(changed)) break;
+        }
+        int lmax = 0;
+        for (int k = tid; k < n; k += nt) {
+            const int lv = (int)gcur[k];
+            lmax = max(lmax, lv);
+            glv[(size_t)t * n + k] = (uint16_t)lv;
+            if (lv <= NLMC_LCAP) {
+                atomicAdd(&hist[lv], 1u);
+                if (a.g.rowptr[k + 1] - a.g.rowptr[k] > 8) atomicAdd(&histL[lv], 1u);
+            }
+        }
+        atomicMax(&sh_max, lmax);
+        __syncthreads();
+        if (tid == 0) { sh_lmax[t] = sh_max; if (sh_max > NLMC_LCAP) sh_fail = 1; }
+        __syncthreads();
+        uint16_t *tmp = gprev; gprev = gcur; gcur = tmp;
+    }
+
+    // publish offsets: levels 1..L in order, each split into chunks of level_cap; hist[lv] becomes the level's start
+    if (tid == 0) {
+        const int L = sh_lmax[T - 1];
+        int32_t *off = a.loff + (size_t)w * (NLMC_LCAP + 1);
+        int m = 0, run = 0, t_next = 0, himax = 0;
+        if (!sh_fail) {
+            for (int lv = 1; lv <= L; ++lv) {
+                const int cnt = (int)hist[lv];
+                hist[lv] = (uint32_t)run;
+                himax = max(himax, (int)histL[lv]);
+                for (int p = 0; p < cnt; p += a.level_cap) { if (m < NLMC_LCAP) off[m] = run + p; ++m; }
+                run += cnt;
+                while (t_next < T && sh_lmax[t_next] == lv) a.send[(size_t)w * T + t_next++] = m - 1;
+            }
+            hist[L + 1] = (uint32_t)run;
+            if (m >= NLMC_LCAP) sh_fail = 1; else off[m] = run;
+        }
+        sh_nlev = sh_fail ? 0 : m;
+        a.nlev[w] = sh_nlev;
+        a.hi_max[w] = himax;
+    }
+    __syncthreads();
+    if (sh_nlev == 0) return;
+
+    // placement: rows longer than 8 entries from the front of their level, the others from the back
+    for (int l = tid; l <= NLMC_LCAP; l += nt) histL[l] = hist[l + 1];     // back cursor of level l = start of level l+1
+    __syncthreads();
+    const size_t TN = (size_t)T * n;
+    int2 *head = a.head + (size_t)w * TN;
+    int4 *ell = reinterpret_cast<int4 *>(a.ell) + (size_t)w * (NLMC_ELL_W32 / 2) * TN;
+    for (int t = 0; t < T; ++t) {
+        for (int k = tid; k < n; k += nt) {
+            const int lv = (int)glv[(size_t)t * n + k];
+            const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
+            const uint32_t pos = deg > 8 ? atomicAdd(&hist[lv], 1u) : atomicSub(&histL[lv], 1u) - 1u;
+            head[pos] = make_int2(k | (deg << 16) | ((t % 3) << 30), __float_as_int(a.g.h32[k]));
+#pragma unroll
+            for (int q = 0; q < NLMC_ELL_W32; q += 2) {
+                EdgeF e0{0, 0.0f}, e1{0, 0.0f};
+                if (q < deg) e0 = a.g.edge32[rs + q];
+                if (q + 1 < deg) e1 = a.g.edge32[rs + q + 1];
+                ell[(size_t)(q / 2) * TN + pos] = make_int4(e0.col, __float_as_int(e0.val), e1.col, __float_as_int(e1.val));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // sweeps
 // ------------------------------------------------------------------------------------------------------
-#define NLMC_LCAP 1024          // level offsets of one sweep kept in LDS by the pipelined path
 #ifdef NLMC_STAMPS
 #define NLMC_CLK(v) { __builtin_amdgcn_sched_barrier(0); v = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
 #else
@@ -246,6 +375,12 @@ struct SweepArgs {
     int lds_flags_off, lds_u_off, lds_loff_off, lds_red_off;
     int lds_u_stride, lds_loff_stride;   // bytes between the two copies (0: single-buffered)
     long long *dbg;           // diagnostic build (-DNLMC_STAMPS) only: per-wave cycle sums [chains][16][4]
+    // fused-window schedule (k_sweep_fused): one merged level list for all n_sweeps of the launch
+    const int32_t *fsend;     // [n_sweeps] published index of the last level holding an item of sweep t
+    const int2 *warm_head;    // head / plane arrays of the NEXT planned window (or nullptr): pulled towards the chip by
+    const EdgeF *warm_ell;    // the helper waves while this window runs
+    int f_workers;            // waves that take schedule items; the remaining waves prepare uniforms
+    int lds_send_off;
 };
 
 // ---- pieces shared by the two sweep kernels ------------------------------------------------------------
@@ -256,6 +391,7 @@ struct ChainCtx {
     uint8_t *fl;
     long long *red;
     int tid, nt, c, n, n_pad;
+    int ustride;              // fused schedule: bytes between the uniform tables of consecutive table slots
     long long e_loc, E, Emin;
     int amin;
     bool per_sweep;
@@ -265,6 +401,7 @@ __device__ __forceinline__ void chain_load(const SweepArgs &a, unsigned char *ld
 {
     x.st = nullptr;
     x.lvl_t = nullptr;
+    x.ustride = a.lds_u_stride;
     x.n = a.g.n; x.n_pad = a.g.n_pad;
     x.tid = threadIdx.x; x.nt = blockDim.x; x.c = blockIdx.x;
     x.s = reinterpret_cast<int8_t *>(lds_raw);
@@ -497,15 +634,18 @@ __device__ __forceinline__ double fma_rn(double a, double b, double c) { return 
 
 // Heat-bath update of one spin from a prefetched schedule item.  J*s is exact (s = +-1), so fma(J, s, x) == x + J*s;
 // the zero-padded slots add +-0 and leave x unchanged, which keeps the oracle's row-order sum bit for bit.
-template <typename T, bool DIAG, bool TAIL>
+template <typename T, bool DIAG, bool TAIL, bool FUSED = false>
 __device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, const T *ur, const Pf<T> &pf, size_t oid, int i,
                                             T cb0, T cb1, double esc)
 {
-    const int k = pf.kd() & 0xFFFF, deg = (int)((unsigned)pf.kd() >> 16);
+    // fused schedule items carry the uniform-table slot of their sweep (t mod 3) in the two top bits
+    const int k = pf.kd() & 0xFFFF, deg = FUSED ? (int)(((unsigned)pf.kd() >> 16) & 0x3FFFu) : (int)((unsigned)pf.kd() >> 16);
     const unsigned f = x.fl ? (unsigned)x.fl[k] : 0u;
     if (f >= 2u) return;                       // frozen
     int8_t *s = x.s;
-    const T uk = ur[k];                        // issued up front with the gathers: off the dependent chain
+    const T *urs = FUSED ? reinterpret_cast<const T *>(reinterpret_cast<const unsigned char *>(ur) +
+                                                        ((unsigned)pf.kd() >> 30) * (unsigned)x.ustride) : ur;
+    const T uk = urs[k];                       // issued up front with the gathers: off the dependent chain
     const int so = (int)s[k];
 #ifdef NLMC_STAMPS
     long long u0, u1, u2, u3, u4;
@@ -540,7 +680,7 @@ __device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, con
         }
     }
     if (deg > W) {                             // rows longer than the packed window: rest from the CSR arrays
-        const int rs = a.ord2[oid * x.n + i].y;
+        const int rs = FUSED ? a.g.rowptr[k] : a.ord2[oid * x.n + i].y;
         for (int e = W; e < deg; ++e) {
             int j; T v;
             Pf<T>::tail(a.g, rs + e, j, v);
@@ -610,9 +750,9 @@ __device__ __forceinline__ void fill_uniforms(double *ur, int n, uint32_t tt, ui
 
 // The pipelined level loop of one sweep (see k_sweep_philox).  TAIL: this wave may hold rows longer than 8 entries and
 // therefore also loads / folds the second half of the 16-entry row window.
-template <typename T, bool DIAG, bool TAIL>
+template <typename T, bool DIAG, bool TAIL, bool FUSED = false>
 __device__ __forceinline__ void run_levels(const SweepArgs &a, ChainCtx &x, const T *ur, const int *loff, size_t so, int nl,
-                                           int n_bar, T cb0, T cb1, double esc)
+                                           int n_bar, T cb0, T cb1, double esc, int n_items = 0)
 {
     // n_bar: levels [0, n_bar) end with a workgroup barrier; levels [n_bar, nl) are at most one wave wide and belong
     // to wave 0 alone, which runs them back to back (LDS executes one wave's accesses in order, so its own writes are
@@ -620,7 +760,7 @@ __device__ __forceinline__ void run_levels(const SweepArgs &a, ChainCtx &x, cons
     // software pipeline over levels: while level l is computed, the schedule items of level l+1 are in flight.
     // Their addresses depend only on the level offsets (LDS), never on spin values, and the schedule was built with
     // level_cap == blockDim.x: at most one spin per thread and level.
-    const int n = x.n, tid = x.tid;
+    const int n = FUSED ? n_items : x.n, tid = x.tid;     // positions per plane of the packed schedule
     Pf<T> pfa, pfb;                // ping-pong (manual 2x unroll: no register rotation)
     bool va, vb;                   // lane has an item in the level held by pfa / pfb
     int ia, ib;
@@ -660,12 +800,12 @@ __device__ __forceinline__ void run_levels(const SweepArgs &a, ChainCtx &x, cons
 #endif
     for (; l < n_live; l += 2) {
         fetch(l + 1, pfb, vb, ib);
-        if (va) update_spin<T, DIAG, TAIL>(a, x, ur, pfa, so, ia, cb0, cb1, esc);
+        if (va) update_spin<T, DIAG, TAIL, FUSED>(a, x, ur, pfa, so, ia, cb0, cb1, esc);
         if (l < n_bar) __syncthreads();
         NLMC_LVL_STAMP(l)
         if (l + 1 < nl) {
             fetch(l + 2, pfa, va, ia);
-            if (vb) update_spin<T, DIAG, TAIL>(a, x, ur, pfb, so, ib, cb0, cb1, esc);
+            if (vb) update_spin<T, DIAG, TAIL, FUSED>(a, x, ur, pfb, so, ib, cb0, cb1, esc);
             if (l + 1 < n_bar) __syncthreads();
             NLMC_LVL_STAMP(l + 1)
         }
@@ -792,6 +932,102 @@ __global__ void k_sweep_philox(SweepArgs a)
         d[6] = (long long)__builtin_readcyclecounter() - st_begin; d[7] = st_epi;
     }
 #endif
+    chain_store(a, x);
+}
+
+// ---- fused-window sweeps ----------------------------------------------------------------------------------
+// All sweeps of a launch share ONE level list (k_levelize_fused): an update of sweep t+1 is scheduled as soon as the
+// updates it depends on -- earlier neighbours of sweep t+1, every neighbour's and its own update of sweep t -- are
+// done, so the narrow tail of sweep t overlaps the wide head of sweep t+1 and every level is ~0.07 n wide.  The
+// sequential semantics (and therefore every result bit) are those of the sweep-by-sweep schedule.  At most two sweeps
+// are live in any level (k_levelize_fused floors sweep t+2 behind the end of sweep t), uniforms live in three LDS
+// tables (slot = t mod 3): while sweeps t, t+1 run, the helper waves fill the table of sweep t+2 (its slot was freed
+// when sweep t-1 ended).  Worker waves [0, f_workers) take the items (level cap = 64 f_workers), helper waves only
+// generate uniforms; all execute the same number of barriers.  No per-sweep epilogue: used when the caller wants
+// neither per-sweep energies, nor recorded configurations, nor the running minimum, and beta is constant.
+template <bool DIAG>
+__global__ void k_sweep_fused(SweepArgs a)
+{
+    typedef float T;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    ChainCtx x;
+    chain_load(a, lds_raw, x);
+    if ((unsigned)reinterpret_cast<size_t>(lds_raw) != 0u) __builtin_trap();   // see k_sweep_philox
+    const int n = x.n, tid = x.tid, nt = x.nt, c = x.c;
+    T *ur = reinterpret_cast<T *>(lds_raw + a.lds_u_off);
+    int *loff = reinterpret_cast<int *>(lds_raw + a.lds_loff_off);
+    int *send = reinterpret_cast<int *>(lds_raw + a.lds_send_off);
+    const uint32_t gc = (uint32_t)(a.chain_base + c);
+    const int row = a.slot_of_chain ? a.slot_of_chain[gc] : c;
+    const double esc = __longlong_as_double((long long)(1023 + a.escale) << 52);
+    const int Tn = a.n_sweeps, nl = a.nlev[0];
+    const T cb0 = (T)a.tab[(size_t)row * a.tab_cs], cb1 = (T)a.tab[(size_t)row * a.tab_cs + 1];
+
+    // prologue: uniforms of the first three sweeps, level offsets, sweep ends
+    for (int t = 0; t < min(3, Tn); ++t)
+        fill_uniforms(reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(ur) + (size_t)t * a.lds_u_stride), n,
+                      a.sweep0 + (uint32_t)t, gc, a.seed_lo, a.seed_hi, tid, nt);
+    for (int l = tid; l <= nl; l += nt) loff[l] = a.lvl_off[l];
+    for (int t = tid; t < Tn; t += nt) send[t] = a.fsend[t];
+    __syncthreads();
+
+    const int wbase = tid & ~63;
+    if (wbase < a.f_workers * 64) {
+        const bool role_long = wbase < a.hi_max[0];
+        if (role_long) run_levels<T, DIAG, true, true>(a, x, ur, loff, 0, nl, nl, cb0, cb1, esc, Tn * n);
+        else run_levels<T, DIAG, false, true>(a, x, ur, loff, 0, nl, nl, cb0, cb1, esc, Tn * n);
+    } else {
+        const int hid = tid - a.f_workers * 64, hcnt = nt - a.f_workers * 64;
+        const int nblk = (n + 3) / 4, nj = (nblk + hcnt - 1) / hcnt;      // Philox calls per helper lane and sweep
+        // Second job of the helpers: pull the NEXT window's schedule towards the chip.  A window's schedule (72 B per
+        // update actually touched) is read once per launch and sits in HBM when many windows were planned ahead; the
+        // workers prefetch one level (~1 us) ahead, which does not cover a cold miss that every chain of an XCD then
+        // waits on (measured: 236 us per launch cold vs 191 us when the window is still in the memory-side cache).
+        // The chains of a launch share the work: one dword per 128-byte line of the head array and of planes 0-3,
+        // striped over chains and helper lanes, one load per level, retired a level later.
+        const unsigned warm_lines = a.warm_head ? (unsigned)(((size_t)Tn * n * 8 + 127) / 128) : 0u;       // head
+        const unsigned warm_lines_p = a.warm_head ? (unsigned)(((size_t)Tn * n * 16 * 4 + 127) / 128) : 0u; // planes 0-3
+        unsigned warm_at = (unsigned)c * (unsigned)hcnt + (unsigned)hid;
+        const unsigned warm_step = gridDim.x * (unsigned)hcnt;
+        unsigned wv = 0u;
+        auto warm_next = [&]() {
+            asm volatile("" :: "v"(wv) : "memory");          // retire the previous one before reusing its register
+            if (warm_at < warm_lines + warm_lines_p) {
+                const char *p = warm_at < warm_lines ? reinterpret_cast<const char *>(a.warm_head) + (size_t)warm_at * 128
+                                                     : reinterpret_cast<const char *>(a.warm_ell) + (size_t)(warm_at - warm_lines) * 128;
+                wv = *reinterpret_cast<const unsigned *>(p);
+                warm_at += warm_step;
+            }
+        };
+        auto fill_step = [&](int l, int &u) {
+            if (u < Tn && l > send[u - 3]) {        // slot u mod 3 is free: sweep u-3 has ended
+                const int w0 = send[u - 3], wlen = send[u - 2] - w0;          // levels (w0, w0 + wlen] are ours
+                const int per = (nj + wlen - 1) / wlen, step = l - w0 - 1;
+                T *dst = reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(ur) + (size_t)(u % 3) * a.lds_u_stride);
+                for (int j = step * per; j < min(nj, (step + 1) * per); ++j) {
+                    const int b = hid + j * hcnt;
+                    if (b < nblk) {
+                        const u32x4 r = philox4x32_10((uint32_t)b, a.sweep0 + (uint32_t)u, gc, NLMC_TAG_UNIFORM, a.seed_lo, a.seed_hi);
+                        float4 v;
+                        v.x = (float)(r.x >> 8) * 5.9604644775390625e-08f;
+                        v.y = (float)(r.y >> 8) * 5.9604644775390625e-08f;
+                        v.z = (float)(r.z >> 8) * 5.9604644775390625e-08f;
+                        v.w = (float)(r.w >> 8) * 5.9604644775390625e-08f;
+                        reinterpret_cast<float4 *>(dst)[b] = v;
+                    }
+                }
+                if (l == send[u - 2]) ++u;          // complete before the first item of sweep u (k_levelize_fused floor)
+            }
+        };
+        int u = 3;                                  // next sweep whose table has to be produced
+        for (int l = 0; l < nl; ++l) {
+            warm_next();
+            fill_step(l, u);
+            __syncthreads();
+        }
+        while (warm_at < warm_lines + warm_lines_p) warm_next();     // few chains: the rest of this chain's share
+        asm volatile("" :: "v"(wv) : "memory");
+    }
     chain_store(a, x);
 }
 

@@ -50,7 +50,12 @@ class ShardedTempering:
     def plan(self, n_sweeps, n_rounds=0):
         """Build the level schedules of the next n_sweeps sweeps and the pair selections of the next n_rounds swap
         rounds ahead of time (both depend on the RNG only)."""
-        self.eng.plan_philox(self.sweeps_done, n_sweeps, self.seed, precision=self.precision)
+        planned = 0
+        if n_rounds > 0 and n_sweeps % n_rounds == 0 and self.precision == "f32" and hasattr(self.eng, "plan_philox_fused"):
+            # rounds of equal length: one fused level list per round (bit-identical results, fewer and fuller levels)
+            planned = self.eng.plan_philox_fused(self.sweeps_done, n_rounds, n_sweeps // n_rounds, self.seed)
+        if planned < max(1, n_rounds):
+            self.eng.plan_philox(self.sweeps_done, n_sweeps, self.seed, precision=self.precision)
         if n_rounds > 0 and self.n_pairs > 0 and hasattr(self.eng, "pt_plan"):
             self.eng.pt_plan(self.rounds_done, n_rounds, self.seed, self.n_pairs)
 

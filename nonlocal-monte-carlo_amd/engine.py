@@ -199,6 +199,14 @@ class Engine:
         prec = {"f32": _abi.F32, "f64": _abi.F64}[precision]
         self._ck(self._L.nlmc_plan_philox(self._ctx, prec, _abi.ORDER_SHARED, int(sweep0), int(n_sweeps), int(seed)))
 
+    def plan_philox_fused(self, sweep0, n_windows, window, seed):
+        """Fused-window schedules for `n_windows` launches of exactly `window` sweeps (include/nlmc.h).  Returns the
+        number of windows planned (0: the instance does not qualify; calls then take the sweep-by-sweep path)."""
+        k = ctypes.c_int32(0)
+        self._ck(self._L.nlmc_plan_philox_fused(self._ctx, int(sweep0) & 0xFFFFFFFF, int(n_windows), int(window), int(seed),
+                                                ctypes.byref(k)))
+        return int(k.value)
+
     # -- replica exchange -------------------------------------------------------------------------------
     def pt_init(self, beta_list):
         b = _abi.as_c(beta_list, np.float64).reshape(-1)
