@@ -19,7 +19,7 @@ import numpy as np
 
 from . import hostlogic
 from .base import SweepMixin
-from .engine import Engine
+from .engine import Engine, RoundPlanner
 
 
 class APT_ICM(SweepMixin):
@@ -201,8 +201,7 @@ class APT_ICM(SweepMixin):
         try:
             eng.set_spins(np.sign(2 * host_rng.random((G, N)) - 1).astype(np.int8))
             eng.pt_init(beta_list)
-            if rounds * S > 0:
-                eng.plan_philox(self._sweep_counter, rounds * S, self.seed)
+            planner = RoundPlanner(eng, self._sweep_counter, rounds, S, self.seed)
             if self.num_swapping_pairs > 0 and rounds > 0:
                 eng.pt_plan(0, rounds, self.seed, self.num_swapping_pairs)
             last, slots_last = None, np.arange(G, dtype=np.int32) % R
@@ -211,8 +210,7 @@ class APT_ICM(SweepMixin):
                 is_last = ii == rounds - 1
                 if is_last:
                     slots_last = eng.pt_slots()
-                o = eng.sweep_philox(S, self.seed, sweep0=self._sweep_counter + ii * S, beta=None,
-                                     record_stride=1 if is_last else 0)
+                o = planner.sweep(ii, record_stride=1 if is_last else 0)
                 if is_last:
                     last = o["spins"]
                 # Houdayer: for every temperature slot pair up the K sub-replicas that currently hold it

@@ -10,6 +10,8 @@ of ranks.
 """
 import numpy as np
 
+from .engine import RoundPlanner
+
 
 def block_partition(n_global, world, rank):
     """Contiguous block of chains owned by `rank` (first `n_global % world` ranks get one extra)."""
@@ -50,18 +52,25 @@ class ShardedTempering:
     def plan(self, n_sweeps, n_rounds=0):
         """Build the level schedules of the next n_sweeps sweeps and the pair selections of the next n_rounds swap
         rounds ahead of time (both depend on the RNG only)."""
-        planned = 0
-        if n_rounds > 0 and n_sweeps % n_rounds == 0 and self.precision == "f32" and hasattr(self.eng, "plan_philox_fused"):
-            # rounds of equal length: one fused level list per round (bit-identical results, fewer and fuller levels)
-            planned = self.eng.plan_philox_fused(self.sweeps_done, n_rounds, n_sweeps // n_rounds, self.seed)
-        if planned < max(1, n_rounds):
+        self._planner = None
+        if n_rounds > 0 and n_sweeps % n_rounds == 0 and hasattr(self.eng, "plan_philox_fused"):
+            # rounds of equal length: fused-window level lists where the instance qualifies (same bits, fuller levels)
+            self._planner = RoundPlanner(self.eng, self.sweeps_done, n_rounds, n_sweeps // n_rounds, self.seed,
+                                         precision=self.precision, budget_bytes=4 << 30)
+            self._planner_round0 = self.rounds_done
+            self._planner._plan(0, True)
+        else:
             self.eng.plan_philox(self.sweeps_done, n_sweeps, self.seed, precision=self.precision)
         if n_rounds > 0 and self.n_pairs > 0 and hasattr(self.eng, "pt_plan"):
             self.eng.pt_plan(self.rounds_done, n_rounds, self.seed, self.n_pairs)
 
     def round(self, n_sweeps, want_log=False):
         """`n_sweeps` sweeps of every local chain at its ladder temperature, then one swap attempt round."""
-        self.eng.sweep_philox(n_sweeps, self.seed, sweep0=self.sweeps_done, beta=None, precision=self.precision)
+        pl = getattr(self, "_planner", None)
+        if pl is not None and n_sweeps == pl.S and 0 <= self.rounds_done - self._planner_round0 < pl.R:
+            pl.sweep(self.rounds_done - self._planner_round0)
+        else:
+            self.eng.sweep_philox(n_sweeps, self.seed, sweep0=self.sweeps_done, beta=None, precision=self.precision)
         self.sweeps_done += n_sweeps
         log = None
         if self.n_pairs > 0:

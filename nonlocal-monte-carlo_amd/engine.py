@@ -301,3 +301,60 @@ class Engine:
 
 def device_count():
     return int(_abi.lib().nlmc_device_count())
+
+
+def fused_window(n_sweeps, lo=3, hi=64):
+    """Largest divisor of n_sweeps in [lo, hi] (the launch length of the fused-window schedule), or 0."""
+    for t in range(min(hi, n_sweeps), lo - 1, -1):
+        if n_sweeps % t == 0:
+            return t
+    return 0
+
+
+class RoundPlanner:
+    """Level schedules planned ahead for `n_rounds` rounds of `sweeps_per_round` sweeps each (they depend on the RNG
+    only), a bounded number of rounds at a time.  Rounds whose sweeps need no per-sweep output run on the fused-window
+    schedule when the instance qualifies (one or more launches of `window` sweeps), everything else on the
+    sweep-by-sweep schedule; the results are the same bits either way."""
+
+    BYTES_PER_UPDATE = 140              # packed schedule: head 8 + row window 128 + scratch
+
+    def __init__(self, eng, sweep0, n_rounds, sweeps_per_round, seed, precision="f32", budget_bytes=1 << 30):
+        self.eng, self.sweep0, self.R, self.S, self.seed, self.precision = eng, int(sweep0), int(n_rounds), int(sweeps_per_round), int(seed), precision
+        self.window = fused_window(self.S) if precision == "f32" else 0
+        per_round = max(1, self.S * eng.n * self.BYTES_PER_UPDATE)
+        self.chunk = max(1, min(self.R, int(budget_bytes // per_round)))
+        self._fused_from = self._fused_to = self._plain_from = self._plain_to = 0      # planned round ranges
+
+    def _plan(self, ii, want_fused):
+        r0, r1 = ii, min(self.R, ii + self.chunk)
+        if want_fused and self.window:
+            k = self.eng.plan_philox_fused(self.sweep0 + r0 * self.S, (r1 - r0) * (self.S // self.window), self.window, self.seed)
+            if k == (r1 - r0) * (self.S // self.window):
+                self._fused_from, self._fused_to = r0, r1
+                return True
+            self.window = 0              # the instance does not qualify: stop asking
+        if not want_fused or not self.window:
+            self.eng.plan_philox(self.sweep0 + r0 * self.S, (r1 - r0) * self.S, self.seed, precision=self.precision)
+            self._plain_from, self._plain_to = r0, r1
+        return False
+
+    def sweep(self, ii, **outputs):
+        """The sweeps of round ii at the PT ladder temperatures.  `outputs`: record_stride / want_* of sweep_philox."""
+        needs_plain = any(outputs.get(k) for k in ("record_stride", "want_energy", "want_min", "want_state"))
+        if self.S == 0:
+            return self.eng.sweep_philox(0, self.seed, sweep0=self.sweep0, beta=None, precision=self.precision, **outputs)
+        if not needs_plain and self.window:
+            if not (self._fused_from <= ii < self._fused_to):
+                self._plan(ii, True)
+            if self._fused_from <= ii < self._fused_to:
+                o = None
+                for j in range(self.S // self.window):
+                    o = self.eng.sweep_philox(self.window, self.seed, sweep0=self.sweep0 + ii * self.S + j * self.window,
+                                              beta=None, precision=self.precision)
+                return o
+        if not (self._plain_from <= ii < self._plain_to) and not needs_plain:
+            self._plan(ii, False)
+        # (a round with outputs outside the planned range builds its schedule inside the call)
+        return self.eng.sweep_philox(self.S, self.seed, sweep0=self.sweep0 + ii * self.S, beta=None, precision=self.precision,
+                                     **outputs)

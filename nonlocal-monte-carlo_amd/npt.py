@@ -19,7 +19,7 @@ import numpy as np
 
 from . import hostlogic
 from .base import Common
-from .engine import Engine
+from .engine import Engine, RoundPlanner
 
 
 class NPT(Common):
@@ -256,8 +256,7 @@ class NPT(Common):
             m0 = np.sign(2 * np.random.default_rng(self.seed).random((G, N)) - 1).astype(np.int8)
             eng.set_spins(m0)
             eng.pt_init(beta_list)
-            if rounds * S > 0:
-                eng.plan_philox(self._sweep_counter, rounds * S, self.seed)
+            planner = RoundPlanner(eng, self._sweep_counter, rounds, S, self.seed)
             if self.num_swapping_pairs > 0:
                 eng.pt_plan(0, rounds, self.seed, self.num_swapping_pairs)
             pairs_log, acc_log = [], []
@@ -267,8 +266,7 @@ class NPT(Common):
                 is_last = ii == rounds - 1
                 if is_last:
                     slots_last = eng.pt_slots()
-                o = eng.sweep_philox(S, self.seed, sweep0=self._sweep_counter + ii * S, beta=None,
-                                     record_stride=1 if is_last else 0)
+                o = planner.sweep(ii, record_stride=1 if is_last else 0)
                 if is_last:
                     last = o["spins"]
                 if self.num_swapping_pairs > 0:

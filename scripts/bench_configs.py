@@ -78,10 +78,10 @@ def c5():
     G = R * K
     eng = P.Engine(J, h, G)
     eng.set_spins(init_spins(G, N)); eng.pt_init(np.geomspace(0.05, 4.0, R))
-    eng.plan_philox(0, S * (rounds + 1), 5); eng.pt_plan(0, rounds + 1, 5, 10)
+    planner = P.engine.RoundPlanner(eng, 0, rounds + 1, S, 5); planner._plan(0, True); eng.pt_plan(0, rounds + 1, 5, 10)
     rng = np.random.default_rng(0)
     def one(r):
-        eng.sweep_philox(S, 5, sweep0=r * S, beta=None)
+        planner.sweep(r)
         slots = eng.pt_slots()
         holder = np.empty((K, R), dtype=np.int64)
         for j in range(K):

@@ -1,0 +1,122 @@
+"""Fused-window schedule (include/nlmc.h: nlmc_plan_philox_fused; k_levelize_fused / k_sweep_fused).
+
+It is a re-ordering of independent updates only, so the bar is bit-equality: with the sequential oracle (spins and
+tracked fixed-point energies) and with the sweep-by-sweep kernel on the same seeds -- plain ladder, NMC phase flags,
+an instance with a diagonal, rows longer than the 16-entry packed window, swaps between windows, sharded contexts."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+from helpers import make_instance, init_spins
+
+pytestmark = pytest.mark.gpu
+SEED = 0xA5A50000
+
+
+def run_windows(product, inst, R, T, W, betas, fused, flags=None, temp_x=1.0, swaps=0, m0=None, base=0, G=None):
+    with product.Engine(inst, None, R, chain_base=base, n_chains_global=G) as eng:
+        eng.set_spins(init_spins(R, inst.n, base=1000 + base) if m0 is None else m0)
+        eng.pt_init(betas)
+        if flags is not None:
+            eng.set_flags(flags, temp_x)
+        planned = eng.plan_philox_fused(0, W, T, SEED) if fused else 0
+        if swaps:
+            eng.pt_plan(0, W, SEED, swaps)
+        lv = []
+        for w in range(W):
+            eng.sweep_philox(T, SEED, sweep0=w * T, beta=None)
+            st = eng.last_schedule_stats()
+            lv.append(st["levels"] / max(1, st["orders"]))
+            if swaps:
+                eng.pt_swap_philox(w, SEED, swaps, want_log=False)
+        return eng.get_spins(), eng.energy(), eng.pt_slots(), planned, lv, eng.energy_scale
+
+
+def test_fused_equals_oracle_and_plain(product):
+    N, R, T, W = 8000, 6, 5, 3
+    J, h = make_instance(N, seed=31)
+    inst = product.Instance(J, h)
+    betas = np.geomspace(0.1, 3.0, R)
+    m0 = init_spins(R, N)
+    sf, ef, _, planned, lvf, esc = run_windows(product, inst, R, T, W, betas, True, m0=m0)
+    sp_, ep, _, _, lvp, _ = run_windows(product, inst, R, T, W, betas, False, m0=m0)
+    assert planned == W
+    assert max(lvf) < min(lvp)                         # the fused path really ran (fewer levels per sweep)
+    assert np.array_equal(sf, sp_) and np.array_equal(ef, ep)
+    csr = oracle.Csr(J)
+    for c in (0, R - 1):
+        cb = np.tile(np.array(oracle.cb_pair(betas[c])), (T * W, 1))
+        e0 = int(np.rint(oracle.energy(csr, h, m0[c]) * 2.0 ** esc))
+        _, s_fin, tr = oracle.sweeps_philox(csr, h, m0[c], cb, SEED, c, escale=esc, efix0=e0, want_M=False)
+        assert np.array_equal(sf[c], s_fin)
+        assert ef[c] == tr[-1] * 2.0 ** -esc
+
+
+def test_fused_with_phase_flags_diagonal_and_long_rows(product):
+    """Gaussian couplings (the fp64 energy fallback and non-trivial float sums), a non-zero diagonal (DIAG kernel),
+    one hub row with 40 neighbours (CSR tail beyond the packed window), cluster / frozen flags with temp_x."""
+    N, R, T, W = 9000, 4, 4, 2
+    rng = np.random.default_rng(5)
+    Jb, h = make_instance(N, seed=8)
+    A = sp.lil_matrix(sp.csr_matrix(Jb).multiply(1.0))
+    hub = 17
+    for j in rng.choice(np.arange(100, N), 40, replace=False):
+        A[hub, j] = A[j, hub] = rng.normal()
+    A = sp.csr_matrix(A)
+    A.data = A.data * rng.normal(1.0, 0.3, A.nnz)
+    A = ((A + A.T) * 0.5).tocsr()
+    A.setdiag(rng.normal(0, 0.2, N))
+    A = A.tocsr()
+    hv = rng.normal(0, 0.1, N)
+    inst = product.Instance(A, hv)
+    betas = np.geomspace(0.3, 2.0, R)
+    flags = np.zeros((R, N), np.uint8)
+    flags[:, :N // 10] = 1                              # scaled rows
+    flags[1, N // 2:] = 2
+    flags[2, N // 2:] = 3                              # frozen +-
+    a = run_windows(product, inst, R, T, W, betas, True, flags=flags, temp_x=20.0)
+    b = run_windows(product, inst, R, T, W, betas, False, flags=flags, temp_x=20.0)
+    assert a[3] == W and max(a[4]) < min(b[4])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_fused_with_swaps_and_sharded_contexts(product):
+    """Replica exchange between windows; two half-size contexts with global chain ids give the same bits (weak-scaling
+    invariant of bench.py), fused and plain."""
+    N, G, T, W = 8192, 8, 6, 3
+    J, h = make_instance(N, seed=12)
+    inst = product.Instance(J, h)
+    betas = np.geomspace(0.05, 4.0, G)
+    m0 = init_spins(G, N)
+    full_f = run_windows(product, inst, G, T, W, betas, True, swaps=2, m0=m0)
+    full_p = run_windows(product, inst, G, T, W, betas, False, swaps=2, m0=m0)
+    assert full_f[3] == W
+    assert np.array_equal(full_f[0], full_p[0]) and np.array_equal(full_f[1], full_p[1]) and np.array_equal(full_f[2], full_p[2])
+    # sharded, no swaps in between (a swap needs the all-gather): first window only
+    one_f = run_windows(product, inst, G, T, 1, betas, True, m0=m0)
+    lo = run_windows(product, inst, G // 2, T, 1, betas, True, m0=m0[:G // 2], base=0, G=G)
+    hi = run_windows(product, inst, G // 2, T, 1, betas, True, m0=m0[G // 2:], base=G // 2, G=G)
+    assert np.array_equal(one_f[0], np.concatenate([lo[0], hi[0]]))
+
+
+def test_fused_plan_declines_what_it_cannot_run(product):
+    """Small instance (workgroup smaller than 1024 threads), window of 2: nothing planned, calls take the plain path;
+    calls with per-sweep outputs ignore a fused plan."""
+    J, h = make_instance(1000, seed=3)
+    with product.Engine(J, h, 2) as eng:
+        assert eng.plan_philox_fused(0, 4, 10, SEED) == 0
+    N, T = 8000, 5
+    J, h = make_instance(N, seed=31)
+    with product.Engine(J, h, 2) as eng:
+        assert eng.plan_philox_fused(0, 2, 2, SEED) == 0
+        assert eng.plan_philox_fused(0, 2, T, SEED) == 2
+        eng.set_spins(init_spins(2, N))
+        o = eng.sweep_philox(T, SEED, sweep0=0, beta=1.0, want_energy=True, want_min=True)     # per-sweep outputs
+        st = eng.last_schedule_stats()
+        assert o["energy"].shape == (2, T) and st["orders"] == T and st["levels"] / T > 15
+        e_plain = eng.energy()
+        eng.set_spins(init_spins(2, N))
+        eng.sweep_philox(T, SEED, sweep0=0, beta=1.0)                                           # fused
+        assert eng.last_schedule_stats()["levels"] / T < st["levels"] / T
+        assert np.array_equal(eng.energy(), e_plain)
