@@ -11,7 +11,7 @@ scaling: per-GPU work is fixed; the only collective is one all-gather of 256 flo
 Inputs (instance, replica states, level schedules) are resident in HBM before the timed region starts.
 
 Prints ONE JSON line (rank 0).  `value` = spin-updates/s of the whole job; `roofline` prices the dominant kernel
-(k_sweep_philox) with HIP events recorded on the stream it runs on; `cpu_baseline` times the oracle (a C port of the
+(k_sweep_fused) with HIP events recorded on the stream it runs on; `cpu_baseline` times the oracle (a C port of the
 same algorithm, one thread) on a bounded sample of the same workload.
 """
 import argparse
@@ -34,10 +34,11 @@ INSTANCE_SEED = 20250225
 PHILOX_SEED = 0xA5A50000
 BYTES_PER_UPDATE = 63        # 9*d + 9 at d = 6 (fp32 J, int32 col, int8 spins)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
-# HBM bytes per k_sweep_philox launch of THIS workload from the PMC passes committed in
-# profiles/r01_d_sweep_hbm_traffic_pmc.csv: (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 read correction applied).
-# It is the touched part of the level schedule fetched once per XCD plus the spin write-back; PMC cannot be read live.
-HBM_TRAFFIC_BYTES_PER_LAUNCH = 79_693_123
+# HBM bytes per k_sweep_fused launch of THIS workload from the PMC passes committed in
+# profiles/r01_e_sweep_hbm_traffic_pmc.csv: (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 read correction applied).
+# It is the touched part of the level schedule fetched once per XCD (plus the warm-up touch of the next window's) and the
+# spin write-back; PMC cannot be read live.
+HBM_TRAFFIC_BYTES_PER_LAUNCH = 85_645_256
 
 
 def cpu_baseline(J, h, seconds=12.0):
@@ -154,12 +155,14 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": HBM_TRAFFIC_BYTES_PER_LAUNCH if (world == 1 and count == REPLICAS_PER_GPU) else None,
-                         "traffic_source": "profiles/r01_d_sweep_hbm_traffic_pmc.csv",
+                         "traffic_source": "profiles/r01_e_sweep_hbm_traffic_pmc.csv",
                          "algorithmic_bytes_per_launch": upd_launch * BYTES_PER_UPDATE,
-                         "kernel": "k_sweep_philox<float,false>", "us_per_launch": ms_launch * 1e3,
+                         "kernel": "k_sweep_fused<false>", "us_per_launch": ms_launch * 1e3,
                          "bytes_per_update": BYTES_PER_UPDATE, "updates_per_launch": upd_launch,
-                         "note": "algorithmic bytes; the working set (spins in LDS, schedule in L2/MALL) never "
-                                 "streams from HBM at this size, see DESIGN.md"},
+                         "note": "algorithmic bytes (SURVEY 8d: 63 B per update, no discount for rows shared by chains); "
+                                 "spins live in LDS and one level schedule serves all 256 chains, so HBM carries ~5 % of "
+                                 "that (traffic) and frac can exceed 1 -- the kernel is bound by VALU issue and per-level "
+                                 "latency, see DESIGN.md section 5"},
             "levels_per_sweep": sched["levels"] / max(1, sched["orders"]),
             "min_energy": {"start": float(e_start.min()), "end": float(e_end.min())},
         }

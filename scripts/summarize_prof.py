@@ -12,7 +12,7 @@ import os
 import sys
 from collections import defaultdict
 
-KERNEL = "k_sweep_philox"
+KERNELS = ("k_sweep_fused", "k_sweep_philox")     # dominant kernel: the first of these that appears in the trace
 
 
 def find(d, suffix):
@@ -23,13 +23,17 @@ def find(d, suffix):
 
 
 def counters(d):
-    acc, n = defaultdict(float), defaultdict(int)
     with open(find(d, "counter_collection.csv")) as f:
-        for row in csv.DictReader(f):
-            if KERNEL in row["Kernel_Name"]:
-                acc[row["Counter_Name"]] += float(row["Counter_Value"])
-                n[row["Counter_Name"]] += 1
-    return {k: (n[k], acc[k] / n[k]) for k in acc}
+        rows = list(csv.DictReader(f))
+    kernel = next(k for k in KERNELS if any(k in r["Kernel_Name"] for r in rows))
+    acc, n = defaultdict(float), defaultdict(int)
+    for row in rows:
+        if kernel in row["Kernel_Name"]:
+            acc[row["Counter_Name"]] += float(row["Counter_Value"])
+            n[row["Counter_Name"]] += 1
+    out = {k: (n[k], acc[k] / n[k]) for k in acc}
+    out["__kernel__"] = kernel
+    return out
 
 
 def main():
@@ -37,12 +41,14 @@ def main():
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
     with open(find(stats_dir, "kernel_stats.csv")) as f, open(os.path.join(out, f"{tag}_bench_n1_kernel_stats.csv"), "w") as g:
         g.write(f.read())
-    fs, ws = counters(fetch_dir)["FETCH_SIZE"], counters(write_dir)["WRITE_SIZE"]
+    fc = counters(fetch_dir)
+    kname = fc["__kernel__"]
+    fs, ws = fc["FETCH_SIZE"], counters(write_dir)["WRITE_SIZE"]
     hbm = int(round((2.0 * fs[1] + ws[1]) * 1024))
     with open(os.path.join(out, f"{tag}_sweep_hbm_traffic_pmc.csv"), "w") as g:
         g.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE  and (separate pass)  --pmc WRITE_SIZE  -- python3 bench.py "
                 "--steps 20 --warmup 3 --no-cpu-baseline\n"
-                "# per launch of k_sweep_philox<float,false> (256 chains x 1e4 spins x 10 sweeps); counter unit = KiB\n"
+                f"# per launch of {kname}<false> (256 chains x 1e4 spins x 10 sweeps); counter unit = KiB\n"
                 "# gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of wide coalesced reads -> "
                 "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024\n"
                 "counter,n_launches,mean_per_launch\n"
@@ -51,11 +57,12 @@ def main():
     if sq_dirs:
         with open(os.path.join(out, f"{tag}_sweep_pmc_summary.csv"), "w") as g:
             g.write("# rocprofv3 --kernel-trace --pmc <counters, one pass per line group> -- python3 bench.py --steps 20 "
-                    "--warmup 3 --no-cpu-baseline\n# k_sweep_philox<float,false>, per launch (256 chains x 1e4 spins x 10 sweeps)\n"
+                    f"--warmup 3 --no-cpu-baseline\n# {kname}<false>, per launch (256 chains x 1e4 spins x 10 sweeps)\n"
                     "counter,mean_per_launch\n")
             for d in sq_dirs:
-                for k, (_, v) in sorted(counters(d).items()):
-                    g.write(f"{k},{v:.6g}\n")
+                for k, val in sorted(counters(d).items()):
+                    if k != "__kernel__":
+                        g.write(f"{k},{val[1]:.6g}\n")
     print("hbm_bytes_per_launch", hbm)
 
 
