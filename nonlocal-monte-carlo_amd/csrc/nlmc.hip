@@ -95,10 +95,14 @@ struct nlmc_ctx {
     int stat_fused_window = -1;          // >= 0: the most recent sweep call ran this fused window
     bool fz_valid = false;
     uint32_t fz_sweep0 = 0;
-    int fz_windows = 0, fz_T = 0;
+    int fz_windows = 0, fz_T = 0, fz_workers = 13;
     uint64_t fz_seed = 0;
     std::vector<int32_t> fz_nlev_host;
     DevBuf<uint16_t> fz_glv;
+    DevBuf<uint32_t> fz_perm;
+    DevBuf<uint16_t> fz_adj;
+    DevBuf<long long> fz_stats;
+    bool fz_adj_ready = false;
     DevBuf<int2> fz_head;
     DevBuf<EdgeF> fz_ell;
     DevBuf<int32_t> fz_loff, fz_nlev, fz_himax, fz_send;
@@ -241,7 +245,12 @@ int run_levelize(nlmc_ctx *c, int n_orders, const uint32_t *keys_in, int per_cha
 }
 
 // ---- fused-window path ------------------------------------------------------------------------------------
-constexpr int FUSED_WORKERS = 13;          // of the 16 waves of a 1024-thread workgroup; 3 waves generate uniforms
+// worker waves of the 16 of a 1024-thread workgroup; the others generate uniforms (NLMC_FUSED_WORKERS: tuning knob)
+int fused_workers()
+{
+    if (const char *s = getenv("NLMC_FUSED_WORKERS")) { const int v = atoi(s); if (v >= 8 && v <= 15) return v; }
+    return 13;
+}
 
 // LDS of k_sweep_fused: spins | flags | 3 uniform tables | level offsets | sweep ends | reduction scratch
 struct FusedLds { int flags_off, u_off, u_bytes, loff_off, send_off, red_off; size_t total; };
@@ -267,7 +276,7 @@ FusedLds fused_lds(int n, int n_pad, bool has_flags, int T)
 bool fused_supported(const nlmc_ctx *c, int T)
 {
     if (getenv("NLMC_NO_FUSED")) return false;
-    if (sweep_block(c->n) != 1024 || c->max_deg > 0x3FFF || T < 3 || T > NLMC_FUSED_TMAX) return false;
+    if (sweep_block(c->n) != 1024 || c->n > NLMC_FZ_SPT * 1024 || c->max_deg > 0x3FFF || T < 3 || T > NLMC_FUSED_TMAX) return false;
     if ((size_t)T * c->n > ((size_t)1 << 22)) return false;            // 32-bit buffer offsets of the packed planes
     return fused_lds(c->n, c->n_pad, true, T).total <= (size_t)150 * 1024;
 }
@@ -300,7 +309,7 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
         a.warm_head = c->fz_head.p + (size_t)(w + 1) * TN;
         a.warm_ell = c->fz_ell.p + (size_t)(w + 1) * TN * NLMC_ELL_W32;
     }
-    a.f_workers = FUSED_WORKERS;
+    a.f_workers = c->fz_workers;
     a.n_sweeps = T;
     a.sweep0 = sweep0;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
@@ -622,13 +631,13 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
     for (int k = 0; k < n; ++k) h32[k] = (float)h[k];
 
     CT(c->rowptr.reserve((size_t)n + 1));
-    // +8 entries of padding: the sweep kernel prefetches fixed-width row windows (never used past the row end)
-    CT(c->col.reserve((size_t)nnz + 8));
-    CT(c->val64.reserve((size_t)nnz + 8));
-    CT(c->edge32.reserve((size_t)nnz + 8));
-    CT(hipMemset(c->col.p, 0, sizeof(int32_t) * ((size_t)nnz + 8)));
-    CT(hipMemset(c->val64.p, 0, sizeof(double) * ((size_t)nnz + 8)));
-    CT(hipMemset(c->edge32.p, 0, sizeof(EdgeF) * ((size_t)nnz + 8)));
+    // +16 entries of padding: fixed-width row windows are read unconditionally (never used past the row end)
+    CT(c->col.reserve((size_t)nnz + 16));
+    CT(c->val64.reserve((size_t)nnz + 16));
+    CT(c->edge32.reserve((size_t)nnz + 16));
+    CT(hipMemset(c->col.p, 0, sizeof(int32_t) * ((size_t)nnz + 16)));
+    CT(hipMemset(c->val64.p, 0, sizeof(double) * ((size_t)nnz + 16)));
+    CT(hipMemset(c->edge32.p, 0, sizeof(EdgeF) * ((size_t)nnz + 16)));
     CT(c->h64.reserve((size_t)n));
     CT(c->h32.reserve((size_t)n));
     CT(hipMemcpy(c->rowptr.p, rowptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
@@ -683,7 +692,7 @@ void nlmc_destroy(nlmc_ctx *c)
     c->spins.release(); c->best.release(); c->flags.release(); c->efix.release(); c->emin.release(); c->etrace.release();
     c->argmin.release(); c->energy.release(); c->tab.release(); c->ustream.release(); c->etrace_d.release();
     c->keys.release(); c->strace.release(); c->cfg.release(); c->scratch.release(); c->plan.release();
-    c->fz_glv.release(); c->fz_head.release(); c->fz_ell.release(); c->fz_loff.release(); c->fz_nlev.release();
+    c->fz_glv.release(); c->fz_perm.release(); c->fz_adj.release(); c->fz_stats.release(); c->fz_head.release(); c->fz_ell.release(); c->fz_loff.release(); c->fz_nlev.release();
     c->fz_himax.release(); c->fz_send.release();
     c->lbp_src.release(); c->lbp_rev.release(); c->lbp_flag.release(); c->lbp_out_i.release(); c->lbp_tJ.release();
     c->lbp_eps.release(); c->lbp_ms.release(); c->lbp_lams.release(); c->lbp_w0.release(); c->lbp_w1.release();
@@ -912,6 +921,13 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     const int n = c->n, T = window;
     const size_t W = (size_t)n_windows, TN = (size_t)T * n;
     HIP_TRY(c, c->fz_glv.reserve(W * TN));
+    HIP_TRY(c, c->fz_perm.reserve(W * TN));
+    if (!c->fz_adj_ready) {
+        HIP_TRY(c, c->fz_adj.reserve((size_t)n * NLMC_FZ_ADJ));
+        hipLaunchKernelGGL(k_fused_adjacency, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->rowptr.p, c->col.p, c->fz_adj.p);
+        HIP_TRY(c, hipGetLastError());
+        c->fz_adj_ready = true;
+    }
     HIP_TRY(c, c->fz_head.reserve(W * TN));
     HIP_TRY(c, c->fz_ell.reserve(W * TN * NLMC_ELL_W32));
     HIP_TRY(c, c->fz_loff.reserve(W * (NLMC_LCAP + 1)));
@@ -922,16 +938,25 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     a.g = c->g;
     a.T = T;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.sweep0 = sweep0;
-    a.level_cap = FUSED_WORKERS * 64;
-    a.glv = c->fz_glv.p; a.head = c->fz_head.p; a.ell = c->fz_ell.p; a.loff = c->fz_loff.p; a.nlev = c->fz_nlev.p;
+    c->fz_workers = fused_workers();
+    a.level_cap = c->fz_workers * 64;
+    a.adj = reinterpret_cast<const uint4 *>(c->fz_adj.p); a.glv = c->fz_glv.p; a.perm = c->fz_perm.p; a.head = c->fz_head.p; a.ell = c->fz_ell.p; a.loff = c->fz_loff.p; a.nlev = c->fz_nlev.p;
     a.hi_max = c->fz_himax.p; a.send = c->fz_send.p;
-    const size_t lds = (size_t)n * 4 + 2 * (size_t)((n + 1) & ~1) * 2 + 2 * (size_t)(NLMC_LCAP + 2) * 4 + 16;
+    const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
+    const size_t lds = (size_t)n * 8 + n4 * 2 + n4 + n4 * 2 + 2 * (size_t)(NLMC_LCAP + 2) * 4 + 16;
     { int rc = ensure_lds(c, 10, reinterpret_cast<const void *>(k_levelize_fused), lds); if (rc) return rc; }
+    const bool fz_diag = getenv("NLMC_FZ_STATS") != nullptr;     // diagnostic: phase cycle counts of window 0 on stderr
+    if (fz_diag) { HIP_TRY(c, c->fz_stats.reserve(W * 8)); a.stats = c->fz_stats.p; }
     hipLaunchKernelGGL(k_levelize_fused, dim3(n_windows), dim3(1024), lds, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     c->fz_nlev_host.assign(W, 0);
     HIP_TRY(c, hipMemcpyAsync(c->fz_nlev_host.data(), c->fz_nlev.p, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (fz_diag) {
+        long long st[8] = {0};
+        HIP_TRY(c, hipMemcpy(st, c->fz_stats.p, sizeof(st), hipMemcpyDeviceToHost));
+        fprintf(stderr, "k_levelize_fused window 0 (cycles): keys %lld, init %lld, passes %lld (%lld passes), place-1 %lld, place-2 %lld\n", st[0], st[1], st[2], st[3], st[4], st[5]);
+    }
     int ok = 0;
     for (int32_t v : c->fz_nlev_host) ok += v > 0;
     c->fz_valid = true;

@@ -209,7 +209,10 @@ struct FusedLevelizeArgs {
     int T;                    // sweeps per window
     uint32_t seed_lo, seed_hi, sweep0;     // window w covers sweeps sweep0 + w T ... + T - 1 (shared order, group 0)
     int level_cap;            // 64 x worker waves of k_sweep_fused
+    const uint4 *adj;         // [n][2]: the first 16 neighbours of every spin as 16-bit indices (k_fused_adjacency)
     uint16_t *glv;            // scratch [n_windows][T][n]: level of update (t, k), 1-based
+    uint32_t *perm;           // scratch [n_windows][T n]: item id k | t << 16 at its position
+    long long *stats;         // diagnostic (NLMC_FZ_STATS): [n_windows][8] cycles keys / init / passes, pass count, place 1 / 2
     int2 *head;               // [n_windows][T n]   { k | deg << 16 | (t mod 3) << 30, bits of (float)h_k }
     EdgeF *ell;               // [n_windows][8][T n][2]   row window planes, position-minor
     int32_t *loff;            // [n_windows][NLMC_LCAP + 1] published level offsets
@@ -218,68 +221,144 @@ struct FusedLevelizeArgs {
     int32_t *send;            // [n_windows][T] published index of the last level that holds an item of sweep t
 };
 
+// 16-bit neighbour lists, 32 B per spin (absent slots hold the spin's own index, which every consumer skips): one
+// pair of 16-byte loads instead of a chain of dependent 4-byte CSR reads per spin in k_levelize_fused.
+#define NLMC_FZ_ADJ 16
+__global__ void k_fused_adjacency(int n, const int32_t *rowptr, const int32_t *col, uint16_t *adj)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int rs = rowptr[k], deg = rowptr[k + 1] - rs;
+    for (int q = 0; q < NLMC_FZ_ADJ; ++q) adj[(size_t)k * NLMC_FZ_ADJ + q] = (uint16_t)(q < deg ? col[rs + q] : k);
+}
+
 // Level of update (t, k) = 1 + max over: its own update of sweep t-1; every neighbour's update of sweep t that comes
 // earlier in the order of sweep t; every other neighbour's update of sweep t-1 (its value is read, and it must not be
 // overwritten before the neighbours of sweep t-1 that read the old one are done -- they precede by the same rule);
 // and the end of sweep t-2 (at most two sweeps live per level: three uniform tables suffice).
-// LDS: key u32[n] | gA u16[n] | gB u16[n] | hist u32[LCAP + 2] | histL u32[LCAP + 2]
-__global__ void k_levelize_fused(FusedLevelizeArgs a)
+// Per sweep: (1) every spin gets base = the part of the maximum known up front and cnt = number of neighbours that
+// precede it; (2) topological passes: a spin with cnt == 0 is final at level m + 1 and pushes that level to its later
+// neighbours (LDS atomicMax on m, then decrement of their cnt) -- every edge is handled once per sweep, a pass costs a
+// look at the thread's own <= NLMC_FZ_SPT counters plus the pushes of the spins that became final.
+// LDS: key u32[n] | m u32[n] | g u16[n] | cnt u8[n] | queue u16[n] | hist u32[LCAP + 2] | histL u32[LCAP + 2]
+#define NLMC_FZ_SPT 11         // spins per thread: n <= 11 * 1024
+__global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int n = a.g.n, T = a.T, w = blockIdx.x;
+    const int n4 = (n + 3) & ~3;
     uint32_t *key = reinterpret_cast<uint32_t *>(lds_raw);
-    uint16_t *gA = reinterpret_cast<uint16_t *>(lds_raw + (size_t)n * 4);
-    uint16_t *gB = gA + ((n + 1) & ~1);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(gB + ((n + 1) & ~1));
+    uint32_t *mx = key + n;
+    uint16_t *g = reinterpret_cast<uint16_t *>(mx + n);
+    uint8_t *cnt8 = reinterpret_cast<uint8_t *>(g + n4);
+    uint32_t *cnt32 = reinterpret_cast<uint32_t *>(cnt8);
+    uint16_t *queue = reinterpret_cast<uint16_t *>(cnt8 + n4);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(queue + n4);
     uint32_t *histL = hist + NLMC_LCAP + 2;
     __shared__ int sh_lmax[NLMC_FUSED_TMAX];
-    __shared__ int sh_max, sh_fail, sh_himax, sh_nlev;
+    __shared__ int sh_max, sh_fail, sh_himax, sh_nlev, sh_qn;
     const int tid = threadIdx.x, nt = blockDim.x;
-    uint16_t *gprev = gA, *gcur = gB;
-    for (int k = tid; k < n; k += nt) gprev[k] = 0;
+    for (int k = tid; k < n; k += nt) g[k] = 0;
     for (int l = tid; l < 2 * (NLMC_LCAP + 2); l += nt) hist[l] = 0u;      // hist and histL are adjacent
-    if (tid == 0) { sh_fail = 0; sh_himax = 0; }
+    if (tid == 0) { sh_fail = 0; sh_himax = 0; sh_qn = 0; }
     __syncthreads();
     uint16_t *glv = a.glv + (size_t)w * T * n;
 
+    long long st[6] = {0, 0, 0, 0, 0, 0};
     for (int t = 0; t < T; ++t) {
         const uint32_t tt = a.sweep0 + (uint32_t)(w * T + t);
-        for (int k = tid; k < n; k += nt) {
-            key[k] = philox4x32_10((uint32_t)k, tt, 0u, NLMC_TAG_ORDER, a.seed_lo, a.seed_hi).x;
-            gcur[k] = 0;
-        }
+        long long c0 = (long long)__builtin_readcyclecounter();
+        for (int k = tid; k < n; k += nt) key[k] = philox4x32_10((uint32_t)k, tt, 0u, NLMC_TAG_ORDER, a.seed_lo, a.seed_hi).x;
         if (tid == 0) sh_max = 0;
         __syncthreads();
+        long long c1 = (long long)__builtin_readcyclecounter();
+        st[0] += c1 - c0;
         const int floor_lv = t >= 2 ? sh_lmax[t - 2] : 0;
-        for (int it = 0; it <= n; ++it) {          // chaotic relaxation to the least fixed point (values only grow)
-            int changed = 0;
-            for (int k = tid; k < n; k += nt) {
+        for (int i = 0; i < NLMC_FZ_SPT; ++i) {        // this thread's spins: k = tid + i nt
+            const int k = tid + i * nt;
+            if (k < n) {
+                const int re = a.g.rowptr[k + 1], rs = a.g.rowptr[k];
                 const uint32_t kk = key[k];
-                int m = max((int)gprev[k], floor_lv);
-                for (int e = a.g.rowptr[k]; e < a.g.rowptr[k + 1]; ++e) {
-                    const int j = a.g.col[e];
-                    if (j != k) m = max(m, precedes(key[j], j, kk, k) ? (int)gcur[j] : (int)gprev[j]);
+                int base = max((int)g[k], floor_lv), c = 0;
+                const uint4 a0 = a.adj[2 * k], a1 = a.adj[2 * k + 1];
+                const uint32_t aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int q = 0; q < NLMC_FZ_ADJ; ++q) {
+                    const int j = (int)((aw[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu);
+                    if (j != k) { if (precedes(key[j], j, kk, k)) ++c; else base = max(base, (int)g[j]); }
                 }
-                m = min(m + 1, 65535);
-                if (m != (int)gcur[k]) { gcur[k] = (uint16_t)m; changed = 1; }
+                for (int e = rs + NLMC_FZ_ADJ; e < re; ++e) {      // rows longer than 16 entries
+                    const int j = a.g.col[e];
+                    if (j != k) { if (precedes(key[j], j, kk, k)) ++c; else base = max(base, (int)g[j]); }
+                }
+                mx[k] = (uint32_t)base;
+                cnt8[k] = (uint8_t)min(c, 255);
+                if (c > 255) sh_fail = 1;          // more than 255 preceding neighbours: no fused schedule
             }
-            if (!__syncthreads_or(changed)) break;
         }
+        __syncthreads();                           // every old level has been read: g is rewritten below
+        c0 = (long long)__builtin_readcyclecounter();
+        st[1] += c0 - c1;
+        unsigned todo = 0u;
+        for (int i = 0; i < NLMC_FZ_SPT; ++i) if (tid + i * nt < n) todo |= 1u << i;
         int lmax = 0;
-        for (int k = tid; k < n; k += nt) {
-            const int lv = (int)gcur[k];
-            lmax = max(lmax, lv);
-            glv[(size_t)t * n + k] = (uint16_t)lv;
-            if (lv <= NLMC_LCAP) {
-                atomicAdd(&hist[lv], 1u);
-                if (a.g.rowptr[k + 1] - a.g.rowptr[k] > 8) atomicAdd(&histL[lv], 1u);
+        // Topological passes with a compacted work queue: (a) every thread looks at its own counters and queues the
+        // spins that became ready; (b) the queue is processed one spin per lane (a wave that handled "its own" spins
+        // would run the body for every i in which ANY of its 64 lanes has a ready spin: 7 % lane efficiency).
+        for (int pass = 0; pass <= n; ++pass) {
+            for (int i = 0; i < NLMC_FZ_SPT; ++i) {
+                const int k = tid + i * nt;
+                if ((todo & (1u << i)) && cnt8[k] == 0) {       // (a wave-aggregated reservation measured slower)
+                    todo &= ~(1u << i);
+                    queue[atomicAdd(&sh_qn, 1)] = (uint16_t)k;
+                }
             }
+            __syncthreads();
+            const int qn = sh_qn;
+            if (qn == 0) break;                    // nothing ready: all done (a DAG always has a ready node otherwise)
+            for (int idx = tid; idx < qn; idx += nt) {
+                const int k = (int)queue[idx];
+                const int re = a.g.rowptr[k + 1], rs = a.g.rowptr[k];
+                const uint4 a0 = a.adj[2 * k], a1 = a.adj[2 * k + 1];
+                const int lv = min((int)mx[k] + 1, 65535);
+                g[k] = (uint16_t)lv;
+                glv[(size_t)t * n + k] = (uint16_t)lv;
+                lmax = max(lmax, lv);
+                if (lv <= NLMC_LCAP) {
+                    atomicAdd(&hist[lv], 1u);
+                    if (re - rs > 8) atomicAdd(&histL[lv], 1u);
+                }
+                const uint32_t kk = key[k];
+                const uint32_t aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                uint32_t kj[NLMC_FZ_ADJ];
+#pragma unroll
+                for (int q = 0; q < NLMC_FZ_ADJ; ++q) kj[q] = key[(aw[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu];   // one batch
+#pragma unroll
+                for (int q = 0; q < NLMC_FZ_ADJ; ++q) {
+                    const int j = (int)((aw[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu);
+                    if (j != k && precedes(kk, k, kj[q], j)) {                // k comes before j: j waits for k
+                        atomicMax(&mx[j], (uint32_t)lv);
+                        atomicSub(&cnt32[j >> 2], 1u << ((j & 3) * 8));       // after the max (one wave's LDS ops are in order)
+                    }
+                }
+                for (int e = rs + NLMC_FZ_ADJ; e < re; ++e) {
+                    const int j = a.g.col[e];
+                    if (j != k && precedes(kk, k, key[j], j)) {
+                        atomicMax(&mx[j], (uint32_t)lv);
+                        atomicSub(&cnt32[j >> 2], 1u << ((j & 3) * 8));
+                    }
+                }
+            }
+            st[3] += 1;
+            __syncthreads();
+            if (tid == 0) sh_qn = 0;
+            __syncthreads();
         }
+        st[2] += (long long)__builtin_readcyclecounter() - c0;
         atomicMax(&sh_max, lmax);
         __syncthreads();
         if (tid == 0) { sh_lmax[t] = sh_max; if (sh_max > NLMC_LCAP) sh_fail = 1; }
         __syncthreads();
-        uint16_t *tmp = gprev; gprev = gcur; gcur = tmp;
     }
 
     // publish offsets: levels 1..L in order, each split into chunks of level_cap; hist[lv] becomes the level's start
@@ -309,23 +388,44 @@ __global__ void k_levelize_fused(FusedLevelizeArgs a)
     // placement: rows longer than 8 entries from the front of their level, the others from the back
     for (int l = tid; l <= NLMC_LCAP; l += nt) histL[l] = hist[l + 1];     // back cursor of level l = start of level l+1
     __syncthreads();
+    // Two steps so that the 136 B per update are written with coalesced stores: (1) scatter the 4-byte item ids to
+    // their positions, (2) position-major: lane p gathers row k(p) (CSR is cache resident) and writes head[p] and the
+    // planes [q][p] next to its neighbours' -- a direct scatter of 16-byte pieces ran at a tenth of the bandwidth.
     const size_t TN = (size_t)T * n;
-    int2 *head = a.head + (size_t)w * TN;
-    int4 *ell = reinterpret_cast<int4 *>(a.ell) + (size_t)w * (NLMC_ELL_W32 / 2) * TN;
+    long long p0 = (long long)__builtin_readcyclecounter();
+    uint32_t *perm = a.perm + (size_t)w * TN;
     for (int t = 0; t < T; ++t) {
         for (int k = tid; k < n; k += nt) {
             const int lv = (int)glv[(size_t)t * n + k];
-            const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
+            const int deg = a.g.rowptr[k + 1] - a.g.rowptr[k];
             const uint32_t pos = deg > 8 ? atomicAdd(&hist[lv], 1u) : atomicSub(&histL[lv], 1u) - 1u;
-            head[pos] = make_int2(k | (deg << 16) | ((t % 3) << 30), __float_as_int(a.g.h32[k]));
-#pragma unroll
-            for (int q = 0; q < NLMC_ELL_W32; q += 2) {
-                EdgeF e0{0, 0.0f}, e1{0, 0.0f};
-                if (q < deg) e0 = a.g.edge32[rs + q];
-                if (q + 1 < deg) e1 = a.g.edge32[rs + q + 1];
-                ell[(size_t)(q / 2) * TN + pos] = make_int4(e0.col, __float_as_int(e0.val), e1.col, __float_as_int(e1.val));
-            }
+            perm[pos] = (uint32_t)k | ((uint32_t)t << 16);
         }
+    }
+    __threadfence_block();
+    __syncthreads();
+    long long p1 = (long long)__builtin_readcyclecounter();
+    st[4] = p1 - p0;
+    int2 *head = a.head + (size_t)w * TN;
+    int4 *ell = reinterpret_cast<int4 *>(a.ell) + (size_t)w * (NLMC_ELL_W32 / 2) * TN;
+    for (size_t pos = tid; pos < TN; pos += nt) {
+        const uint32_t it = perm[pos];
+        const int k = (int)(it & 0xFFFFu), t = (int)(it >> 16);
+        const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
+        head[pos] = make_int2(k | (deg << 16) | ((t % 3) << 30), __float_as_int(a.g.h32[k]));
+        EdgeF ed[NLMC_ELL_W32];
+#pragma unroll
+        for (int q = 0; q < NLMC_ELL_W32; ++q) ed[q] = a.g.edge32[rs + q];     // unconditional (the array is padded by
+#pragma unroll                                                                  // a full window): independent loads
+        for (int q = 0; q < NLMC_ELL_W32; q += 2) {
+            const EdgeF z{0, 0.0f};
+            const EdgeF e0 = q < deg ? ed[q] : z, e1 = q + 1 < deg ? ed[q + 1] : z;
+            ell[(size_t)(q / 2) * TN + pos] = make_int4(e0.col, __float_as_int(e0.val), e1.col, __float_as_int(e1.val));
+        }
+    }
+    if (a.stats && tid == 0) {
+        st[5] = (long long)__builtin_readcyclecounter() - p1;
+        for (int i = 0; i < 6; ++i) a.stats[(size_t)w * 8 + i] = st[i];
     }
 }
 

@@ -16,10 +16,17 @@ for mode in ("plain", "fused"):
         eng.set_spins(init_spins(R, N))
         eng.pt_init(betas)
         if mode == "fused":
+            t0 = time.perf_counter()
             k = eng.plan_philox_fused(0, W, T, 99)
-            print("windows planned:", k, flush=True)
+            print("windows planned:", k, "in", round((time.perf_counter() - t0) * 1e3, 2), "ms", flush=True)
+            t0 = time.perf_counter()
+            eng.plan_philox_fused(0, W, T, 99)
+            print("  second call (buffers allocated):", round((time.perf_counter() - t0) * 1e3, 2), "ms", flush=True)
         else:
+            t0 = time.perf_counter()
             eng.plan_philox(0, W * T, 99)
+            eng.energy()
+            print("plain plan in", round((time.perf_counter() - t0) * 1e3, 2), "ms", flush=True)
         eng.timing_reset(True)
         for w in range(W):
             eng.sweep_philox(T, 99, sweep0=w * T, beta=None)
