@@ -12,7 +12,8 @@ Inputs (instance, replica states, level schedules) are resident in HBM before th
 
 Prints ONE JSON line (rank 0).  `value` = spin-updates/s of the whole job; `roofline` prices the dominant kernel
 (k_sweep_fused) with HIP events recorded on the stream it runs on; `cpu_baseline` times the oracle (a C port of the
-same algorithm, one thread) on a bounded sample of the same workload.
+same algorithm, one thread) on a bounded sample of the same workload; `cpu_baseline_numpy_path` times the
+reference's own NumPy loop structure (restated in oracle/numpy_path.py, pinned to a golden) the same way.
 """
 import argparse
 import json
@@ -60,6 +61,24 @@ def cpu_baseline(J, h, seconds=12.0):
     return {"value": done * csr.n / dt, "unit": "spin-updates/s", "cores": 1, "kind": "port",
             "sample": f"1 chain x {csr.n} spins x {done} sweeps at beta=1 ({dt:.1f} s of oracle/nlo.c:nlo_sweeps_philox)",
             "min_energy_seen": emin}
+
+
+def numpy_path_baseline(J, h, seconds=10.0):
+    """oracle/numpy_path.py (kind "port"): the reference's own per-update work (state tuple + full sparse mat-vec +
+    NumPy call overhead per SPIN update, NMC/nmc.py:70-88) restated, one process; the reference itself cannot travel to
+    this box.  Bounded: whole sweeps until `seconds` are used (one sweep of 10^4 spins costs ~5 s)."""
+    from oracle.numpy_path import mcmc_numpy_path
+    n = J.shape[0]
+    np.random.seed(7)
+    m = np.sign(2 * np.random.rand(n) - 1)
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        m = mcmc_numpy_path(1, m, 1.0, J, h)[:, -1]
+        done += 1
+    dt = time.perf_counter() - t0
+    return {"value": done * n / dt, "unit": "spin-updates/s", "cores": 1, "kind": "port",
+            "sample": f"1 chain x {n} spins x {done} sweeps at beta=1 ({dt:.1f} s of oracle/numpy_path.py: the reference's "
+                      "NumPy loop structure)"}
 
 
 def main():
@@ -168,6 +187,7 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(J, h)
+            out["cpu_baseline_numpy_path"] = numpy_path_baseline(J, h)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -37,6 +37,21 @@ def test_mcmc_fixed_beta(name):
     assert_energy(E, g["energies"])
 
 
+@pytest.mark.parametrize("name", ["mcmc_fixed_pmj100_s0", "mcmc_fixed_chimera128_s1", "mcmc_fixed_gauss16_s12345"])
+def test_numpy_path_baseline_is_the_reference_bit_for_bit(name):
+    """oracle/numpy_path.py (the reference's per-update cost structure, timed by bench.py as the NumPy CPU baseline)
+    reproduces the reference's M under the same np.random seed."""
+    import scipy.sparse as sp
+    from oracle.numpy_path import mcmc_numpy_path
+    g = golden(name)
+    N = int(g["N"])
+    J = sp.csr_matrix((g["data"], g["indices"], g["indptr"]), shape=(N, N)).toarray()
+    np.random.seed(int(g["seed"]))
+    m0 = np.sign(2 * np.random.rand(N) - 1)
+    M = mcmc_numpy_path(int(g["num_sweeps"]), m0, float(g["beta"]), J, g["h"])
+    assert np.array_equal(M.T.astype(np.int8), g["M"])
+
+
 @pytest.mark.parametrize("name", golden_names("mcmc_anneal_"))
 def test_mcmc_anneal(name):
     g = golden(name)
