@@ -145,6 +145,13 @@ int nlmc_icm_get_labels(nlmc_ctx *ctx, int32_t *out /*[n]*/);
 /* Device-decided batch: pairs [n_pairs][2] local chain ids, pick = philox(pair, round, ., ICM) */
 int nlmc_icm_round_philox(nlmc_ctx *ctx, const int32_t *pairs, int n_pairs, uint32_t round, uint64_t seed,
                           int katzgraber, int32_t *out_info /*[n_pairs][2] nullable*/);
+/* The Houdayer step of one APT round decided entirely on the device (NPT/apt_ICM.py:216-246 for every temperature):
+ * chains are K = n_chains_global / ladder_len ladders (sub-replicas) of ladder_len temperature slots (nlmc_pt_init);
+ * per slot the ladders are shuffled (Philox(ladder, round, slot, ICM_PAIR) keys) and paired, each pair gets one
+ * iso-cluster move with a Philox-picked cluster, tracked energies are resynchronised.  No host round trip.
+ * out_n_pairs = ladder_len * (K / 2); out_info (nullable) [n_pairs][2] = {n_components, picked size}, slot-major. */
+int nlmc_icm_round_ladders(nlmc_ctx *ctx, uint32_t round, uint64_t seed, int katzgraber, int32_t *out_n_pairs,
+                           int32_t *out_info /*nullable*/);
 
 /* Convexified loopy belief propagation (backbone inference), batched: replaces the lambda loop of LBP_convexified
  * (NMC/nmc.py:126-160) together with LoopyBeliefPropagation (NMC/nmc.py:168-228) for n_problems seeds m_star on the

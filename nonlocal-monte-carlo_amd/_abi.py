@@ -23,7 +23,7 @@ EXPORTS = [
     "nlmc_abi_version", "nlmc_device_count", "nlmc_create", "nlmc_destroy", "nlmc_last_error", "nlmc_set_spins",
     "nlmc_get_spins", "nlmc_set_flags", "nlmc_energy", "nlmc_energy_dev", "nlmc_energy_scale", "nlmc_energy_of", "nlmc_sweep_stream",
     "nlmc_sweep_philox", "nlmc_plan_philox", "nlmc_plan_philox_fused", "nlmc_pt_init", "nlmc_pt_get_slots", "nlmc_pt_set_slots",
-    "nlmc_pt_apply_swap", "nlmc_pt_swap_philox", "nlmc_pt_plan", "nlmc_icm_components", "nlmc_icm_move", "nlmc_icm_get_labels", "nlmc_icm_round_philox",
+    "nlmc_pt_apply_swap", "nlmc_pt_swap_philox", "nlmc_pt_plan", "nlmc_icm_components", "nlmc_icm_move", "nlmc_icm_get_labels", "nlmc_icm_round_philox", "nlmc_icm_round_ladders",
     "nlmc_lbp_convexified", "nlmc_find_clusters",
     "nlmc_last_timing", "nlmc_timing_reset", "nlmc_timing_total", "nlmc_last_schedule_stats",
 ]
@@ -105,6 +105,8 @@ def lib():
     L.nlmc_icm_get_labels.argtypes = [_vp, _vp]
     L.nlmc_icm_round_philox.restype = _i
     L.nlmc_icm_round_philox.argtypes = [_vp, _vp, _i, _u32, _u64, _i, _vp]
+    L.nlmc_icm_round_ladders.restype = _i
+    L.nlmc_icm_round_ladders.argtypes = [_vp, _u32, _u64, _i, _vp, _vp]
     L.nlmc_lbp_convexified.restype = _i
     L.nlmc_lbp_convexified.argtypes = [_vp, _i, _vp, _vp, _vp, _i, _dbl, _dbl, _i, _dbl, _vp, _vp, _vp, _vp, _vp]
     L.nlmc_find_clusters.restype = _i

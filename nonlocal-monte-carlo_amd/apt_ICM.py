@@ -196,7 +196,7 @@ class APT_ICM(SweepMixin):
         R, K, N = self.num_replicas, self.num_subreplicas, inst.n
         S, rounds = self.num_sweeps_MCMC_per_swap, int(self.num_swap_attempts)
         G = K * R                                       # chain id = j * R + slot-holder index
-        host_rng = np.random.default_rng(self.seed)
+        host_rng = np.random.default_rng(self.seed)      # initial states only
         eng = Engine(inst, None, G, device=self._cache.device)
         try:
             eng.set_spins(np.sign(2 * host_rng.random((G, N)) - 1).astype(np.int8))
@@ -206,6 +206,7 @@ class APT_ICM(SweepMixin):
                 eng.pt_plan(0, rounds, self.seed, self.num_swapping_pairs)
             last, slots_last = None, np.arange(G, dtype=np.int32) % R
             acc_log, icm_sizes = [], []
+            log_every = max(1, rounds // 64)
             for ii in range(rounds):
                 is_last = ii == rounds - 1
                 if is_last:
@@ -213,20 +214,17 @@ class APT_ICM(SweepMixin):
                 o = planner.sweep(ii, record_stride=1 if is_last else 0)
                 if is_last:
                     last = o["spins"]
-                # Houdayer: for every temperature slot pair up the K sub-replicas that currently hold it
-                slots = eng.pt_slots()
-                holder = np.empty((K, R), dtype=np.int64)              # holder[j, r] = chain of ladder j at slot r
-                for j in range(K):
-                    holder[j, slots[j * R:(j + 1) * R]] = j * R + np.arange(R)
-                pairs = []
-                for r in range(R):
-                    sh = host_rng.permutation(K)
-                    pairs += [(holder[sh[2 * p], r], holder[sh[2 * p + 1], r]) for p in range(K // 2)]
-                info = eng.icm_round_philox(np.array(pairs, dtype=np.int32), ii, self.seed, self.useKatzgraber, want_info=True)
-                icm_sizes.append(info[:, 1].copy())
+                # Houdayer: for every temperature slot the K sub-replicas that currently hold it are shuffled and paired
+                # on the device (nlmc_icm_round_ladders); logs are read back on a sample of the rounds only (a read-back
+                # synchronises the stream)
+                logged = rounds <= 256 or is_last or ii % log_every == 0
+                info = eng.icm_round_ladders(ii, self.seed, self.useKatzgraber, want_info=logged)
+                if logged:
+                    icm_sizes.append(info[:, 1].copy())
                 if self.num_swapping_pairs > 0:
-                    _, a = eng.pt_swap_philox(ii, self.seed, self.num_swapping_pairs, want_log=True)
-                    acc_log.append(a)
+                    _, a = eng.pt_swap_philox(ii, self.seed, self.num_swapping_pairs, want_log=logged)
+                    if logged:
+                        acc_log.append(a)
             self._sweep_counter += rounds * S
             M = np.zeros((N * R, S * K))
             Energy = np.zeros(R)

@@ -45,6 +45,7 @@ struct nlmc_ctx {
     double temp_x = 1.0;
     bool has_flags = false;
     bool has_diag = false;
+    bool has_zero_vals = false;   // a stored entry is 0.0 (or underflows to 0 in fp32)
     size_t lds_opt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // dynamic-LDS opt-in already granted per kernel
 
     DevBuf<int32_t> rowptr, col;
@@ -587,7 +588,7 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
         return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: bad sizes or NULL arrays");
     if (n > NLMC_MAX_N) return fail(nullptr, NLMC_ERR_UNSUPPORTED, "nlmc_create: n exceeds NLMC_MAX_N (spins are LDS-resident)");
     if (rowptr[0] != 0 || rowptr[n] != nnz) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: rowptr[0] != 0 or rowptr[n] != nnz");
-    bool diag = false;
+    bool diag = false, zero_vals = false;
     int max_deg = 0;
     for (int k = 0; k < n; ++k) {
         if (rowptr[k + 1] < rowptr[k]) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: rowptr not monotone");
@@ -595,6 +596,7 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
         for (int e = rowptr[k]; e < rowptr[k + 1]; ++e) {
             if (colidx[e] < 0 || colidx[e] >= n) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: column index out of range");
             if (colidx[e] == k && vals[e] != 0.0) diag = true;
+            if ((float)vals[e] == 0.0f) zero_vals = true;
         }
     }
     int ndev = 0;
@@ -615,6 +617,7 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
     c->chain_base = chain_base;
     c->n_chains_global = n_chains_global;
     c->has_diag = diag;
+    c->has_zero_vals = zero_vals;
     c->max_deg = max_deg;
 
     // fixed-point scale: |E| <= sum|J|/2 + sum|h|
@@ -1179,7 +1182,8 @@ static int icm_launch_components(nlmc_ctx *c, const int32_t *pairs_dev, int n_pa
     HIP_TRY(c, c->icm_info.reserve((size_t)n_pairs * 2));
     IcmArgs a{};
     a.g = c->g; a.spins = c->spins.p; a.pairs = pairs_dev; a.label = c->icm_label.p; a.info = c->icm_info.p;
-    const size_t lds = (size_t)c->n * 4 + 16;
+    a.has_zero_vals = c->has_zero_vals ? 1 : 0;
+    const size_t lds = (size_t)c->n * 4 + (((size_t)c->n + 1) & ~(size_t)1) * 2 + 16;
     { int rc = ensure_lds(c, 1, reinterpret_cast<const void *>(k_icm_components), lds); if (rc) return rc; }
     hipLaunchKernelGGL(k_icm_components, dim3(n_pairs), dim3(c->n >= 4096 ? 1024 : 256), lds, c->stream, a);
     HIP_TRY(c, hipGetLastError());
@@ -1288,6 +1292,33 @@ int nlmc_icm_round_philox(nlmc_ctx *c, const int32_t *pairs, int n_pairs, uint32
     return NLMC_OK;
 }
 
+int nlmc_icm_round_ladders(nlmc_ctx *c, uint32_t round, uint64_t seed, int katzgraber, int32_t *out_n_pairs,
+                           int32_t *out_info)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (c->ladder_len == 0) return fail(c, NLMC_ERR_STATE, "nlmc_icm_round_ladders: nlmc_pt_init first");
+    if (c->chain_base != 0 || c->n_chains != c->n_chains_global)
+        return fail(c, NLMC_ERR_UNSUPPORTED, "nlmc_icm_round_ladders: the sub-replicas of a temperature must live in one context");
+    const int R = c->ladder_len, K = c->n_chains_global / R, n_pairs = R * (K / 2);
+    if (out_n_pairs) *out_n_pairs = n_pairs;
+    if (n_pairs == 0) return NLMC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, c->icm_pairs.reserve((size_t)n_pairs * 2));
+    hipLaunchKernelGGL(k_icm_pair_ladders, dim3((R + 63) / 64), dim3(64), 0, c->stream, R, K, round, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), c->chain_of_slot.p, c->icm_pairs.p);
+    HIP_TRY(c, hipGetLastError());
+    int rc = icm_launch_components(c, c->icm_pairs.p, n_pairs);
+    if (rc) return rc;
+    rc = icm_apply(c, n_pairs, nullptr, 0, round, seed, katzgraber, 1);
+    if (rc) return rc;
+    rc = launch_energy_self(c, nullptr);
+    if (rc) return rc;
+    if (out_info) {
+        HIP_TRY(c, hipMemcpyAsync(out_info, c->icm_info.p, sizeof(int32_t) * 2 * n_pairs, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return NLMC_OK;
+}
 
 // ------------------------------------------------------------------------------------------------------
 // convexified loopy belief propagation (backbone inference), batched over problems

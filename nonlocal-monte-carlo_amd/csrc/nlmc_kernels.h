@@ -1153,11 +1153,35 @@ __global__ void k_energy(EnergyArgs a)
     const int8_t *src = a.spins + (size_t)blockIdx.x * a.stride;
     for (int i = tid; i < n; i += nt) s[i] = src[i];
     __syncthreads();
+    // Four rows per thread at a time, the first 8 entries of each fetched unconditionally (padded arrays): 64
+    // independent loads in flight instead of a rowptr -> entry -> entry chain per row.  The association of every sum
+    // is the plain row-by-row, entry-by-entry one (a skipped slot leaves x untouched).
     double acc = 0.0;
-    for (int k = tid; k < n; k += nt) {
-        double x = 0.0;
-        for (int e = a.g.rowptr[k]; e < a.g.rowptr[k + 1]; ++e) x += a.g.val64[e] * (double)s[a.g.col[e]];
-        acc += (double)s[k] * (0.5 * x + a.g.h64[k]);
+    for (int k0 = tid; k0 < n; k0 += 4 * nt) {
+        int rs[4], dg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * nt;
+            rs[u] = k < n ? a.g.rowptr[k] : 0;
+            dg[u] = k < n ? a.g.rowptr[k + 1] - rs[u] : 0;
+        }
+        int cj[4][8];
+        double vj[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { cj[u][q] = a.g.col[rs[u] + q]; vj[u][q] = a.g.val64[rs[u] + q]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * nt;
+            if (k < n) {
+                double x = 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x = q < dg[u] ? x + vj[u][q] * (double)s[cj[u][q]] : x;
+                for (int e = rs[u] + 8; e < rs[u] + dg[u]; ++e) x += a.g.val64[e] * (double)s[a.g.col[e]];
+                acc += (double)s[k] * (0.5 * x + a.g.h64[k]);
+            }
+        }
     }
     acc = wave_sum_f64_tree(acc);
     if ((tid & 63) == 0) part[tid >> 6] = acc;

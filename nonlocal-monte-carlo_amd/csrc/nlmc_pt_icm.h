@@ -151,6 +151,7 @@ struct IcmArgs {
     const int32_t *pairs;     // [n_pairs][2] local chain ids
     int32_t *label;           // [n_pairs][n]  min member index of the component, or INT_MAX if the spins agree
     int32_t *info;            // [n_pairs][2]  {n_components, picked size}
+    int has_zero_vals;        // some stored entry of J is 0 (or underflows in fp32): test values like the reference does
 };
 
 // Connected components of the sub-graph induced by {k : s_a[k] s_b[k] = -1} (NPT/apt_ICM.py:116-143): union-find in
@@ -170,25 +171,43 @@ __global__ void k_icm_components(IcmArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     int32_t *lab = reinterpret_cast<int32_t *>(lds_raw);
-    __shared__ int nroots;
+    __shared__ int nroots, ncand;
     const int n = a.g.n, tid = threadIdx.x, nt = blockDim.x, p = blockIdx.x;
+    uint16_t *cand = reinterpret_cast<uint16_t *>(lab + n);          // the disagreeing spins, compacted (any order)
     const int8_t *sa = a.spins + (size_t)a.pairs[2 * p] * a.g.n_pad;
     const int8_t *sb = a.spins + (size_t)a.pairs[2 * p + 1] * a.g.n_pad;
-    for (int k = tid; k < n; k += nt) lab[k] = ((int)sa[k] * (int)sb[k] == -1) ? k : INT_MAX;
-    if (tid == 0) nroots = 0;
+    if (tid == 0) { nroots = 0; ncand = 0; }
     __syncthreads();
+    for (int k = tid; k < n; k += nt) {
+        const bool d = (int)sa[k] * (int)sb[k] == -1;
+        lab[k] = d ? k : INT_MAX;
+        if (d) cand[atomicAdd(&ncand, 1)] = (uint16_t)k;
+    }
+    __syncthreads();
+    const int nc = ncand;
+    // Hook rounds over the candidates only; the first 8 entries of a row are fetched as independent loads before the
+    // dependent find/hook chain starts (the arrays are padded, entries past the row end are ignored).
     for (int it = 0; it <= n; ++it) {
         int changed = 0;
-        for (int k = tid; k < n; k += nt) {
-            if (lab[k] == INT_MAX) continue;
+        for (int idx = tid; idx < nc; idx += nt) {
+            const int k = (int)cand[idx];
+            const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
+            EdgeF ed[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ed[q] = a.g.edge32[rs + q];
             int rk = icm_find(lab, k);
-            for (int e = a.g.rowptr[k]; e < a.g.rowptr[k + 1]; ++e) {
-                const EdgeF ed = a.g.edge32[e];
-                if (ed.val == 0.0f && a.g.val64[e] == 0.0) continue;       // `val != 0` test, NPT/apt_ICM.py:129
-                if (lab[ed.col] == INT_MAX) continue;
-                const int rj = icm_find(lab, ed.col);
+            auto hook = [&](int j, bool nz) {
+                if (!nz || lab[j] == INT_MAX) return;
+                const int rj = icm_find(lab, j);
                 if (rj < rk) { atomicMin(&lab[rk], rj); rk = rj; changed = 1; }
                 else if (rk < rj) { atomicMin(&lab[rj], rk); changed = 1; }
+            };
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < deg) hook(ed[q].col, !a.has_zero_vals || ed[q].val != 0.0f || a.g.val64[rs + q] != 0.0);   // `val != 0`, NPT/apt_ICM.py:129
+            for (int e = rs + 8; e < rs + deg; ++e) {
+                const EdgeF t = a.g.edge32[e];
+                hook(t.col, !a.has_zero_vals || t.val != 0.0f || a.g.val64[e] != 0.0);
             }
         }
         if (!__syncthreads_or(changed)) break;
@@ -204,6 +223,28 @@ __global__ void k_icm_components(IcmArgs a)
     if (cnt) atomicAdd(&nroots, cnt);
     __syncthreads();
     if (tid == 0) { a.info[2 * p] = nroots; a.info[2 * p + 1] = 0; }
+}
+
+// Houdayer pairing on the device (NPT/apt_ICM.py:216-222): for every temperature slot r the K ladders (sub-replicas)
+// are shuffled -- order = sort of the keys philox(j, round, r, ICM_PAIR) -- and paired (sh[0], sh[1]), (sh[2], sh[3]), ...;
+// a pair is written as the two LOCAL chains that currently hold slot r in those ladders.  One thread per slot.
+#define NLMC_TAG_ICM_PAIR 6u
+__global__ void k_icm_pair_ladders(int R, int K, uint32_t round, uint32_t seed_lo, uint32_t seed_hi,
+                                   const int32_t *chain_of_slot, int32_t *pairs)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int half = K / 2;
+    for (int j = 0; j < K; ++j) {
+        const uint32_t kj = philox4x32_10((uint32_t)j, round, (uint32_t)r, NLMC_TAG_ICM_PAIR, seed_lo, seed_hi).x;
+        int rank = 0;                          // position of ladder j in the shuffled order
+        for (int i = 0; i < K; ++i) {
+            if (i == j) continue;
+            const uint32_t ki = philox4x32_10((uint32_t)i, round, (uint32_t)r, NLMC_TAG_ICM_PAIR, seed_lo, seed_hi).x;
+            rank += (ki < kj) || (ki == kj && i < j);
+        }
+        if (rank < 2 * half) pairs[((size_t)r * half + rank / 2) * 2 + (rank & 1)] = chain_of_slot[(size_t)j * R + r];
+    }
 }
 
 struct IcmMoveArgs {

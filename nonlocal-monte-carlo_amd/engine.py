@@ -261,6 +261,16 @@ class Engine:
                                                int(bool(katzgraber)), _abi.ptr(info)))
         return info
 
+    def icm_round_ladders(self, round_idx, seed, katzgraber=True, want_info=False):
+        """Houdayer step of one APT round with the pairing decided on the device (include/nlmc.h)."""
+        npairs = ctypes.c_int32(0)
+        R = self.ladder_len
+        K = self.n_chains_global // R
+        info = np.zeros((R * (K // 2), 2), np.int32) if want_info else None
+        self._ck(self._L.nlmc_icm_round_ladders(self._ctx, int(round_idx), int(seed), int(bool(katzgraber)),
+                                                ctypes.byref(npairs), _abi.ptr(info)))
+        return info
+
     # -- backbone inference (loopy BP on the device) -------------------------------------------------------
     def lbp_convexified(self, m_star, epsilon, lambdas, beta, tolerance, max_iterations, sat, want_all=False):
         """Batched lambda loop of LBP_convexified (include/nlmc.h: nlmc_lbp_convexified).  m_star [P, n] float64.

@@ -79,18 +79,9 @@ def c5():
     eng = P.Engine(J, h, G)
     eng.set_spins(init_spins(G, N)); eng.pt_init(np.geomspace(0.05, 4.0, R))
     planner = P.engine.RoundPlanner(eng, 0, rounds + 1, S, 5); planner._plan(0, True); eng.pt_plan(0, rounds + 1, 5, 10)
-    rng = np.random.default_rng(0)
     def one(r):
         planner.sweep(r)
-        slots = eng.pt_slots()
-        holder = np.empty((K, R), dtype=np.int64)
-        for j in range(K):
-            holder[j, slots[j * R:(j + 1) * R]] = j * R + np.arange(R)
-        pairs = []
-        for rr in range(R):
-            sh = rng.permutation(K)
-            pairs += [(holder[sh[2 * p], rr], holder[sh[2 * p + 1], rr]) for p in range(K // 2)]
-        eng.icm_round_philox(np.array(pairs, dtype=np.int32), r, 5, True)
+        eng.icm_round_ladders(r, 5, True)
         eng.pt_swap_philox(r, 5, 10, want_log=False)
     one(0); eng.energy()
     def run():

@@ -124,3 +124,48 @@ def test_icm_round_philox_batch(product):
         else:
             exp[a, cl[pick]], exp[b, cl[pick]] = m0[b, cl[pick]], m0[a, cl[pick]]
     assert np.array_equal(got, exp)
+
+
+def test_icm_round_ladders_pairing_and_moves(product):
+    """nlmc_icm_round_ladders: per temperature slot the K ladders are shuffled by Philox keys and paired
+    (NPT/apt_ICM.py:216-222); each pair gets the iso-cluster move of test_icm_round_philox_batch.  Restated on the host
+    with the oracle's Philox and cluster routines, after a few swap rounds so that slots are no longer the identity."""
+    TAG_ICM_PAIR = 6
+    N, R, K = 150, 4, 6
+    J, h = make_instance(N, seed=21)
+    csr = oracle.Csr(J)
+    G = R * K
+    seed, rnd = 99887766, 5
+    with product.Engine(J, h, G) as eng:
+        eng.set_spins(init_spins(G, N))
+        eng.pt_init(np.geomspace(0.2, 2.0, R))
+        eng.sweep_philox(3, seed, beta=None)
+        for r0 in range(3):
+            eng.pt_swap_philox(r0, seed, 1, want_log=False)
+        slots = eng.pt_slots()
+        m0 = eng.get_spins()
+        info = eng.icm_round_ladders(rnd, seed, katzgraber=True, want_info=True)
+        got = eng.get_spins()
+        E = eng.energy()
+    assert not np.array_equal(slots, np.arange(G) % R)
+    exp = m0.copy()
+    p = 0
+    for r in range(R):
+        keys = [int(oracle.philox(j, rnd, r, TAG_ICM_PAIR, seed & 0xFFFFFFFF, seed >> 32)[0]) for j in range(K)]
+        sh = sorted(range(K), key=lambda j: (keys[j], j))
+        holder = {j: j * R + int(np.where(slots[j * R:(j + 1) * R] == r)[0][0]) for j in range(K)}
+        for q in range(K // 2):
+            a, b = holder[sh[2 * q]], holder[sh[2 * q + 1]]
+            cl = oracle.clusters(csr, m0[a], m0[b])
+            assert info[p, 0] == len(cl)
+            if cl:
+                w = int(oracle.philox(a, rnd, b, TAG_ICM, seed & 0xFFFFFFFF, seed >> 32)[0])
+                pick = (w * len(cl)) >> 32
+                assert info[p, 1] == len(cl[pick])
+                if len(cl[pick]) > N // 2:
+                    exp[a] = -exp[a]
+                else:
+                    exp[a, cl[pick]], exp[b, cl[pick]] = m0[b, cl[pick]], m0[a, cl[pick]]
+            p += 1
+    assert np.array_equal(got, exp)
+    assert np.allclose(E, [oracle.energy(csr, h, s) for s in got], rtol=0, atol=1e-9)
