@@ -120,3 +120,24 @@ def test_fused_plan_declines_what_it_cannot_run(product):
         eng.sweep_philox(T, SEED, sweep0=0, beta=1.0)                                           # fused
         assert eng.last_schedule_stats()["levels"] / T < st["levels"] / T
         assert np.array_equal(eng.energy(), e_plain)
+
+
+@pytest.mark.parametrize("N", [1600, 3000, 5000])
+def test_fused_small_workgroups(product, N):
+    """Sweep workgroups of 4 / 6 / 10 waves (3 / 5 / 9 workers + one helper wave): same bits as the plain path and as
+    the sequential oracle."""
+    R, T, W = 5, 7, 2
+    J, h = make_instance(N, seed=N)
+    inst = product.Instance(J, h)
+    betas = np.geomspace(0.2, 2.5, R)
+    m0 = init_spins(R, N)
+    f = run_windows(product, inst, R, T, W, betas, True, m0=m0)
+    p = run_windows(product, inst, R, T, W, betas, False, m0=m0)
+    assert f[3] == W and max(f[4]) < min(p[4])
+    assert np.array_equal(f[0], p[0]) and np.array_equal(f[1], p[1])
+    csr = oracle.Csr(J)
+    c = R - 1
+    cb = np.tile(np.array(oracle.cb_pair(betas[c])), (T * W, 1))
+    e0 = int(np.rint(oracle.energy(csr, h, m0[c]) * 2.0 ** f[5]))
+    _, s_fin, tr = oracle.sweeps_philox(csr, h, m0[c], cb, SEED, c, escale=f[5], efix0=e0, want_M=False)
+    assert np.array_equal(f[0][c], s_fin) and f[1][c] == tr[-1] * 2.0 ** -f[5]
