@@ -1382,7 +1382,7 @@ int nlmc_lbp_convexified(nlmc_ctx *c, int n_problems, const double *m_star, cons
     a.n = n; a.nnz = nnz; a.n_lams = n_lambdas; a.max_iter = max_iterations;
     a.rowptr = c->rowptr.p; a.col = c->col.p; a.src = c->lbp_src.p; a.rev = c->lbp_rev.p;
     a.val = c->val64.p; a.tJ = c->lbp_tJ.p; a.h = c->h64.p; a.eps = c->lbp_eps.p; a.m_star = c->lbp_ms.p; a.lams = c->lbp_lams.p;
-    a.beta = beta; a.inv_beta = 1.0 / beta; a.tol = tolerance; a.sat = sat;
+    a.beta = beta; a.inv_beta = 1.0 / beta; a.tol = tolerance; a.sat = sat; a.usat = std::atanh(sat) / beta;
     a.w0 = c->lbp_w0.p; a.w1 = c->lbp_w1.p; a.hm = c->lbp_hm.p; a.tot = c->lbp_tot.p; a.mag = c->lbp_mag.p;
     a.mag_all = out_mag_all ? c->lbp_mag_all.p : nullptr;
     a.out_nlam = c->lbp_out_i.p; a.out_status = c->lbp_out_i.p + P; a.out_iters = c->lbp_out_i.p + 2 * P;
