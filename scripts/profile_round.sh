@@ -15,6 +15,11 @@ timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVES SQ
 timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -d "$OUT/sq2" -o q -- $B > "$OUT/sq2.log" 2>&1
 timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES -d "$OUT/sq3" -o q -- $B > "$OUT/sq3.log" 2>&1
 python3 "$REPO/scripts/summarize_prof.py" "$TAG" "$OUT/stats" "$OUT/fetch" "$OUT/write" "$OUT/sq1" "$OUT/sq2" "$OUT/sq3"
+# secondary kernels: backbone inference (k_lbp) and the APT + iso-cluster round (C5)
+timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/lbp" -o s -- python3 $REPO/scripts/lbp_throughput.py > "$OUT/lbp.log" 2>&1
+timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c5" -o s -- python3 $REPO/scripts/c5_only.py > "$OUT/c5.log" 2>&1
+cp "$OUT/lbp/s_kernel_stats.csv" "$REPO/profiles/${TAG}_lbp_kernel_stats.csv"
+cp "$OUT/c5/s_kernel_stats.csv" "$REPO/profiles/${TAG}_c5_kernel_stats.csv"
 cp "$REPO"/profiles/${TAG}_* "$OUT"/
 python3 "$REPO/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -1 "$OUT/bench.json"
