@@ -36,10 +36,10 @@ PHILOX_SEED = 0xA5A50000
 BYTES_PER_UPDATE = 63        # 9*d + 9 at d = 6 (fp32 J, int32 col, int8 spins)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 # HBM bytes per k_sweep_fused launch of THIS workload from the PMC passes committed in
-# profiles/r01_e_sweep_hbm_traffic_pmc.csv: (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 read correction applied).
+# profiles/r01_f_sweep_hbm_traffic_pmc.csv: (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 read correction applied).
 # It is the touched part of the level schedule fetched once per XCD (plus the warm-up touch of the next window's) and the
 # spin write-back; PMC cannot be read live.
-HBM_TRAFFIC_BYTES_PER_LAUNCH = 85_645_256
+HBM_TRAFFIC_BYTES_PER_LAUNCH = 85_637_031
 
 
 def cpu_baseline(J, h, seconds=12.0):
@@ -174,7 +174,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": HBM_TRAFFIC_BYTES_PER_LAUNCH if (world == 1 and count == REPLICAS_PER_GPU) else None,
-                         "traffic_source": "profiles/r01_e_sweep_hbm_traffic_pmc.csv",
+                         "traffic_source": "profiles/r01_f_sweep_hbm_traffic_pmc.csv",
                          "algorithmic_bytes_per_launch": upd_launch * BYTES_PER_UPDATE,
                          "kernel": "k_sweep_fused<false>", "us_per_launch": ms_launch * 1e3,
                          "bytes_per_update": BYTES_PER_UPDATE, "updates_per_launch": upd_launch,

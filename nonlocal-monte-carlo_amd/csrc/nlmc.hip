@@ -1308,7 +1308,7 @@ int nlmc_icm_round_ladders(nlmc_ctx *c, uint32_t round, uint64_t seed, int katzg
     if (n_pairs == 0) return NLMC_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, c->icm_pairs.reserve((size_t)n_pairs * 2));
-    hipLaunchKernelGGL(k_icm_pair_ladders, dim3((R + 63) / 64), dim3(64), 0, c->stream, R, K, round, (uint32_t)seed,
+    hipLaunchKernelGGL(k_icm_pair_ladders, dim3((R * K + 63) / 64), dim3(64), 0, c->stream, R, K, round, (uint32_t)seed,
                        (uint32_t)(seed >> 32), c->chain_of_slot.p, c->icm_pairs.p);
     HIP_TRY(c, hipGetLastError());
     int rc = icm_launch_components(c, c->icm_pairs.p, n_pairs);

@@ -227,24 +227,22 @@ __global__ void k_icm_components(IcmArgs a)
 
 // Houdayer pairing on the device (NPT/apt_ICM.py:216-222): for every temperature slot r the K ladders (sub-replicas)
 // are shuffled -- order = sort of the keys philox(j, round, r, ICM_PAIR) -- and paired (sh[0], sh[1]), (sh[2], sh[3]), ...;
-// a pair is written as the two LOCAL chains that currently hold slot r in those ladders.  One thread per slot.
+// a pair is written as the two LOCAL chains that currently hold slot r in those ladders.
 #define NLMC_TAG_ICM_PAIR 6u
 __global__ void k_icm_pair_ladders(int R, int K, uint32_t round, uint32_t seed_lo, uint32_t seed_hi,
                                    const int32_t *chain_of_slot, int32_t *pairs)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    const int half = K / 2;
-    for (int j = 0; j < K; ++j) {
-        const uint32_t kj = philox4x32_10((uint32_t)j, round, (uint32_t)r, NLMC_TAG_ICM_PAIR, seed_lo, seed_hi).x;
-        int rank = 0;                          // position of ladder j in the shuffled order
-        for (int i = 0; i < K; ++i) {
-            if (i == j) continue;
-            const uint32_t ki = philox4x32_10((uint32_t)i, round, (uint32_t)r, NLMC_TAG_ICM_PAIR, seed_lo, seed_hi).x;
-            rank += (ki < kj) || (ki == kj && i < j);
-        }
-        if (rank < 2 * half) pairs[((size_t)r * half + rank / 2) * 2 + (rank & 1)] = chain_of_slot[(size_t)j * R + r];
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per (slot r, ladder j)
+    if (id >= R * K) return;
+    const int r = id / K, j = id % K, half = K / 2;
+    const uint32_t kj = philox4x32_10((uint32_t)j, round, (uint32_t)r, NLMC_TAG_ICM_PAIR, seed_lo, seed_hi).x;
+    int rank = 0;                              // position of ladder j in the shuffled order of slot r
+    for (int i = 0; i < K; ++i) {
+        if (i == j) continue;
+        const uint32_t ki = philox4x32_10((uint32_t)i, round, (uint32_t)r, NLMC_TAG_ICM_PAIR, seed_lo, seed_hi).x;
+        rank += (ki < kj) || (ki == kj && i < j);
     }
+    if (rank < 2 * half) pairs[((size_t)r * half + rank / 2) * 2 + (rank & 1)] = chain_of_slot[(size_t)j * R + r];
 }
 
 struct IcmMoveArgs {
