@@ -109,7 +109,7 @@ int nlmc_plan_philox(nlmc_ctx *ctx, int precision, int order_mode, uint32_t swee
  * (DESIGN.md section 3).  A later nlmc_sweep_philox call with F32, shared order, n_sweeps == window, a planned
  * sweep0, constant beta and no per-sweep outputs (no recorded spins, energies or minima) runs on it; every other call
  * takes the sweep-by-sweep path.  Results are bit-identical either way.  out_planned: number of windows that got a
- * fused schedule (0 when the instance does not qualify: n <= 1536 (sweep workgroup below 4 waves) or n > 11264,
+ * fused schedule (0 when the instance does not qualify: n < 256 or n > 11264,
  * window < 3 or > 64, or the three uniform tables do not fit in LDS next to the spins). */
 int nlmc_plan_philox_fused(nlmc_ctx *ctx, uint32_t sweep0, int n_windows, int window, uint64_t seed, int32_t *out_planned);
 

@@ -248,6 +248,9 @@ int run_levelize(nlmc_ctx *c, int n_orders, const uint32_t *keys_in, int per_cha
 // ---- fused-window path ------------------------------------------------------------------------------------
 // worker waves of a sweep workgroup of nt threads; the others generate uniforms and warm the cache
 // (NLMC_FUSED_WORKERS: tuning knob for the 16-wave case)
+// threads of a fused sweep workgroup: at least 4 waves (3 workers + 1 helper) also for small instances
+int fused_block(int n) { return std::max(256, sweep_block(n)); }
+
 int fused_workers(int nt)
 {
     const int waves = nt / 64;
@@ -280,7 +283,7 @@ FusedLds fused_lds(int n, int n_pad, bool has_flags, int T)
 bool fused_supported(const nlmc_ctx *c, int T)
 {
     if (getenv("NLMC_NO_FUSED")) return false;
-    if (sweep_block(c->n) < 256 || c->n > NLMC_FZ_SPT * 1024 || c->max_deg > 0x3FFF || T < 3 || T > NLMC_FUSED_TMAX) return false;
+    if (c->n < 256 || c->n > NLMC_FZ_SPT * 1024 || c->max_deg > 0x3FFF || T < 3 || T > NLMC_FUSED_TMAX) return false;
     if ((size_t)T * c->n > ((size_t)1 << 22)) return false;            // 32-bit buffer offsets of the packed planes
     return fused_lds(c->n, c->n_pad, true, T).total <= (size_t)150 * 1024;
 }
@@ -326,7 +329,7 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
     a.argmin = c->argmin.p;
     a.lds_flags_off = L.flags_off; a.lds_u_off = L.u_off; a.lds_u_stride = L.u_bytes; a.lds_loff_off = L.loff_off;
     a.lds_send_off = L.send_off; a.lds_red_off = L.red_off;
-    const int nt = sweep_block(n);
+    const int nt = fused_block(n);
     if (c->has_diag) hipLaunchKernelGGL((k_sweep_fused<true>), dim3(R), dim3(nt), L.total, c->stream, a);
     else hipLaunchKernelGGL((k_sweep_fused<false>), dim3(R), dim3(nt), L.total, c->stream, a);
     HIP_TRY(c, hipGetLastError());
@@ -945,7 +948,7 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     a.g = c->g;
     a.T = T;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.sweep0 = sweep0;
-    c->fz_workers = fused_workers(sweep_block(c->n));
+    c->fz_workers = fused_workers(fused_block(c->n));
     a.level_cap = c->fz_workers * 64;
     a.adj = reinterpret_cast<const uint4 *>(c->fz_adj.p); a.glv = c->fz_glv.p; a.perm = c->fz_perm.p; a.head = c->fz_head.p; a.ell = c->fz_ell.p; a.loff = c->fz_loff.p; a.nlev = c->fz_nlev.p;
     a.hi_max = c->fz_himax.p; a.send = c->fz_send.p;

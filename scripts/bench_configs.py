@@ -59,11 +59,11 @@ def c3():
     G = L * NL
     eng = P.Engine(J, h, G)
     eng.set_spins(init_spins(G, N)); eng.pt_init(np.geomspace(0.1, 3.0, L))
-    eng.plan_philox(0, S * (rounds + 1), 3); eng.pt_plan(0, rounds + 1, 3, pairs)
-    eng.sweep_philox(S, 3, sweep0=0, beta=None); eng.pt_swap_philox(0, 3, pairs, want_log=False); eng.energy()
+    planner = P.engine.RoundPlanner(eng, 0, rounds + 1, S, 3); planner._plan(0, True); eng.pt_plan(0, rounds + 1, 3, pairs)
+    planner.sweep(0); eng.pt_swap_philox(0, 3, pairs, want_log=False); eng.energy()
     def run():
         for r in range(1, rounds + 1):
-            eng.sweep_philox(S, 3, sweep0=r * S, beta=None)
+            planner.sweep(r)
             eng.pt_swap_philox(r, 3, pairs, want_log=False)
         return eng.energy()
     dt, E = timed(run)

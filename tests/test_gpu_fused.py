@@ -101,9 +101,9 @@ def test_fused_with_swaps_and_sharded_contexts(product):
 
 
 def test_fused_plan_declines_what_it_cannot_run(product):
-    """Small instance (workgroup smaller than 1024 threads), window of 2: nothing planned, calls take the plain path;
+    """Tiny instance (n < 256), window of 2: nothing planned, calls take the plain path;
     calls with per-sweep outputs ignore a fused plan."""
-    J, h = make_instance(1000, seed=3)
+    J, h = make_instance(200, seed=3)
     with product.Engine(J, h, 2) as eng:
         assert eng.plan_philox_fused(0, 4, 10, SEED) == 0
     N, T = 8000, 5
@@ -122,7 +122,7 @@ def test_fused_plan_declines_what_it_cannot_run(product):
         assert np.array_equal(eng.energy(), e_plain)
 
 
-@pytest.mark.parametrize("N", [1600, 3000, 5000])
+@pytest.mark.parametrize("N", [300, 1000, 1600, 3000, 5000])
 def test_fused_small_workgroups(product, N):
     """Sweep workgroups of 4 / 6 / 10 waves (3 / 5 / 9 workers + one helper wave): same bits as the plain path and as
     the sequential oracle."""
