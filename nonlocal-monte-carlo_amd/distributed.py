@@ -56,7 +56,7 @@ class ShardedTempering:
         if n_rounds > 0 and n_sweeps % n_rounds == 0 and hasattr(self.eng, "plan_philox_fused"):
             # rounds of equal length: fused-window level lists where the instance qualifies (same bits, fuller levels)
             self._planner = RoundPlanner(self.eng, self.sweeps_done, n_rounds, n_sweeps // n_rounds, self.seed,
-                                         precision=self.precision, budget_bytes=4 << 30)
+                                         precision=self.precision, budget_bytes=16 << 30)
             self._planner_round0 = self.rounds_done
             self._planner._plan(0, True)
         else:
