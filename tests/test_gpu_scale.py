@@ -183,3 +183,45 @@ def test_c4_size_determinism_race_screen(product):
     assert np.array_equal(outs[0][0], outs[1][0])
     assert np.array_equal(outs[0][1], outs[1][1])
     assert np.array_equal(outs[0][2], outs[1][2])
+
+
+def test_c4_size_fused_windows_oracle_sample_and_energy(product):
+    """The exact workload bench.py times (N = 10^4, 256 replicas, fused windows of 10 sweeps, swap round between
+    windows): tracked energies == fp64 recomputation for every replica; the hot, a middle and the cold replica of the
+    first window re-run by the sequential oracle, spins bit for bit; same seed twice -> same bits (race screen)."""
+    N, R, T, W, SEED, PAIRS = 10_000, 256, 10, 3, 0xA5A50000, 77
+    J, h = make_instance(N)
+    csr = oracle.Csr(J)
+    betas = np.geomspace(0.05, 4.0, R)
+    m0 = init_spins(R, N)
+
+    def run(n_windows):
+        with product.Engine(J, h, R) as eng:
+            eng.set_spins(m0)
+            eng.pt_init(betas)
+            E0 = eng.energy()
+            assert eng.plan_philox_fused(0, n_windows, T, SEED) == n_windows
+            eng.pt_plan(0, n_windows, SEED, PAIRS)
+            for w in range(n_windows):
+                eng.sweep_philox(T, SEED, sweep0=w * T, beta=None)
+                assert eng.last_schedule_stats()["levels"] / T < 18.5        # fused list (sweep by sweep: ~21)
+                if w + 1 < n_windows:
+                    eng.pt_swap_philox(w, SEED, PAIRS, want_log=False)
+            tracked = eng.energy()                       # tracked fixed-point energies
+            spins = eng.get_spins()
+            exact = eng.energy_of(spins)
+            return E0, tracked, spins, exact, eng.pt_slots(), eng.energy_scale
+
+    E0, tracked, spins, exact, slots, esc = run(1)
+    assert np.array_equal(tracked, exact)
+    for c in (0, 131, 255):
+        cb = np.tile(np.array(oracle.cb_pair(betas[c])), (T, 1))
+        _, s_fin, tr = oracle.sweeps_philox(csr, h, m0[c], cb, SEED, c, escale=esc, efix0=int(np.rint(E0[c] * 2.0 ** esc)),
+                                            want_M=False)
+        assert np.array_equal(spins[c], s_fin)
+        assert tracked[c] == tr[-1] * 2.0 ** -esc
+    a = run(W)
+    b = run(W)
+    assert np.array_equal(a[1], a[3])                                        # energies consistent after swaps too
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4])
+    assert not np.array_equal(a[4], np.arange(R))                            # swaps happened
