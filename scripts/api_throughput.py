@@ -15,3 +15,15 @@ for (N, R, sweeps, rounds, pairs) in ((10_000, 256, 1000, 100, 77), (1000, 32, 1
         dt = time.perf_counter() - t0
     print(f"NPT.run philox N={N} R={R} sweeps={sweeps} rounds={rounds}: {dt:.3f} s wall incl. instance upload, planning, "
           f"read-out -> {R * N * sweeps / dt:.3e} updates/s ; min energy {E.min():.1f} ; swaps accepted {obj.swap_accepted.mean():.2f}", flush=True)
+
+# NMC(J, h, rng="philox").run(): single chain, the reference's headline call (NMC/examples/general_example.py)
+for (N, s0, s, cycles) in ((1000, 1000, 1000, 4), (10_000, 1000, 1000, 2)):
+    J, h = make_instance(N)
+    obj = P.NMC(J, h, rng="philox", seed=1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        t0 = time.perf_counter()
+        M, E, emin = obj.run(s0, s, cycles, 1, 1, 20, 3, 3, 0.01, 0.9, 0.9999999, 0.999999, 100, np.finfo(float).eps)
+        dt = time.perf_counter() - t0
+    tot = s0 + 3 * cycles * s
+    print(f"NMC.run philox N={N}: {tot} sweeps of one chain + {cycles} backbone inferences in {dt:.3f} s "
+          f"({dt / tot * 1e6:.1f} us per sweep all in) ; min energy {emin:.1f}", flush=True)
