@@ -256,11 +256,11 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
     uint32_t *hist = reinterpret_cast<uint32_t *>(queue + n4);
     uint32_t *histL = hist + NLMC_LCAP + 2;
     __shared__ int sh_lmax[NLMC_FUSED_TMAX];
-    __shared__ int sh_max, sh_fail, sh_himax, sh_nlev, sh_qn;
+    __shared__ int sh_max, sh_fail, sh_nlev, sh_qn;
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int k = tid; k < n; k += nt) g[k] = 0;
     for (int l = tid; l < 2 * (NLMC_LCAP + 2); l += nt) hist[l] = 0u;      // hist and histL are adjacent
-    if (tid == 0) { sh_fail = 0; sh_himax = 0; sh_qn = 0; }
+    if (tid == 0) { sh_fail = 0; sh_qn = 0; }
     __syncthreads();
     uint16_t *glv = a.glv + (size_t)w * T * n;
 
