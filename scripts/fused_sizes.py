@@ -6,7 +6,7 @@ sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 from conftest import load_product
 from helpers import make_instance, init_spins
 P = load_product()
-T, W = 10, 20
+T, W = 10, int(os.environ.get("W", 20))
 for N, R in ((300, 1024), (1000, 256), (1000, 1024), (1600, 512), (2048, 512), (4096, 256), (7000, 256), (10000, 256)):
     J, h = make_instance(N, seed=5)
     inst = P.Instance(J, h)
