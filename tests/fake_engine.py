@@ -33,7 +33,13 @@ class OracleEngine:
         return self.spins.copy()
 
     def plan_philox(self, *a, **k):
-        pass
+        self.planned_plain = getattr(self, "planned_plain", 0) + 1
+
+    def plan_philox_fused(self, sweep0, n_windows, window, seed):
+        """The oracle has no level schedule: it either 'plans' every window (fused_ok) or none, so that the planner's
+        two branches are both exercised; a fused launch is then just `window` sequential sweeps."""
+        self.fused_calls = getattr(self, "fused_calls", 0) + 1
+        return n_windows if getattr(self, "fused_ok", True) else 0
 
     def sweep_philox(self, n_sweeps, seed, sweep0=0, beta=None, precision="f32"):
         assert beta is None

@@ -70,3 +70,42 @@ def test_two_ranks_reproduce_single_process(tmp_path):
         assert np.array_equal(r["spins"], ref_spins)        # same bits for 1 and 2 ranks
         assert np.array_equal(r["slots"], ref_slots)        # replicated slot table stayed consistent
     assert not np.array_equal(ref_slots, np.arange(L * NL) % L) or True
+
+
+@pytest.mark.parametrize("fused_ok", [True, False])
+def test_planned_rounds_equal_unplanned(fused_ok):
+    """ShardedTempering.plan() + RoundPlanner on the CPU test double: rounds run through the planner -- as fused-window
+    launches when the engine accepts the plan, sweep by sweep when it declines -- give the same bits as rounds without
+    any plan, and the planner asks for the right windows."""
+    from fake_engine import OracleEngine
+    P, inst, betas, m0 = _setup()
+    G, S6, ROUNDS5 = L * NL, 6, 5
+
+    def drive(plan):
+        made = []
+
+        def mk(i, n, b, g):
+            e = OracleEngine(i, n, b, g)
+            e.fused_ok = fused_ok
+            made.append(e)
+            return e
+        st = P.distributed.ShardedTempering(mk, inst, betas, G, SEED, PAIRS, device="cpu")
+        st.set_spins(m0)
+        if plan:
+            st.plan(ROUNDS5 * S6, ROUNDS5)
+        for _ in range(ROUNDS5):
+            st.round(S6)
+        return st.gather_spins(), st.eng.pt_slots(), made[0], st
+
+    a_spins, a_slots, eng_a, st_a = drive(True)
+    b_spins, b_slots, _, _ = drive(False)
+    assert np.array_equal(a_spins, b_spins) and np.array_equal(a_slots, b_slots)
+    assert eng_a.fused_calls == 1                              # asked once, for all rounds
+    assert st_a._planner.window == (6 if fused_ok else 0)      # S = 6 sweeps -> one window of 6 per round
+    assert getattr(eng_a, "planned_plain", 0) == (0 if fused_ok else 1)
+
+
+def test_fused_window_choice():
+    P = load_product()
+    fw = P.engine.fused_window
+    assert fw(10) == 10 and fw(100) == 50 and fw(64) == 64 and fw(97) == 0 and fw(2) == 0 and fw(128) == 64 and fw(9) == 9
