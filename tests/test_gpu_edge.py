@@ -119,3 +119,35 @@ def test_size_limits(product):
             eng.sweep_philox(1, 4, beta=0.7, precision="f64")
     with pytest.raises(NotImplementedError):
         product.Engine(sp.identity(n + 1, format="csr") * 0.0 + sp.eye(n + 1, k=1) + sp.eye(n + 1, k=-1), np.zeros(n + 1), 1)
+
+
+def test_new_entry_points_degenerate_inputs(product):
+    """Fused plan, device backbone inference and the ladder pairing on degenerate inputs: zero windows, a dense graph
+    (schedule deeper than the fused level table -> declined, plain path still right), a graph without edges (the
+    reference's convergence ratio is 0/0 there: every lambda runs out of iterations -> ValueError), one sub-replica per
+    temperature (no pairs), no backbone seeds (no clusters)."""
+    SEED = 5
+    J, h = make_instance(600, seed=1)
+    with product.Engine(J, h, 2) as eng:
+        assert eng.plan_philox_fused(0, 0, 10, SEED) == 0
+        eng.set_spins(init_spins(2, 600))
+        eng.pt_init(np.array([0.5, 1.0]))                         # K = 1 ladder of 2 slots: nothing to pair
+        before = eng.get_spins()
+        info = eng.icm_round_ladders(0, SEED, True, want_info=True)
+        assert info.shape == (0, 2) and np.array_equal(eng.get_spins(), before)
+    # dense 300-spin graph: ~300 levels per sweep, 10 sweeps do not fit the 1024-entry fused level table
+    rng = np.random.default_rng(0)
+    A = rng.normal(size=(300, 300)); A = (A + A.T) / 2; np.fill_diagonal(A, 0.0)
+    with product.Engine(A, np.zeros(300), 2) as eng:
+        assert eng.plan_philox_fused(0, 2, 10, SEED) == 0         # declined, not an error
+    check_philox(product, sp.csr_matrix(A), np.zeros(300), R=2, S=3)
+    # no edges at all
+    n = 40
+    inst = product.Instance(sp.csr_matrix((n, n)), np.linspace(-1, 1, n))
+    graph = product.lbp.EdgeGraph(inst)
+    with product.Engine(inst, None, 1) as eng:
+        with pytest.raises(ValueError, match="LBP diverged at initial lambda"):
+            product.lbp.lbp_convexified_device(eng, graph, 0.5, 0.01, 0.9, np.ones((1, n)), graph.epsilon(inst.h),
+                                               np.finfo(float).eps, 20, 0.999999, 0.99999, 2.5)
+    assert product.lbp.find_clusters(graph, np.zeros(n), 0.999999, 0.99999, 0.01) == []
+    assert product.lbp.find_clusters(graph, np.zeros(n), 0.999999, 0.99999, 0.01, flat=True).size == 0
