@@ -66,6 +66,9 @@ int nlmc_set_flags(nlmc_ctx *ctx, const uint8_t *flags, double temp_x);
 int nlmc_energy(nlmc_ctx *ctx, double *out /*[n_chains]*/);
 /* Same, result left in device memory (for an RCCL all-gather issued by the caller). */
 int nlmc_energy_dev(nlmc_ctx *ctx, double *dev_out /*[n_chains], device pointer*/);
+/* Persistent variant: every later sweep call also stores the tracked energies of its final states there (the send
+ * buffer of the per-round all-gather, NPT/npt.py:657-658 energies) -- no extra launch.  NULL switches it off. */
+int nlmc_set_energy_sink(nlmc_ctx *ctx, double *dev_out /*[n_chains], device pointer or NULL*/);
 
 /* log2 of the fixed-point scale of the incrementally tracked energies (E_tracked = integer * 2^-scale). */
 int nlmc_energy_scale(const nlmc_ctx *ctx);

@@ -42,6 +42,7 @@ struct nlmc_ctx {
     int64_t nnz = 0;
     int n_chains = 0, chain_base = 0, n_chains_global = 0;
     int escale = 32;
+    double *energy_sink = nullptr;     // device buffer the sweep kernels also write the tracked energies to
     double temp_x = 1.0;
     bool has_flags = false;
     bool has_diag = false;
@@ -323,6 +324,7 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
     a.tab = tab_dev; a.tab_cs = tab_cs; a.tab_ss = 0;
     a.slot_of_chain = use_slots ? c->slot_of_chain.p : nullptr;
     a.efix = c->efix.p;
+    a.energy_sink = c->energy_sink;
     a.escale = c->escale;
     a.trace_sweeps = T;
     a.rec_stride = 1;
@@ -470,6 +472,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         a.slot_of_chain = use_slots ? c->slot_of_chain.p : nullptr;
         a.ustream = ustream_dev;
         a.efix = c->efix.p;
+        a.energy_sink = c->energy_sink;
         a.escale = c->escale;
         a.etrace = o.out_energy ? c->etrace.p : nullptr;
         a.trace_sweeps = n_sweeps;
@@ -776,6 +779,13 @@ int nlmc_energy_dev(nlmc_ctx *c, double *dev_out)
     hipLaunchKernelGGL(k_efix_to_double, dim3((c->n_chains + 255) / 256), dim3(256), 0, c->stream, c->efix.p, dev_out,
                        c->n_chains, c->escale);
     HIP_TRY(c, hipGetLastError());
+    return NLMC_OK;
+}
+
+int nlmc_set_energy_sink(nlmc_ctx *c, double *dev_out)
+{
+    if (!c) return NLMC_ERR_ARG;
+    c->energy_sink = dev_out;
     return NLMC_OK;
 }
 

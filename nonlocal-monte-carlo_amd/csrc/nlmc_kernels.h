@@ -463,6 +463,7 @@ struct SweepArgs {
     const double *ustream;    // [n_chains*n_sweeps][n] uniform to be consumed by spin k
     // energies
     long long *efix;          // [n_chains] in/out
+    double *energy_sink;      // [n_chains] or nullptr: tracked energy as a double, written with the final state
     int escale;
     long long *etrace;        // [n_chains][trace_sweeps] or nullptr
     int trace_sweeps, t0;     // sweeps of the whole call / index of this launch's first sweep inside the call
@@ -570,6 +571,7 @@ __device__ __forceinline__ void chain_store(const SweepArgs &a, ChainCtx &x)
     for (int i = x.tid; i < x.n_pad / 16; i += x.nt) dst[i] = src[i];
     if (x.tid == 0) {
         a.efix[x.c] = x.E;
+        if (a.energy_sink) a.energy_sink[x.c] = (double)x.E * __longlong_as_double((long long)(1023 - a.escale) << 52);
         if (a.emin) { a.emin[x.c] = x.Emin; a.argmin[x.c] = x.amin; }
     }
 }

@@ -45,6 +45,10 @@ class ShardedTempering:
         if self.collective:
             self.e_local = torch.empty(self.count, dtype=torch.float64, device=device)
             self.e_all = torch.empty(self.G, dtype=torch.float64, device=device)
+            # the sweep kernels write their chains' energies straight into the all-gather's send buffer
+            self._sink = hasattr(self.eng, "set_energy_sink")
+            if self._sink:
+                self.eng.set_energy_sink(self.e_local.data_ptr())
 
     def set_spins(self, spins_global):
         self.eng.set_spins(np.asarray(spins_global)[self.base:self.base + self.count])
@@ -75,7 +79,8 @@ class ShardedTempering:
         log = None
         if self.n_pairs > 0:
             if self.collective:
-                self.eng.energy_dev(self.e_local.data_ptr())           # tracked energies -> device/host buffer
+                if not self._sink or n_sweeps == 0:
+                    self.eng.energy_dev(self.e_local.data_ptr())       # tracked energies -> device/host buffer
                 self.dist.all_gather_into_tensor(self.e_all, self.e_local)   # the ONE collective of the round
                 log = self.eng.pt_swap_philox(self.rounds_done, self.seed, self.n_pairs,
                                               energies_all_dev=self.e_all.data_ptr(), want_log=want_log)

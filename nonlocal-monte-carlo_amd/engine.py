@@ -114,6 +114,10 @@ class Engine:
         self._ck(self._L.nlmc_energy(self._ctx, _abi.ptr(out)))
         return out
 
+    def set_energy_sink(self, dev_ptr):
+        """Later sweep calls also write the tracked energies of their final states to this device buffer (None: off)."""
+        self._ck(self._L.nlmc_set_energy_sink(self._ctx, ctypes.c_void_p(int(dev_ptr)) if dev_ptr else None))
+
     def energy_dev(self, dev_ptr):
         self._ck(self._L.nlmc_energy_dev(self._ctx, ctypes.c_void_p(int(dev_ptr))))
 

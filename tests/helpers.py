@@ -67,5 +67,11 @@ class DeviceBuffer:
         assert self._hip.hipMalloc(ctypes.byref(self.ptr), ctypes.c_size_t(a.nbytes)) == 0
         assert self._hip.hipMemcpy(self.ptr, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(a.nbytes), 1) == 0   # H2D
 
+    def read(self, count):
+        out = np.empty(count, dtype=np.float64)
+        assert self._hip.hipDeviceSynchronize() == 0
+        assert self._hip.hipMemcpy(out.ctypes.data_as(self._ct.c_void_p), self.ptr, self._ct.c_size_t(out.nbytes), 2) == 0  # D2H
+        return out
+
     def free(self):
         self._hip.hipFree(self.ptr)

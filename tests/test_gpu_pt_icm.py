@@ -169,3 +169,27 @@ def test_icm_round_ladders_pairing_and_moves(product):
             p += 1
     assert np.array_equal(got, exp)
     assert np.allclose(E, [oracle.energy(csr, h, s) for s in got], rtol=0, atol=1e-9)
+
+
+def test_energy_sink_is_written_by_the_sweep_kernels(product):
+    """nlmc_set_energy_sink: the buffer the sharded driver all-gathers from holds the tracked energies after every sweep
+    call (plain and fused path), without a separate conversion launch."""
+    from helpers import DeviceBuffer
+    N, R, T = 2048, 6, 5
+    J, h = make_instance(N, seed=4)
+    with product.Engine(J, h, R) as eng:
+        eng.set_spins(init_spins(R, N))
+        eng.pt_init(np.geomspace(0.2, 2.0, R))
+        buf = DeviceBuffer(np.zeros(R))
+        eng.set_energy_sink(buf.ptr.value)
+        eng.sweep_philox(T, 9, sweep0=0, beta=None)                       # plain path
+        assert np.array_equal(buf.read(R), eng.energy())
+        assert eng.plan_philox_fused(T, 1, T, 9) == 1
+        eng.sweep_philox(T, 9, sweep0=T, beta=None)                       # fused window
+        assert eng.last_schedule_stats()["orders"] == T
+        assert np.array_equal(buf.read(R), eng.energy())
+        eng.set_energy_sink(None)
+        before = buf.read(R)
+        eng.sweep_philox(T, 9, sweep0=2 * T, beta=None)
+        assert np.array_equal(buf.read(R), before)                        # switched off
+        buf.free()
