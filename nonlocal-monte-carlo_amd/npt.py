@@ -280,8 +280,15 @@ class NPT(Common):
                 for c in range(R):                       # restart 0 is the one returned in the reference's shape
                     r = int(slots_last[c])
                     M[r * N:(r + 1) * N, :] = last[c].T
-                for r in range(R):
-                    Energy[r] = self.replica_energy(M[r * N:(r + 1) * N, :], self.num_sweeps_read_per_swap)[0]
+                # replica_energy (NPT/npt.py:31-45, :685-692) of every replica: min over the FIRST R_swap columns --
+                # one batched energy call instead of one per replica
+                k = self.num_sweeps_read_per_swap
+                if k > 0:
+                    E_cols = eng.energy_of(np.ascontiguousarray(last[:R, :k]).reshape(R * k, N)).reshape(R, k)
+                    Energy[slots_last[:R]] = E_cols.min(axis=1)
+                else:
+                    for r in range(R):
+                        Energy[r] = self.replica_energy(M[r * N:(r + 1) * N, :], k)[0]     # np.min of nothing: ValueError
             self.swap_pairs = (np.concatenate([p[0] for p in pairs_log]) + 1) if pairs_log else np.zeros((0, 2), np.int32)
             self.swap_accepted = np.concatenate([a[0] for a in acc_log]).astype(np.int8) if acc_log else np.zeros(0, np.int8)
             self.final_slots = eng.pt_slots()
