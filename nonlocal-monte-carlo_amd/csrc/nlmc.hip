@@ -576,6 +576,8 @@ void rows_to_host_finish(nlmc_ctx *c, void *dst_host, int rows)
 
 extern "C" {
 
+static int ensure_adjacency(nlmc_ctx *c);
+
 int nlmc_abi_version(void) { return 1; }
 
 int nlmc_device_count(void)
@@ -942,12 +944,7 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     const size_t W = (size_t)n_windows, TN = (size_t)T * n;
     HIP_TRY(c, c->fz_glv.reserve(W * TN));
     HIP_TRY(c, c->fz_perm.reserve(W * TN));
-    if (!c->fz_adj_ready) {
-        HIP_TRY(c, c->fz_adj.reserve((size_t)n * NLMC_FZ_ADJ));
-        hipLaunchKernelGGL(k_fused_adjacency, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->rowptr.p, c->col.p, c->fz_adj.p);
-        HIP_TRY(c, hipGetLastError());
-        c->fz_adj_ready = true;
-    }
+    { int rc = ensure_adjacency(c); if (rc) return rc; }
     HIP_TRY(c, c->fz_head.reserve(W * TN));
     HIP_TRY(c, c->fz_ell.reserve(W * TN * NLMC_ELL_W32));
     HIP_TRY(c, c->fz_loff.reserve(W * (NLMC_LCAP + 1)));
@@ -1193,13 +1190,28 @@ int nlmc_pt_swap_philox(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs,
 // ---------------------------------------------------------------------------------------------------
 // iso-cluster move
 // ---------------------------------------------------------------------------------------------------
+// 16-bit neighbour table shared by k_levelize_fused and k_icm_components (built once per context)
+static int ensure_adjacency(nlmc_ctx *c)
+{
+    if (c->fz_adj_ready) return NLMC_OK;
+    HIP_TRY(c, c->fz_adj.reserve((size_t)c->n * NLMC_FZ_ADJ));
+    hipLaunchKernelGGL(k_fused_adjacency, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->n, c->rowptr.p, c->col.p, c->fz_adj.p);
+    HIP_TRY(c, hipGetLastError());
+    c->fz_adj_ready = true;
+    return NLMC_OK;
+}
+
 static int icm_launch_components(nlmc_ctx *c, const int32_t *pairs_dev, int n_pairs)
 {
     HIP_TRY(c, c->icm_label.reserve((size_t)n_pairs * c->n));
     HIP_TRY(c, c->icm_info.reserve((size_t)n_pairs * 2));
     IcmArgs a{};
     a.g = c->g; a.spins = c->spins.p; a.pairs = pairs_dev; a.label = c->icm_label.p; a.info = c->icm_info.p;
-    a.has_zero_vals = c->has_zero_vals ? 1 : 0;
+    if (!c->has_zero_vals && c->n <= 65535) {
+        int rc = ensure_adjacency(c);
+        if (rc) return rc;
+        a.adj = reinterpret_cast<const uint4 *>(c->fz_adj.p);
+    }
     const size_t lds = (size_t)c->n * 4 + (((size_t)c->n + 1) & ~(size_t)1) * 2 + 16;
     { int rc = ensure_lds(c, 1, reinterpret_cast<const void *>(k_icm_components), lds); if (rc) return rc; }
     hipLaunchKernelGGL(k_icm_components, dim3(n_pairs), dim3(c->n >= 4096 ? 1024 : 256), lds, c->stream, a);

@@ -151,7 +151,8 @@ struct IcmArgs {
     const int32_t *pairs;     // [n_pairs][2] local chain ids
     int32_t *label;           // [n_pairs][n]  min member index of the component, or INT_MAX if the spins agree
     int32_t *info;            // [n_pairs][2]  {n_components, picked size}
-    int has_zero_vals;        // some stored entry of J is 0 (or underflows in fp32): test values like the reference does
+    const uint4 *adj;         // 16-bit adjacency table [n][2] (k_fused_adjacency) or nullptr: use the CSR entries and
+                              // test `val != 0` like the reference (needed when a stored coupling is 0)
 };
 
 // Connected components of the sub-graph induced by {k : s_a[k] s_b[k] = -1} (NPT/apt_ICM.py:116-143): union-find in
@@ -185,29 +186,41 @@ __global__ void k_icm_components(IcmArgs a)
     }
     __syncthreads();
     const int nc = ncand;
-    // Hook rounds over the candidates only; the first 8 entries of a row are fetched as independent loads before the
-    // dependent find/hook chain starts (the arrays are padded, entries past the row end are ignored).
+    // Hook rounds over the candidates only.  Neighbour lists come from the 16-bit adjacency table (two 16-byte loads
+    // per spin, absent slots hold the spin itself) when every stored coupling is non-zero -- the common case --
+    // otherwise from the CSR entries with the reference's `val != 0` test (NPT/apt_ICM.py:129).
     for (int it = 0; it <= n; ++it) {
         int changed = 0;
         for (int idx = tid; idx < nc; idx += nt) {
             const int k = (int)cand[idx];
-            const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
-            EdgeF ed[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) ed[q] = a.g.edge32[rs + q];
-            int rk = icm_find(lab, k);
-            auto hook = [&](int j, bool nz) {
-                if (!nz || lab[j] == INT_MAX) return;
+            int rk;
+            auto hook = [&](int j) {
+                if (j == k || lab[j] == INT_MAX) return;
                 const int rj = icm_find(lab, j);
                 if (rj < rk) { atomicMin(&lab[rk], rj); rk = rj; changed = 1; }
                 else if (rk < rj) { atomicMin(&lab[rj], rk); changed = 1; }
             };
+            if (a.adj) {
+                const uint4 a0 = a.adj[2 * k], a1 = a.adj[2 * k + 1];
+                const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
+                rk = icm_find(lab, k);
+                const uint32_t aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (q < deg) hook(ed[q].col, !a.has_zero_vals || ed[q].val != 0.0f || a.g.val64[rs + q] != 0.0);   // `val != 0`, NPT/apt_ICM.py:129
-            for (int e = rs + 8; e < rs + deg; ++e) {
-                const EdgeF t = a.g.edge32[e];
-                hook(t.col, !a.has_zero_vals || t.val != 0.0f || a.g.val64[e] != 0.0);
+                for (int q = 0; q < NLMC_FZ_ADJ; ++q) hook((int)((aw[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu));
+                for (int e = rs + NLMC_FZ_ADJ; e < rs + deg; ++e) hook(a.g.col[e]);
+            } else {
+                const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
+                EdgeF ed[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ed[q] = a.g.edge32[rs + q];
+                rk = icm_find(lab, k);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q < deg && (ed[q].val != 0.0f || a.g.val64[rs + q] != 0.0)) hook(ed[q].col);
+                for (int e = rs + 8; e < rs + deg; ++e) {
+                    const EdgeF t = a.g.edge32[e];
+                    if (t.val != 0.0f || a.g.val64[e] != 0.0) hook(t.col);
+                }
             }
         }
         if (!__syncthreads_or(changed)) break;
