@@ -225,3 +225,42 @@ def test_c4_size_fused_windows_oracle_sample_and_energy(product):
     assert np.array_equal(a[1], a[3])                                        # energies consistent after swaps too
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4])
     assert not np.array_equal(a[4], np.arange(R))                            # swaps happened
+
+
+def test_c5_size_icm_rounds_properties(product):
+    """C5 (APT + iso-cluster moves) at full size -- N = 10^4, 32 temperatures x 8 sub-replicas = 256 chains, rounds of
+    10 sweeps + device-paired Houdayer step + swaps -- through properties that need no full oracle run: a Houdayer
+    exchange conserves the SUM of the two energies of a pair (checked on the whole batch: total energy before == after
+    for rounds where no Katzgraber flip fired -- with h = 0 a global flip conserves it too); tracked == recomputed
+    energies; spins stay +-1; every chain keeps exactly one temperature slot per ladder; same seed -> same bits."""
+    N, R, K, T, ROUNDS, SEED = 10_000, 32, 8, 10, 3, 77
+    J, h = make_instance(N)
+    G = R * K
+    m0 = init_spins(G, N)
+
+    def run():
+        with product.Engine(J, h, G) as eng:
+            eng.set_spins(m0)
+            eng.pt_init(np.geomspace(0.05, 4.0, R))
+            pl = product.engine.RoundPlanner(eng, 0, ROUNDS, T, SEED)
+            eng.pt_plan(0, ROUNDS, SEED, 10)
+            sums = []
+            for r in range(ROUNDS):
+                pl.sweep(r)
+                e_before = eng.energy()
+                info = eng.icm_round_ladders(r, SEED, True, want_info=True)
+                e_after = eng.energy()
+                sums.append((e_before.sum(), e_after.sum(), int((info[:, 1] > 0).sum())))
+                eng.pt_swap_philox(r, SEED, 10, want_log=False)
+            spins = eng.get_spins()
+            return spins, eng.energy(), eng.energy_of(spins), eng.pt_slots(), sums
+
+    s1, tracked, exact, slots, sums = run()
+    s2, _, _, slots2, _ = run()
+    assert np.array_equal(s1, s2) and np.array_equal(slots, slots2)
+    assert set(np.unique(s1)) == {-1, 1}
+    assert np.array_equal(tracked, exact)
+    for before, after, moved in sums:
+        assert before == after and moved > 0           # +-J, h = 0: integer energies, the pair sums are conserved exactly
+    for j in range(K):
+        assert sorted(slots[j * R:(j + 1) * R]) == list(range(R))
