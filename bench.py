@@ -1,27 +1,38 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the sweep + replica-exchange path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--strong]
 
-A "step" is one replica-exchange round of NPT: S_SWAP heat-bath sweeps of every replica at its ladder temperature
-followed by one swap-attempt round.  Workload (SURVEY.md section 8d, config C4 on one GPU): synthetic +-J spin glass,
-N = 10^4 spins, exactly 3N edges (mean degree 6), h = 0; 256 replicas PER GPU on a geometric beta ladder 0.05 -> 4
-that spans all GPUs (256*N_gpus slots); 10 sweeps per round; round(0.3 * replicas) swap pairs per round.  Weak
-scaling: per-GPU work is fixed; the only collective is one all-gather of 256 float64 energies per rank and round.
-Inputs (instance, replica states, level schedules) are resident in HBM before the timed region starts.
+With N > 1 and no torch.distributed environment this script starts `python -m torch.distributed.run --nproc-per-node N
+bench.py ...` itself as a CHILD process (before anything touches the GPU) and exits with the child's code; launched by
+torch.distributed.run it is one rank per GPU over RCCL.
 
-Prints ONE JSON line (rank 0).  `value` = spin-updates/s of the whole job; `roofline` prices the dominant kernel
-(k_sweep_fused) with HIP events recorded on the stream it runs on; `cpu_baseline` times the oracle (a C port of the
-same algorithm, one thread) on a bounded sample of the same workload; `cpu_baseline_numpy_path` times the
-reference's own NumPy loop structure (restated in oracle/numpy_path.py, pinned to a golden) the same way.
+A "step" is ROUNDS_PER_STEP = 16 replica-exchange rounds of NPT; a round is S_SWAP = 10 heat-bath sweeps of every
+replica at its ladder temperature followed by one swap-attempt round.  Workload (SURVEY.md section 8d, config C4 on
+one GPU): synthetic +-J spin glass, N = 10^4 spins, exactly 3N edges (mean degree 6), h = 0; 256 replicas PER GPU on a
+geometric beta ladder 0.05 -> 4 that spans all GPUs (256*N_gpus slots; --strong: 256 replicas in total, 256/N per
+GPU); round(0.3 * replicas) swap pairs per round.  The only collective is one all-gather of the local float64 energies
+per rank and round.
+
+EVERYTHING a round needs is inside the timed region: the per-sweep visiting orders and their level schedules
+(k_levelize_fused -- the reference draws its permutation inside the sweep loop, NMC/nmc.py:62-71) and the pair
+selections (k_pt_select) are built chunk by chunk (256 rounds) by the round that first needs them, after t0.  Only
+the instance, the replica states and the ladder are resident in HBM before the timed region starts.
+
+Prints ONE JSON line (rank 0).  `value` = end-to-end spin-updates/s of the whole job; `value_kernel_loop` = the same
+updates over the summed durations of the sweep kernel alone; `roofline` prices the dominant kernel with HIP events
+recorded on the stream it runs on; `cpu_baseline` times the oracle (a C port of the same algorithm, one thread) on a
+bounded sample of the same workload; `cpu_baseline_numpy_path` times the reference's own NumPy loop structure
+(restated in oracle/numpy_path.py, pinned to a golden) the same way; `f64_field` is a short second leg of the same
+workload with the fp64 field sum of the parity mode (91 algorithmic bytes per update).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
@@ -30,20 +41,35 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 N_SPINS = 10_000
 REPLICAS_PER_GPU = 256
 S_SWAP = 10
+ROUNDS_PER_STEP = 16
+PLAN_CHUNK_ROUNDS = 256      # rounds whose schedules are built together (one workgroup per window: fills the chip)
 BETA_MIN, BETA_MAX = 0.05, 4.0
 INSTANCE_SEED = 20250225
 PHILOX_SEED = 0xA5A50000
-BYTES_PER_UPDATE = 63        # 9*d + 9 at d = 6 (fp32 J, int32 col, int8 spins)
+BYTES_PER_UPDATE = 63        # 9*d + 9 at d = 6 (4-byte J, int32 col, int8 spins)
+BYTES_PER_UPDATE_F64 = 91    # 13*d + 13: fp64 J (parity-grade field sum)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
-# HBM bytes per k_sweep_fused launch of THIS workload from the PMC passes committed in
-# profiles/r01_f_sweep_hbm_traffic_pmc.csv: (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 read correction applied).
-# It is the touched part of the level schedule fetched once per XCD (plus the warm-up touch of the next window's) and the
-# spin write-back; PMC cannot be read live.
-HBM_TRAFFIC_BYTES_PER_LAUNCH = 85_637_031
+L2_PEAK_GBS = 34500.0        # MI355X_MICROARCH.md, L2 (per XCD): ~34.5 TB/s aggregate
+VALU_LANES_PER_CU_CLK = 128  # 4 SIMD-32 per CU, one wave64 instruction per 2 cycles per SIMD (MI355X_MICROARCH.md)
+CLOCK_GHZ = 2.4
+N_CUS = 256
+SCHEDULE_BYTES_PER_UPDATE = 72   # what the sweep kernel reads per update from L2: item head 8 B + row window 64 B
+
+
+def load_pmc():
+    """Per-launch PMC figures of the sweep kernel on THIS workload (collected by scripts/profile_round.sh in separate
+    --pmc passes, committed under profiles/; PMC cannot be read live).  Returns {} when the file is absent."""
+    path = os.path.join(REPO, "profiles", "current_sweep_pmc.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except OSError:
+        return {}
 
 
 def cpu_baseline(J, h, seconds=12.0):
     """oracle/nlo.c (kind "port"): sequential C restatement of the same philox-mode sweep, one chain, one thread."""
+    import numpy as np
     import oracle
     csr = oracle.Csr(J)
     s = np.where(np.random.default_rng(1000).random(csr.n) < 0.5, -1, 1).astype(np.int8)
@@ -67,6 +93,7 @@ def numpy_path_baseline(J, h, seconds=10.0):
     """oracle/numpy_path.py (kind "port"): the reference's own per-update work (state tuple + full sparse mat-vec +
     NumPy call overhead per SPIN update, NMC/nmc.py:70-88) restated, one process; the reference itself cannot travel to
     this box.  Bounded: whole sweeps until `seconds` are used (one sweep of 10^4 spins costs ~5 s)."""
+    import numpy as np
     from oracle.numpy_path import mcmc_numpy_path
     n = J.shape[0]
     np.random.seed(7)
@@ -81,14 +108,39 @@ def numpy_path_baseline(J, h, seconds=10.0):
                       "NumPy loop structure)"}
 
 
+def self_launch(a, argv):
+    """N > 1 without a torch.distributed environment: become the launcher.  Runs BEFORE torch is imported -- nothing
+    in this process has touched the GPU, and the ranks are children (no exec after GPU initialisation)."""
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if a.dry_run_launch:
+        print(json.dumps({"would_run": cmd}))
+        return 0
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=32, help="timed steps; one step = %d swap rounds" % ROUNDS_PER_STEP)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--strong", action="store_true", help="256 replicas in total instead of 256 per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f64-leg", action="store_true")
+    ap.add_argument("--dry-run-launch", action="store_true", help="print the launcher command of --gpus N and exit")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a, sys.argv[1:]))
+
+    import numpy as np
     import torch
     from __graft_entry__ import load
     from helpers import make_instance, init_spins
@@ -98,7 +150,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run (also with one rank)
@@ -108,7 +160,9 @@ def main():
 
     J, h = make_instance(N_SPINS, seed=INSTANCE_SEED)
     inst = P.Instance(J, h)
-    G = REPLICAS_PER_GPU * world
+    G = REPLICAS_PER_GPU if a.strong else REPLICAS_PER_GPU * world
+    if G % world:
+        raise SystemExit(f"{G} replicas do not split evenly over {world} ranks")
     betas = np.geomspace(BETA_MIN, BETA_MAX, G)
     n_pairs = round(0.3 * G)
     stream = torch.cuda.current_stream().cuda_stream
@@ -116,46 +170,61 @@ def main():
     def make_engine(i, n, base, g):
         return P.Engine(i, None, n, device=local_rank, stream=stream, chain_base=base, n_chains_global=g)
 
-    st = P.distributed.ShardedTempering(make_engine, inst, betas, G, PHILOX_SEED, n_pairs, torch=torch, dist=dist,
-                                        device=torch.device("cuda", local_rank))
-    base, count = st.base, st.count
-    st.set_spins(np.concatenate([np.zeros((base, N_SPINS), np.int8), init_spins(count, N_SPINS, base=1000 + base),
-                                 np.zeros((G - base - count, N_SPINS), np.int8)]) if world > 1 else init_spins(G, N_SPINS))
-    total_rounds = a.warmup + a.steps
-    st.plan(total_rounds * S_SWAP, total_rounds)  # level schedules + pair selections: resident before timing starts
-    e_start = st.eng.energy()
-
     def sync():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        st.round(S_SWAP)
-    st.eng.timing_reset(True)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        st.round(S_SWAP)
-    sync()
-    dt = time.perf_counter() - t0
-    tm = st.eng.timing_total()
-    st.eng.timing_reset(False)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    e_end = st.eng.energy()
-    sched = st.eng.last_schedule_stats()
+    def run_leg(precision, steps, warmup):
+        """warmup + steps steps of ROUNDS_PER_STEP rounds; every schedule / pair selection of the timed rounds is built
+        inside the timed region (lazy chunks)."""
+        st = P.distributed.ShardedTempering(make_engine, inst, betas, G, PHILOX_SEED, n_pairs, torch=torch, dist=dist,
+                                            device=torch.device("cuda", local_rank), precision=precision)
+        base, count = st.base, st.count
+        st.set_spins(np.concatenate([np.zeros((base, N_SPINS), np.int8), init_spins(count, N_SPINS, base=1000 + base),
+                                     np.zeros((G - base - count, N_SPINS), np.int8)]) if world > 1 else init_spins(G, N_SPINS))
+        e_start = st.eng.energy()
+        chunk = PLAN_CHUNK_ROUNDS if precision == "f32" else 8
+        wr = warmup * ROUNDS_PER_STEP
+        if wr:
+            st.plan(wr * S_SWAP, wr, chunk_rounds=chunk, lazy=True)
+            for _ in range(wr):
+                st.round(S_SWAP)
+        tr = steps * ROUNDS_PER_STEP
+        st.plan(tr * S_SWAP, tr, chunk_rounds=chunk, lazy=True)     # a fresh, EMPTY planner: nothing is built yet
+        st.eng.timing_reset(True)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(tr):
+            st.round(S_SWAP)
+        sync()
+        dt = time.perf_counter() - t0
+        tm = st.eng.timing_total()
+        st.eng.timing_reset(False)
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        e_end = st.eng.energy()
+        sched = st.eng.last_schedule_stats()
+        chunks = st._planner.chunks_planned if getattr(st, "_planner", None) is not None else 0
+        st.close()
+        return {"dt": dt, "tm": tm, "rounds": tr, "count": count, "e_start": e_start, "e_end": e_end, "sched": sched,
+                "chunks": chunks}
+
+    r = run_leg("f32", a.steps, a.warmup)
 
     if rank == 0:
-        updates = float(G) * N_SPINS * S_SWAP * a.steps
+        dt, tm, tr, count = r["dt"], r["tm"], r["rounds"], r["count"]
+        updates = float(G) * N_SPINS * S_SWAP * tr
         upd_launch = float(count) * N_SPINS * S_SWAP
         ms_launch = tm["ms_sweep"] / max(1, tm["launches_sweep"])
-        achieved = upd_launch * BYTES_PER_UPDATE / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0
+        sec_launch = ms_launch * 1e-3
+        achieved = upd_launch * BYTES_PER_UPDATE / sec_launch / 1e9 if ms_launch > 0 else 0.0
+        pmc = load_pmc() if (world == 1 and count == REPLICAS_PER_GPU) else {}
         out = {
-            "metric": "spin-updates/s (replicas x spins x sweeps / s), NPT sweep + swap rounds",
+            "metric": "spin-updates/s (replicas x spins x sweeps / s), NPT sweep + swap rounds, schedule construction included",
             "value": updates / dt,
             "unit": "spin-updates/s",
             "n_gpus": world,
@@ -163,35 +232,67 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if a.strong else "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "i32 field (24-bit fixed-point J) + f32 acceptance test",
             "data": "synthetic",
             "config": {"workload": "NPT heat-bath sweeps + replica exchange, sparse +-J spin glass (C4 per GPU)",
-                       "spins": N_SPINS, "edges": 3 * N_SPINS, "replicas_per_gpu": REPLICAS_PER_GPU,
-                       "replicas_total": G, "sweeps_per_round": S_SWAP, "swap_pairs_per_round": n_pairs,
-                       "beta_ladder": [BETA_MIN, BETA_MAX], "rng": "philox4x32-10", "order": "one permutation per sweep"},
+                       "spins": N_SPINS, "edges": 3 * N_SPINS, "replicas_per_gpu": count,
+                       "replicas_total": G, "sweeps_per_round": S_SWAP, "rounds_per_step": ROUNDS_PER_STEP,
+                       "swap_pairs_per_round": n_pairs, "beta_ladder": [BETA_MIN, BETA_MAX], "rng": "philox4x32-10",
+                       "order": "one permutation per sweep", "plan_chunk_rounds": PLAN_CHUNK_ROUNDS},
+            "plan_in_timed_region": True,
+            "plan_chunks_in_timed_region": r["chunks"],
+            "rounds_timed": tr,
+            "ms_per_round": dt / tr * 1e3,
+            "value_kernel_loop": (upd_launch * tm["launches_sweep"] / (tm["ms_sweep"] * 1e-3)) * world if tm["ms_sweep"] > 0 else None,
+            "ms_levelize": tm["ms_levelize"],
+            "ms_sweep_kernels": tm["ms_sweep"],
+            "sweep_launches": tm["launches_sweep"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": HBM_TRAFFIC_BYTES_PER_LAUNCH if (world == 1 and count == REPLICAS_PER_GPU) else None,
-                         "traffic_source": "profiles/r01_f_sweep_hbm_traffic_pmc.csv",
+                         "traffic": pmc.get("hbm_bytes_per_launch"),
+                         "traffic_source": pmc.get("source"),
                          "algorithmic_bytes_per_launch": upd_launch * BYTES_PER_UPDATE,
                          "kernel": "k_sweep_fused<false>", "us_per_launch": ms_launch * 1e3,
                          "bytes_per_update": BYTES_PER_UPDATE, "updates_per_launch": upd_launch,
-                         "note": "algorithmic bytes (SURVEY 8d: 63 B per update, no discount for rows shared by chains); "
-                                 "spins live in LDS and one level schedule serves all 256 chains, so HBM carries ~5 % of "
-                                 "that (traffic) and frac can exceed 1 -- the kernel is bound by VALU issue and per-level "
-                                 "latency, see DESIGN.md section 5"},
-            "levels_per_sweep": sched["levels"] / max(1, sched["orders"]),
-            "min_energy": {"start": float(e_start.min()), "end": float(e_end.min())},
+                         "note": "SURVEY 8d algorithmic bytes (63 B per update, no discount for rows shared by chains). "
+                                 "This design keeps spins in LDS and shares one level schedule between all chains of a "
+                                 "launch, so HBM carries only `traffic`; the bounds that bind are roofline_l2 and "
+                                 "roofline_issue below (DESIGN.md section 5)"},
+            # every workgroup (= chain = CU) streams the whole window schedule through its L1 from its XCD's L2
+            "roofline_l2": {"bound": "l2", "unit": "GB/s", "peak": L2_PEAK_GBS,
+                            "achieved": upd_launch * SCHEDULE_BYTES_PER_UPDATE / sec_launch / 1e9 if ms_launch > 0 else 0.0,
+                            "frac": upd_launch * SCHEDULE_BYTES_PER_UPDATE / sec_launch / 1e9 / L2_PEAK_GBS if ms_launch > 0 else 0.0,
+                            "bytes_per_update": SCHEDULE_BYTES_PER_UPDATE},
+            "levels_per_sweep": r["sched"]["levels"] / max(1, r["sched"]["orders"]),
+            "min_energy": {"start": float(r["e_start"].min()), "end": float(r["e_end"].min())},
         }
+        if pmc.get("valu_wave_insts_per_launch") and ms_launch > 0:
+            lane_insts = pmc["valu_wave_insts_per_launch"] * 64.0
+            t_issue = lane_insts / (N_CUS * VALU_LANES_PER_CU_CLK * CLOCK_GHZ * 1e9)
+            out["roofline_issue"] = {"bound": "valu-issue", "unit": "lane-instructions/s",
+                                     "peak": N_CUS * VALU_LANES_PER_CU_CLK * CLOCK_GHZ * 1e9,
+                                     "achieved": lane_insts / sec_launch, "frac": t_issue / sec_launch,
+                                     "valu_lane_insts_per_update": lane_insts / upd_launch,
+                                     "lds_bank_conflict_frac": pmc.get("lds_bank_conflict_frac"),
+                                     "wait_any_frac": pmc.get("wait_any_frac"), "source": pmc.get("source")}
+        if world == 1 and not a.no_f64_leg:
+            f = run_leg("f64", 1, 0)
+            ms64 = f["tm"]["ms_sweep"] / max(1, f["tm"]["launches_sweep"])
+            upd64 = float(f["count"]) * N_SPINS * S_SWAP * f["rounds"]
+            out["f64_field"] = {"value": upd64 / f["dt"], "unit": "spin-updates/s", "rounds_timed": f["rounds"],
+                                "dtype": "f64", "bytes_per_update": BYTES_PER_UPDATE_F64,
+                                "kernel": "k_sweep_philox<double>", "ms_sweep_kernels": f["tm"]["ms_sweep"],
+                                "ms_levelize": f["tm"]["ms_levelize"],
+                                "roofline_frac_hbm": upd64 * BYTES_PER_UPDATE_F64 / (f["tm"]["ms_sweep"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                if f["tm"]["ms_sweep"] > 0 else None}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(J, h)
             out["cpu_baseline_numpy_path"] = numpy_path_baseline(J, h)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    st.close()
     if dist is not None:
         dist.destroy_process_group()
 

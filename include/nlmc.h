@@ -31,7 +31,12 @@ enum {
     NLMC_ERR_STATE = -4        /* call order violated (e.g. PT call before nlmc_pt_init) */
 };
 
-enum { NLMC_F32 = 0, NLMC_F64 = 1 };                 /* arithmetic of the local field in philox mode */
+/* arithmetic of the local field in philox mode.  NLMC_F32 (4-byte couplings): J and h are held in 24-bit fixed point,
+ * Jq = rint(J 2^qs) (nlmc_field_scale), the field is an exact int32 sum and the acceptance is one f32 compare with a
+ * logistic threshold drawn from 32 random bits -- the chain samples the Boltzmann law of (Jq, hq) 2^-qs exactly, with
+ * |Jq 2^-qs - J| <= 2^-(qs+1) (nothing is lost for +-J / integer instances).  NLMC_F64: fp64 field in the reference's
+ * summation order (NMC/nmc.py:86), base-2 logistic test on a 53-bit uniform. */
+enum { NLMC_F32 = 0, NLMC_F64 = 1 };
 enum { NLMC_ORDER_SHARED = 0, NLMC_ORDER_PER_CHAIN = 1 }; /* one permutation per sweep for all chains | per chain */
 
 /* phase flags, one byte per (chain, spin): caller contract of NMC/nmc.py:377-381,398-401 */
@@ -72,6 +77,8 @@ int nlmc_set_energy_sink(nlmc_ctx *ctx, double *dev_out /*[n_chains], device poi
 
 /* log2 of the fixed-point scale of the incrementally tracked energies (E_tracked = integer * 2^-scale). */
 int nlmc_energy_scale(const nlmc_ctx *ctx);
+/* qs of the NLMC_F32 path: couplings are held as rint(J 2^qs), |Jq| < 2^23, row sums < 2^31; qs <= energy scale <= qs+29. */
+int nlmc_field_scale(const nlmc_ctx *ctx);
 
 /* Energies of an arbitrary batch of configurations (trace read-out, NPT/npt.py:685-692). */
 int nlmc_energy_of(nlmc_ctx *ctx, const int8_t *spins /*[count][n]*/, int64_t count, double *out /*[count]*/);
@@ -96,7 +103,7 @@ int nlmc_sweep_stream(nlmc_ctx *ctx, int n_sweeps, const int32_t *perm, const do
 
 /* PHILOX mode (throughput): same Markov kernel, counter-based RNG generated on the device.  Sweep t of the run
  * (global index sweep0 + t) visits spins in ascending order of philox(k, t, group, ORDER) and spin k of chain c
- * draws one word of philox(k>>2, t, c, UNIFORM) (f32; k>>1 and two words in f64); results are a pure function of (seed, global chain id, sweep index, spin) and
+ * draws one word of philox(k>>2, t, c, UNIFORM) (f32: 32 bits -> logistic threshold; k>>1 and two words -> 53-bit uniform in f64); results are a pure function of (seed, global chain id, sweep index, spin) and
  * therefore independent of how chains are sharded over GPUs.
  *   beta : as above, or NULL to take each chain's beta from the PT ladder (nlmc_pt_init). */
 int nlmc_sweep_philox(nlmc_ctx *ctx, int precision, int order_mode, int n_sweeps, uint32_t sweep0, uint64_t seed,
@@ -113,7 +120,7 @@ int nlmc_plan_philox(nlmc_ctx *ctx, int precision, int order_mode, uint32_t swee
  * sweep0, constant beta and no per-sweep outputs (no recorded spins, energies or minima) runs on it; every other call
  * takes the sweep-by-sweep path.  Results are bit-identical either way.  out_planned: number of windows that got a
  * fused schedule (0 when the instance does not qualify: n < 256 or n > 11264,
- * window < 3 or > 64, or the three uniform tables do not fit in LDS next to the spins). */
+ * window < 3 or > 64, or the three threshold tables do not fit in LDS next to the spins). */
 int nlmc_plan_philox_fused(nlmc_ctx *ctx, uint32_t sweep0, int n_windows, int window, uint64_t seed, int32_t *out_planned);
 
 /* Replica exchange (NPT/npt.py:602-683).  Chains are grouped into ladders of ladder_len consecutive global

@@ -21,7 +21,7 @@ MAX_N = 24576
 
 EXPORTS = [
     "nlmc_abi_version", "nlmc_device_count", "nlmc_create", "nlmc_destroy", "nlmc_last_error", "nlmc_set_spins",
-    "nlmc_get_spins", "nlmc_set_flags", "nlmc_energy", "nlmc_energy_dev", "nlmc_set_energy_sink", "nlmc_energy_scale", "nlmc_energy_of", "nlmc_sweep_stream",
+    "nlmc_get_spins", "nlmc_set_flags", "nlmc_energy", "nlmc_energy_dev", "nlmc_set_energy_sink", "nlmc_energy_scale", "nlmc_field_scale", "nlmc_energy_of", "nlmc_sweep_stream",
     "nlmc_sweep_philox", "nlmc_plan_philox", "nlmc_plan_philox_fused", "nlmc_pt_init", "nlmc_pt_get_slots", "nlmc_pt_set_slots",
     "nlmc_pt_apply_swap", "nlmc_pt_swap_philox", "nlmc_pt_plan", "nlmc_icm_components", "nlmc_icm_move", "nlmc_icm_get_labels", "nlmc_icm_round_philox", "nlmc_icm_round_ladders",
     "nlmc_lbp_convexified", "nlmc_find_clusters",
@@ -79,6 +79,8 @@ def lib():
     L.nlmc_set_flags.argtypes = [_vp, _vp, _dbl]
     L.nlmc_energy_scale.restype = _i
     L.nlmc_energy_scale.argtypes = [_vp]
+    L.nlmc_field_scale.restype = _i
+    L.nlmc_field_scale.argtypes = [_vp]
     L.nlmc_energy_of.restype = _i
     L.nlmc_energy_of.argtypes = [_vp, _vp, _i64, _vp]
     L.nlmc_sweep_stream.restype = _i

@@ -42,6 +42,7 @@ struct nlmc_ctx {
     int64_t nnz = 0;
     int n_chains = 0, chain_base = 0, n_chains_global = 0;
     int escale = 32;
+    int qs = 0;                        // field scale of the fixed-point ("f32") path: Jq = rint(J 2^qs)
     double *energy_sink = nullptr;     // device buffer the sweep kernels also write the tracked energies to
     double temp_x = 1.0;
     bool has_flags = false;
@@ -51,8 +52,8 @@ struct nlmc_ctx {
 
     DevBuf<int32_t> rowptr, col;
     DevBuf<double> val64, h64;
-    DevBuf<EdgeF> edge32;
-    DevBuf<float> h32;
+    DevBuf<EdgeQ> edge32;
+    DevBuf<int32_t> hq;
     DevBuf<int8_t> spins, best;
     DevBuf<uint8_t> flags;
     DevBuf<long long> efix, emin, etrace, dbg;
@@ -64,7 +65,7 @@ struct nlmc_ctx {
     struct Sched {            // one set of level-schedule buffers (per-call scratch, or the persistent plan)
         DevBuf<int2> order, head32;
         DevBuf<int32_t> lvl_off, nlev, hi_max, ellc64;
-        DevBuf<EdgeF> ell32;
+        DevBuf<EdgeQ> ell32;
         DevBuf<double> ellv64, headh64;
         hipError_t reserve(size_t orders, size_t n, int mode /*0 none, 1 f32, 2 f64*/)
         {
@@ -106,7 +107,7 @@ struct nlmc_ctx {
     DevBuf<long long> fz_stats;
     bool fz_adj_ready = false;
     DevBuf<int2> fz_head;
-    DevBuf<EdgeF> fz_ell;
+    DevBuf<EdgeQ> fz_ell;
     DevBuf<int32_t> fz_loff, fz_nlev, fz_himax, fz_send;
     // PT
     int ladder_len = 0;
@@ -256,7 +257,7 @@ int fused_workers(int nt)
 {
     const int waves = nt / 64;
     if (waves < 16) return waves - 1;
-    if (const char *s = getenv("NLMC_FUSED_WORKERS")) { const int v = atoi(s); if (v >= 8 && v <= 15) return v; }
+    if (const char *s = getenv("NLMC_FUSED_WORKERS")) { const int v = atoi(s); if (v >= 8 && v <= 16) return v; }
     return 13;
 }
 
@@ -326,11 +327,18 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
     a.efix = c->efix.p;
     a.energy_sink = c->energy_sink;
     a.escale = c->escale;
+    a.eshift = c->escale - c->qs;
+    a.qinv = std::ldexp(1.0f, -c->qs);
     a.trace_sweeps = T;
     a.rec_stride = 1;
     a.argmin = c->argmin.p;
     a.lds_flags_off = L.flags_off; a.lds_u_off = L.u_off; a.lds_u_stride = L.u_bytes; a.lds_loff_off = L.loff_off;
     a.lds_send_off = L.send_off; a.lds_red_off = L.red_off;
+#ifdef NLMC_STAMPS
+    HIP_TRY(c, c->dbg.reserve((size_t)R * 16 * 8 + 96));
+    HIP_TRY(c, hipMemsetAsync(c->dbg.p, 0, ((size_t)R * 16 * 8 + 96) * sizeof(long long), c->stream));
+    a.dbg = c->dbg.p;
+#endif
     const int nt = fused_block(n);
     if (c->has_diag) hipLaunchKernelGGL((k_sweep_fused<true>), dim3(R), dim3(nt), L.total, c->stream, a);
     else hipLaunchKernelGGL((k_sweep_fused<false>), dim3(R), dim3(nt), L.total, c->stream, a);
@@ -474,6 +482,8 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         a.efix = c->efix.p;
         a.energy_sink = c->energy_sink;
         a.escale = c->escale;
+        a.eshift = c->escale - c->qs;
+        a.qinv = std::ldexp(1.0f, -c->qs);
         a.etrace = o.out_energy ? c->etrace.p : nullptr;
         a.trace_sweeps = n_sweeps;
         a.t0 = t0;
@@ -608,7 +618,7 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
         for (int e = rowptr[k]; e < rowptr[k + 1]; ++e) {
             if (colidx[e] < 0 || colidx[e] >= n) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: column index out of range");
             if (colidx[e] == k && vals[e] != 0.0) diag = true;
-            if ((float)vals[e] == 0.0f) zero_vals = true;
+            if (vals[e] == 0.0) zero_vals = true;
         }
     }
     int ndev = 0;
@@ -632,18 +642,46 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
     c->has_zero_vals = zero_vals;
     c->max_deg = max_deg;
 
-    // fixed-point scale: |E| <= sum|J|/2 + sum|h|
-    double bound = 0.0;
-    for (int64_t e = 0; e < nnz; ++e) bound += std::fabs(vals[e]) * 0.5;
-    for (int k = 0; k < n; ++k) bound += std::fabs(h[k]);
+    // fixed-point scales.  Energies: integers in units of 2^-escale, |E| <= sum|J|/2 + sum|h|.  Couplings of the "f32"
+    // throughput path: Jq = rint(J 2^qs), hq = rint(h 2^qs) with qs the largest exponent such that every |Jq| fits a
+    // signed 24-bit multiplier and every row sum  sum|Jq| + |hq|  fits int32 (the field is then an exact int32);
+    // qs <= escale <= qs + 29, so that an energy delta is the field times +-2^(escale - qs + 1) in one 32 x 32 -> 64
+    // bit multiply-add.  (Restated in oracle/nlo.c: nlo_field_scale.)
+    double bound = 0.0, maxabs = 0.0, maxh = 0.0;
+    for (int64_t e = 0; e < nnz; ++e) { bound += std::fabs(vals[e]) * 0.5; maxabs = std::max(maxabs, std::fabs(vals[e])); }
+    for (int k = 0; k < n; ++k) { bound += std::fabs(h[k]); maxh = std::max(maxh, std::fabs(h[k])); }
     int ex = 0;
     std::frexp(std::max(bound, 1.0), &ex);       // bound < 2^ex
-    c->escale = std::max(0, std::min(52, 60 - ex));
+    const int escale0 = std::max(0, std::min(52, 60 - ex));
+    int qs = 0;
+    auto rq = [](double v, int q) { return (int64_t)std::llrint(std::ldexp(v, q)); };
+    const double ref = maxabs > 0.0 ? maxabs : maxh;
+    if (ref > 0.0) {
+        int exr = 0;
+        std::frexp(ref, &exr);
+        qs = std::min(23 - exr, escale0);
+        for (;;) {
+            bool ok = true;
+            for (int k = 0; k < n && ok; ++k) {
+                int64_t row = std::llabs(rq(h[k], qs));
+                for (int e = rowptr[k]; e < rowptr[k + 1]; ++e) {
+                    const int64_t q = std::llabs(rq(vals[e], qs));
+                    if (q > 8388607) ok = false;
+                    row += q;
+                }
+                if (row > 2147483647LL) ok = false;
+            }
+            if (ok) break;
+            --qs;
+        }
+    }
+    c->qs = qs;
+    c->escale = std::min(escale0, qs + 29);
 
-    std::vector<EdgeF> e32((size_t)std::max<int64_t>(nnz, 1));
-    std::vector<float> h32((size_t)n);
-    for (int64_t e = 0; e < nnz; ++e) { e32[e].col = colidx[e]; e32[e].val = (float)vals[e]; }
-    for (int k = 0; k < n; ++k) h32[k] = (float)h[k];
+    std::vector<EdgeQ> e32((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<int32_t> hq((size_t)n);
+    for (int64_t e = 0; e < nnz; ++e) { e32[e].col = colidx[e]; e32[e].q = (int32_t)rq(vals[e], qs); }
+    for (int k = 0; k < n; ++k) hq[k] = (int32_t)rq(h[k], qs);
 
     CT(c->rowptr.reserve((size_t)n + 1));
     // +16 entries of padding: fixed-width row windows are read unconditionally (never used past the row end)
@@ -652,17 +690,17 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
     CT(c->edge32.reserve((size_t)nnz + 16));
     CT(hipMemset(c->col.p, 0, sizeof(int32_t) * ((size_t)nnz + 16)));
     CT(hipMemset(c->val64.p, 0, sizeof(double) * ((size_t)nnz + 16)));
-    CT(hipMemset(c->edge32.p, 0, sizeof(EdgeF) * ((size_t)nnz + 16)));
+    CT(hipMemset(c->edge32.p, 0, sizeof(EdgeQ) * ((size_t)nnz + 16)));
     CT(c->h64.reserve((size_t)n));
-    CT(c->h32.reserve((size_t)n));
+    CT(c->hq.reserve((size_t)n));
     CT(hipMemcpy(c->rowptr.p, rowptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
     if (nnz > 0) {
         CT(hipMemcpy(c->col.p, colidx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
         CT(hipMemcpy(c->val64.p, vals, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
-        CT(hipMemcpy(c->edge32.p, e32.data(), sizeof(EdgeF) * (size_t)nnz, hipMemcpyHostToDevice));
+        CT(hipMemcpy(c->edge32.p, e32.data(), sizeof(EdgeQ) * (size_t)nnz, hipMemcpyHostToDevice));
     }
     CT(hipMemcpy(c->h64.p, h, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-    CT(hipMemcpy(c->h32.p, h32.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+    CT(hipMemcpy(c->hq.p, hq.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
 
     const size_t R = (size_t)std::max(n_chains, 1);
     CT(c->spins.reserve(R * c->n_pad));
@@ -679,7 +717,7 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
 
     c->g.n = n; c->g.n_pad = c->n_pad;
     c->g.rowptr = c->rowptr.p; c->g.col = c->col.p; c->g.val64 = c->val64.p; c->g.edge32 = c->edge32.p;
-    c->g.h64 = c->h64.p; c->g.h32 = c->h32.p;
+    c->g.h64 = c->h64.p; c->g.hq = c->hq.p;
 
 #undef CT
     *out = c;
@@ -703,7 +741,7 @@ void nlmc_destroy(nlmc_ctx *c)
     c->dbg.release();
 #endif
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
-    c->rowptr.release(); c->col.release(); c->val64.release(); c->h64.release(); c->edge32.release(); c->h32.release();
+    c->rowptr.release(); c->col.release(); c->val64.release(); c->h64.release(); c->edge32.release(); c->hq.release();
     c->spins.release(); c->best.release(); c->flags.release(); c->efix.release(); c->emin.release(); c->etrace.release();
     c->argmin.release(); c->energy.release(); c->tab.release(); c->ustream.release(); c->etrace_d.release();
     c->keys.release(); c->strace.release(); c->cfg.release(); c->scratch.release(); c->plan.release();
@@ -792,6 +830,8 @@ int nlmc_set_energy_sink(nlmc_ctx *c, double *dev_out)
 }
 
 int nlmc_energy_scale(const nlmc_ctx *c) { return c ? c->escale : 0; }
+
+int nlmc_field_scale(const nlmc_ctx *c) { return c ? c->qs : 0; }
 
 int nlmc_energy_of(nlmc_ctx *c, const int8_t *spins, int64_t count, double *out)
 {
@@ -921,8 +961,15 @@ int nlmc_plan_philox(nlmc_ctx *c, int precision, int order_mode, uint32_t sweep0
     if (n_sweeps == 0) return NLMC_OK;
     const int ell_mode = precision == NLMC_F64 ? 2 : 1;
     HIP_TRY(c, c->plan.reserve((size_t)n_sweeps, (size_t)c->n, ell_mode));
+    hipEvent_t pe0 = nullptr, pe1 = nullptr, pe2 = nullptr;      // planning time -> levelize time of nlmc_timing_total
+    if (c->ev_accumulate) {
+        pe0 = next_event(c); pe1 = next_event(c); pe2 = next_event(c);
+        if (!pe0 || !pe1 || !pe2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(c, hipEventRecord(pe0, c->stream));
+    }
     int rc = run_levelize(c, n_sweeps, nullptr, 0, n_sweeps, sweep0, seed, c->plan, ell_mode);
     if (rc) return rc;
+    if (pe0) { HIP_TRY(c, hipEventRecord(pe1, c->stream)); HIP_TRY(c, hipEventRecord(pe2, c->stream)); }
     c->plan_valid = true;
     c->plan_mode = order_mode;
     c->plan_precision = precision;
@@ -964,8 +1011,17 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     { int rc = ensure_lds(c, 10, reinterpret_cast<const void *>(k_levelize_fused), lds); if (rc) return rc; }
     const bool fz_diag = getenv("NLMC_FZ_STATS") != nullptr;     // diagnostic: phase cycle counts of window 0 on stderr
     if (fz_diag) { HIP_TRY(c, c->fz_stats.reserve(W * 8)); a.stats = c->fz_stats.p; }
+    // planning time counts as levelize time of the accumulating timer (nlmc_timing_total): an event triple whose
+    // sweep part is empty
+    hipEvent_t pe0 = nullptr, pe1 = nullptr, pe2 = nullptr;
+    if (c->ev_accumulate) {
+        pe0 = next_event(c); pe1 = next_event(c); pe2 = next_event(c);
+        if (!pe0 || !pe1 || !pe2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(c, hipEventRecord(pe0, c->stream));
+    }
     hipLaunchKernelGGL(k_levelize_fused, dim3(n_windows), dim3(1024), lds, c->stream, a);
     HIP_TRY(c, hipGetLastError());
+    if (pe0) { HIP_TRY(c, hipEventRecord(pe1, c->stream)); HIP_TRY(c, hipEventRecord(pe2, c->stream)); }
     c->fz_nlev_host.assign(W, 0);
     HIP_TRY(c, hipMemcpyAsync(c->fz_nlev_host.data(), c->fz_nlev.p, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1240,6 +1296,7 @@ int nlmc_icm_components(nlmc_ctx *c, int chain_a, int chain_b, int32_t *out_n_co
     int32_t info[2] = {0, 0};
     HIP_TRY(c, hipMemcpyAsync(info, c->icm_info.p, sizeof(info), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (info[0] < 0) return fail(c, NLMC_ERR_STATE, "icm: the component search did not converge");
     *out_n_components = info[0];
     return NLMC_OK;
 }
@@ -1288,6 +1345,7 @@ int nlmc_icm_move(nlmc_ctx *c, int chain_a, int chain_b, int64_t pick_index, int
     int32_t info[2] = {0, 0};
     HIP_TRY(c, hipMemcpyAsync(info, c->icm_info.p, sizeof(info), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (info[0] < 0) return fail(c, NLMC_ERR_STATE, "icm: the component search did not converge");
     if (out_info) { out_info[0] = info[0]; out_info[1] = info[1]; }
     return NLMC_OK;
 }
@@ -1317,6 +1375,8 @@ int nlmc_icm_round_philox(nlmc_ctx *c, const int32_t *pairs, int n_pairs, uint32
     if (out_info) {
         HIP_TRY(c, hipMemcpyAsync(out_info, c->icm_info.p, sizeof(int32_t) * 2 * n_pairs, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (int p = 0; p < n_pairs; ++p)
+            if (out_info[2 * p] < 0) return fail(c, NLMC_ERR_STATE, "icm: the component search did not converge");
     }
     return NLMC_OK;
 }
@@ -1345,6 +1405,8 @@ int nlmc_icm_round_ladders(nlmc_ctx *c, uint32_t round, uint64_t seed, int katzg
     if (out_info) {
         HIP_TRY(c, hipMemcpyAsync(out_info, c->icm_info.p, sizeof(int32_t) * 2 * n_pairs, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (int p = 0; p < n_pairs; ++p)
+            if (out_info[2 * p] < 0) return fail(c, NLMC_ERR_STATE, "icm: the component search did not converge");
     }
     return NLMC_OK;
 }

@@ -67,15 +67,46 @@ __device__ __forceinline__ double exp2_spec(double z)
     return __longlong_as_double(__double_as_longlong(p) + (long long)(((uint64_t)(int64_t)nf) << 52));
 }
 
-__device__ __forceinline__ float uniform_from(const u32x4 &r, float) { return (float)(r.x >> 8) * 5.9604644775390625e-08f; }
 __device__ __forceinline__ double uniform_from(const u32x4 &r, double)
 {
     return ((double)(r.x >> 5) * 67108864.0 + (double)(r.y >> 6)) / 9007199254740992.0;
 }
 
-// heat-bath acceptance of s=+1:  u < 1/(1+2^z)  <=>  fma(u, 2^z, u) < 1,   z = -2 log2(e) beta x
-__device__ __forceinline__ bool accept_up(float u, float z) { return __fmaf_rn(u, exp2_spec(z), u) < 1.0f; }
+// heat-bath acceptance of s=+1 in the fp64 mode:  u < 1/(1+2^z)  <=>  fma(u, 2^z, u) < 1,   z = -2 log2(e) beta x
 __device__ __forceinline__ bool accept_up(double u, double z) { return __fma_rn(u, exp2_spec(z), u) < 1.0; }
+
+// ---- "f32" throughput mode: logistic threshold from 32 random bits --------------------------------------------
+// log2(1.5 + t) on |t| <= 0.5: degree-7 minimax fit, fma Horner (max error 3.8e-7)
+__device__ __forceinline__ float log2_15_spec(float t)
+{
+    float p = 0x1.e444e6p-7f;
+    p = __fmaf_rn(p, t, -0x1.9b9e5ap-6f);
+    p = __fmaf_rn(p, t, 0x1.32e57ap-5f);
+    p = __fmaf_rn(p, t, -0x1.2122a4p-4f);
+    p = __fmaf_rn(p, t, 0x1.23e4dep-3f);
+    p = __fmaf_rn(p, t, -0x1.4853d8p-2f);
+    p = __fmaf_rn(p, t, 0x1.ec7086p-1f);
+    p = __fmaf_rn(p, t, 0x1.2b803ep-1f);
+    return p;
+}
+
+// W(r) ~= log2((1 - u) / u), u = (r + 1/2) / 2^32.  The heat-bath rule s' = +1 iff u < 1 / (1 + exp(-2 beta x))
+// (NMC/nmc.py:87) becomes  s' = +1 iff z < W(r),  z = -2 log2(e) beta x: the transcendental depends on the random
+// number only, so it is evaluated where the random number is made (off the spin update's dependent chain).  Built
+// from v = min(u, 1 - u): W(~r) == -W(r) exactly.  Restated in oracle/nlo.c (threshold_spec_f32), same bits.
+__device__ __forceinline__ float threshold_spec(uint32_t r)
+{
+    const uint32_t m = (uint32_t)((int32_t)r >> 31);
+    const uint32_t a = r ^ m;
+    const float v = __fmaf_rn((float)a, 0x1p-32f, 0x1p-33f);
+    const uint32_t b = __float_as_uint(v);
+    const float ef = (float)((int32_t)(b >> 23) - 126);
+    const float mant = __uint_as_float((b & 0x7FFFFFu) | 0x3F800000u);
+    const float t1 = mant - 1.5f;
+    const float t2 = __fmaf_rn(v, -2.0f, 0.5f);
+    const float w = (log2_15_spec(t2) - log2_15_spec(t1)) - ef;
+    return __uint_as_float((__float_as_uint(w) & 0x7FFFFFFFu) | (r & 0x80000000u));
+}
 
 // 64-bit wave reduction (wave64) by shuffles
 __device__ __forceinline__ long long wave_sum_i64(long long v)

@@ -12,16 +12,18 @@
 #pragma once
 #include "nlmc_device.h"
 
-struct EdgeF { int32_t col; float val; };   // 8-byte packed CSR entry for the fp32 path (one dwordx2 load)
+// 8-byte packed CSR entry of the "f32" throughput path (one dwordx2 load): column and the coupling in 24-bit fixed
+// point, q = rint(J 2^qs) (nlmc_create).  The field of a spin is then an exact int32, independent of summation order.
+struct EdgeQ { int32_t col; int32_t q; };
 
 struct CsrDev {
     int n, n_pad;
     const int32_t *rowptr;
     const int32_t *col;      // [nnz]
     const double *val64;     // [nnz]
-    const EdgeF *edge32;     // [nnz]
+    const EdgeQ *edge32;     // [nnz]
     const double *h64;       // [n]
-    const float *h32;        // [n]
+    const int32_t *hq;       // [n]  rint(h 2^qs)
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -45,9 +47,9 @@ struct LevelizeArgs {
     int32_t *hi_max;      // [n_orders] largest number of long rows (> 8 entries) at the front of any level
     // optional packed per-order schedule in ELL form (slot-major, position-minor) so that the sweep kernel's
     // loads are fully coalesced: lane i of a level reads slot q at [(o*8+q)*n + i]
-    EdgeF *ell32;         // [n_orders][8][n][2]  first 16 entries of row k(i) as 8 planes of 2 entries (16 B),
-                          //                      zero-padded (col 0, val 0)
-    int2 *head32;         // [n_orders][n]     { k | deg << 16, bits of (float)h_k }
+    EdgeQ *ell32;         // [n_orders][8][n][2]  first 16 entries of row k(i) as 8 planes of 2 entries (16 B),
+                          //                      zero-padded (col 0, q 0)
+    int2 *head32;         // [n_orders][n]     { k | deg << 16, hq_k }
     int32_t *ellc64;      // [n_orders][8][n]
     double *ellv64;       // [n_orders][8][n]
     double *headh64;      // [n_orders][n]
@@ -176,13 +178,13 @@ __global__ void k_levelize(LevelizeArgs a)
         const int kd = k | (deg << 16);
         ord[pos] = make_int2(kd, rs);
         if (a.ell32) {
-            a.head32[(size_t)o * n + pos] = make_int2(kd, __float_as_int(a.g.h32[k]));
+            a.head32[(size_t)o * n + pos] = make_int2(kd, a.g.hq[k]);
 #pragma unroll
             for (int q = 0; q < NLMC_ELL_W32; q += 2) {
-                EdgeF e0{0, 0.0f}, e1{0, 0.0f};
+                EdgeQ e0{0, 0}, e1{0, 0};
                 if (q < deg) e0 = a.g.edge32[rs + q];
                 if (q + 1 < deg) e1 = a.g.edge32[rs + q + 1];
-                int4 pk = make_int4(e0.col, __float_as_int(e0.val), e1.col, __float_as_int(e1.val));
+                int4 pk = make_int4(e0.col, e0.q, e1.col, e1.q);
                 reinterpret_cast<int4 *>(a.ell32)[((size_t)o * (NLMC_ELL_W32 / 2) + q / 2) * n + pos] = pk;
             }
         }
@@ -213,8 +215,8 @@ struct FusedLevelizeArgs {
     uint16_t *glv;            // scratch [n_windows][T][n]: level of update (t, k), 1-based
     uint32_t *perm;           // scratch [n_windows][T n]: item id k | t << 16 at its position
     long long *stats;         // diagnostic (NLMC_FZ_STATS): [n_windows][8] cycles keys / init / passes, pass count, place 1 / 2
-    int2 *head;               // [n_windows][T n]   { k | deg << 16 | (t mod 3) << 30, bits of (float)h_k }
-    EdgeF *ell;               // [n_windows][8][T n][2]   row window planes, position-minor
+    int2 *head;               // [n_windows][T n]   { k | deg << 16 | (t mod 3) << 30, hq_k }
+    EdgeQ *ell;               // [n_windows][8][T n][2]   row window planes, position-minor
     int32_t *loff;            // [n_windows][NLMC_LCAP + 1] published level offsets
     int32_t *nlev;            // [n_windows] published levels; 0 = deeper than NLMC_LCAP - 1 (caller falls back)
     int32_t *hi_max;          // [n_windows] most rows longer than 8 entries in any level
@@ -412,15 +414,15 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
         const uint32_t it = perm[pos];
         const int k = (int)(it & 0xFFFFu), t = (int)(it >> 16);
         const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
-        head[pos] = make_int2(k | (deg << 16) | ((t % 3) << 30), __float_as_int(a.g.h32[k]));
-        EdgeF ed[NLMC_ELL_W32];
+        head[pos] = make_int2(k | (deg << 16) | ((t % 3) << 30), a.g.hq[k]);
+        EdgeQ ed[NLMC_ELL_W32];
 #pragma unroll
         for (int q = 0; q < NLMC_ELL_W32; ++q) ed[q] = a.g.edge32[rs + q];     // unconditional (the array is padded by
 #pragma unroll                                                                  // a full window): independent loads
         for (int q = 0; q < NLMC_ELL_W32; q += 2) {
-            const EdgeF z{0, 0.0f};
-            const EdgeF e0 = q < deg ? ed[q] : z, e1 = q + 1 < deg ? ed[q + 1] : z;
-            ell[(size_t)(q / 2) * TN + pos] = make_int4(e0.col, __float_as_int(e0.val), e1.col, __float_as_int(e1.val));
+            const EdgeQ z{0, 0};
+            const EdgeQ e0 = q < deg ? ed[q] : z, e1 = q + 1 < deg ? ed[q + 1] : z;
+            ell[(size_t)(q / 2) * TN + pos] = make_int4(e0.col, e0.q, e1.col, e1.q);
         }
     }
     if (a.stats && tid == 0) {
@@ -447,7 +449,7 @@ struct SweepArgs {
     // schedule: ord2[o][i] = { k | deg << 16, row start }, lvl_off[o][0..nlev], nlev[o]
     const int2 *ord2;
     const int32_t *lvl_off, *nlev, *hi_max;
-    const EdgeF *ell32;       // packed schedule (philox kernels), see LevelizeArgs: [o][4][n] int4 planes
+    const EdgeQ *ell32;       // packed schedule (philox kernels), see LevelizeArgs: [o][4][n] int4 planes
     const int2 *head32;
     const int32_t *ellc64;
     const double *ellv64, *headh64;
@@ -465,6 +467,8 @@ struct SweepArgs {
     long long *efix;          // [n_chains] in/out
     double *energy_sink;      // [n_chains] or nullptr: tracked energy as a double, written with the final state
     int escale;
+    int eshift;               // escale - qs: an energy delta of the fixed-point path is  (s - s') X << eshift
+    float qinv;               // 2^-qs
     long long *etrace;        // [n_chains][trace_sweeps] or nullptr
     int trace_sweeps, t0;     // sweeps of the whole call / index of this launch's first sweep inside the call
     int rec_stride;
@@ -479,7 +483,7 @@ struct SweepArgs {
     // fused-window schedule (k_sweep_fused): one merged level list for all n_sweeps of the launch
     const int32_t *fsend;     // [n_sweeps] published index of the last level holding an item of sweep t
     const int2 *warm_head;    // head / plane arrays of the NEXT planned window (or nullptr): pulled towards the chip by
-    const EdgeF *warm_ell;    // the helper waves while this window runs
+    const EdgeQ *warm_ell;    // the helper waves while this window runs
     int f_workers;            // waves that take schedule items; the remaining waves prepare uniforms
     int lds_send_off;
 };
@@ -638,8 +642,8 @@ typedef int nlmc_i4 __attribute__((ext_vector_type(4)));
 typedef int nlmc_i2 __attribute__((ext_vector_type(2)));
 template <> struct Pf<float> {
     static constexpr int W = NLMC_ELL_W32;
-    nlmc_i4 pk[W / 2];            // plane q: { col(2q), bits val(2q), col(2q+1), bits val(2q+1) }
-    nlmc_i2 hd;                   // { k | deg << 16, bits of h_k }
+    nlmc_i4 pk[W / 2];            // plane q: { col(2q), Jq(2q), col(2q+1), Jq(2q+1) }   (fixed-point couplings)
+    nlmc_i2 hd;                   // { k | deg << 16, hq_k }
     // The loads of one item (head + 4 planes, or + 8 planes in waves that may hold rows longer than 8 entries) are
     // issued unconditionally inside a pipeline stage: a load behind a branch makes hipcc's vmcnt model
     // path-dependent, and it then drains vmcnt to 0 -- i.e. waits for the prefetch it has just issued -- before every
@@ -674,10 +678,10 @@ template <> struct Pf<float> {
             pk[q] = __builtin_amdgcn_raw_buffer_load_b128(v.ell, o16, q * v.plane_bytes, 0);
     }
     __device__ __forceinline__ int kd() const { return hd.x; }
-    __device__ __forceinline__ float h() const { return __int_as_float(hd.y); }
+    __device__ __forceinline__ int h() const { return hd.y; }
     __device__ __forceinline__ int col(int q) const { return (q & 1) ? pk[q >> 1].z : pk[q >> 1].x; }
-    __device__ __forceinline__ float val(int q) const { return __int_as_float((q & 1) ? pk[q >> 1].w : pk[q >> 1].y); }
-    static __device__ __forceinline__ void tail(const CsrDev &g, int e, int &cj, float &vj) { const EdgeF t = g.edge32[e]; cj = t.col; vj = t.val; }
+    __device__ __forceinline__ int val(int q) const { return (q & 1) ? pk[q >> 1].w : pk[q >> 1].y; }
+    static __device__ __forceinline__ void tail(const CsrDev &g, int e, int &cj, int &vj) { const EdgeQ t = g.edge32[e]; cj = t.col; vj = t.q; }
 };
 template <> struct Pf<double> {
     static constexpr int W = NLMC_ELL_W;
@@ -715,31 +719,27 @@ template <> struct Pf<double> {
     static __device__ __forceinline__ void tail(const CsrDev &g, int e, int &c, double &v) { c = g.col[e]; v = g.val64[e]; }
 };
 
-// -(ds) * x * 2^escale as an exact integer (== llrint of the fp64 product the oracle forms).  For a float x and
-// ds = +-2 the product is mantissa << shift whenever 0 <= shift <= 38: integer ops, branch-free; `slow` flags the
-// lanes (denormal / tiny / huge x) that need the fp64 formula instead.
-__device__ __forceinline__ long long fixed_delta_fast(float xt, int ds, int escale, bool &slow)
-{
-    const uint32_t b = __float_as_uint(xt);
-    const int e = (int)((b >> 23) & 0xFFu);
-    const int sh = e - 149 + escale;                                   // (e - 150) + escale + 1  (|ds| == 2)
-    const bool ok = (e != 0) & (e != 255) & (sh >= 0) & (sh <= 38);
-    const long long mag = (long long)((b & 0x7FFFFFu) | 0x800000u) << (sh & 63);
-    const bool neg = ((b >> 31) != 0u) == (ds < 0);                     // sign(-ds * x)
-    slow = (ds != 0) & !ok;
-    return (ds != 0 && ok) ? (neg ? -mag : mag) : 0ll;
-}
+// -(ds) * x * 2^escale rounded to the nearest integer (fp64 paths)
 __device__ __forceinline__ long long fixed_delta_slow(double xt, int ds, double esc) { return __double2ll_rn(-(double)ds * xt * esc); }
 
-__device__ __forceinline__ float fma_rn(float a, float b, float c) { return __fmaf_rn(a, b, c); }
+__device__ __forceinline__ float scale_cb(float cb, float qinv) { return cb * qinv; }
+__device__ __forceinline__ double scale_cb(double cb, float) { return cb; }
 __device__ __forceinline__ double fma_rn(double a, double b, double c) { return __fma_rn(a, b, c); }
 
 // Heat-bath update of one spin from a prefetched schedule item.  J*s is exact (s = +-1), so fma(J, s, x) == x + J*s;
 // the zero-padded slots add +-0 and leave x unchanged, which keeps the oracle's row-order sum bit for bit.
+template <bool DIAG, bool TAIL, bool FUSED>
+__device__ __forceinline__ void update_spin_q(const SweepArgs &a, ChainCtx &x, const float *wt, const Pf<float> &pf, size_t oid, int i,
+                                              float cq0, float cq1);
+
 template <typename T, bool DIAG, bool TAIL, bool FUSED = false>
 __device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, const T *ur, const Pf<T> &pf, size_t oid, int i,
                                             T cb0, T cb1, double esc)
 {
+    if constexpr (sizeof(T) == 4) {            // "f32" throughput mode: fixed-point field, threshold test
+        update_spin_q<DIAG, TAIL, FUSED>(a, x, ur, pf, oid, i, cb0, cb1);
+        return;
+    } else {
     // fused schedule items carry the uniform-table slot of their sweep (t mod 3) in the two top bits
     const int k = pf.kd() & 0xFFFF, deg = FUSED ? (int)(((unsigned)pf.kd() >> 16) & 0x3FFFu) : (int)((unsigned)pf.kd() >> 16);
     const unsigned f = x.fl ? (unsigned)x.fl[k] : 0u;
@@ -806,36 +806,106 @@ __device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, con
 #endif
     // straight-line tail: branches cost a wave far more than the handful of integer ops they would skip
     const int ds = sn - so;                    // 0 or +-2 (spins are +-1 in this mode)
-    if constexpr (sizeof(T) == 4) {
-        bool slow;
-        long long d = fixed_delta_fast(x_true, ds, a.escale, slow);
-        if (__ballot(slow) != 0ull) {          // practically never; the empty volatile asm keeps hipcc from
-            asm volatile("" ::: "memory");     // if-converting this block into an always-executed fp64 sequence
-            if (slow) d = fixed_delta_slow((double)x_true, ds, esc);
-        }
-        x.e_loc += d;
-    } else {
-        if (ds != 0) x.e_loc += fixed_delta_slow((double)x_true, ds, esc);
-    }
+    if (ds != 0) x.e_loc += fixed_delta_slow((double)x_true, ds, esc);
     s[k] = (int8_t)sn;
 #ifdef NLMC_STAMPS
     NLMC_CLK(u4)
     if (x.st) { x.st[0] += u1 - u0; x.st[1] += u2 - u1; x.st[2] += u3 - u2; x.st[3] += u4 - u3; x.st[4] += 1; }
 #endif
+    }
+}
+
+// Heat-bath update of one spin in the "f32" throughput mode (fixed-point couplings): the field X = hq_k + sum Jq s is
+// an exact int32 whatever the order of the sum, so it is accumulated in two independent multiply-add chains
+// (v_mad_i32_i24: the spins come sign-extended from LDS, |Jq| < 2^23); the acceptance is ONE compare against the
+// threshold that was computed with the random number (threshold_spec); the energy delta is one 32 x 32 -> 64 bit
+// multiply-add, exact.
+template <bool DIAG, bool TAIL, bool FUSED>
+__device__ __forceinline__ void update_spin_q(const SweepArgs &a, ChainCtx &x, const float *wt, const Pf<float> &pf, size_t oid, int i,
+                                              float cq0, float cq1)
+{
+    const int k = pf.kd() & 0xFFFF, deg = FUSED ? (int)(((unsigned)pf.kd() >> 16) & 0x3FFFu) : (int)((unsigned)pf.kd() >> 16);
+    const unsigned f = x.fl ? (unsigned)x.fl[k] : 0u;
+    if (f >= 2u) return;                       // frozen
+    int8_t *s = x.s;
+    // fused schedule items carry the threshold-table slot of their sweep (t mod 3) in the two top bits
+    const float *wts = FUSED ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(wt) +
+                                                                ((unsigned)pf.kd() >> 30) * (unsigned)x.ustride) : wt;
+    const float wk = wts[k];                   // issued up front with the gathers
+    const int so = (int)s[k];
+    constexpr int W = Pf<float>::W;
+    typedef const int8_t __attribute__((address_space(3))) *lds_i8;   // spins sit at LDS offset 0: column == address
+#define NLMC_SPIN_I(c) ((int)(*(lds_i8)(uintptr_t)(unsigned)(c)))
+#ifdef NLMC_STAMPS
+    long long u0, u1, u4;
+    NLMC_CLK(u0)
+#endif
+    int sj[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sj[q] = NLMC_SPIN_I(pf.col(q));       // all LDS reads in flight together
+#ifdef NLMC_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    NLMC_CLK(u1)
+#endif
+    int X0 = pf.h(), X1 = 0, Xd = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+        X0 += __mul24(pf.val(q), sj[q]);
+        X1 += __mul24(pf.val(q + 1), sj[q + 1]);
+    }
+    if (DIAG) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) Xd += (q < deg && pf.col(q) == k) ? __mul24(pf.val(q), sj[q]) : 0;
+    }
+    if (TAIL && __ballot(deg > 8) != 0ull) {   // second half of the packed window: only waves holding a long row
+        int sk[8];
+#pragma unroll
+        for (int q = 8; q < W; ++q) sk[q - 8] = NLMC_SPIN_I(pf.col(q));
+#pragma unroll
+        for (int q = 8; q < W; q += 2) {
+            X0 += __mul24(pf.val(q), sk[q - 8]);
+            X1 += __mul24(pf.val(q + 1), sk[q - 7]);
+        }
+        if (DIAG) {
+#pragma unroll
+            for (int q = 8; q < W; ++q) Xd += (q < deg && pf.col(q) == k) ? __mul24(pf.val(q), sk[q - 8]) : 0;
+        }
+    }
+    if (deg > W) {                             // rows longer than the packed window: rest from the CSR arrays
+        const int rs = FUSED ? a.g.rowptr[k] : a.ord2[oid * x.n + i].y;
+        for (int e = W; e < deg; ++e) {
+            int j, v;
+            Pf<float>::tail(a.g, rs + e, j, v);
+            const int t = __mul24(v, (int)s[j]);
+            X0 += t;
+            if (DIAG && j == k) Xd += t;
+        }
+    }
+    const int X = X0 + X1;
+    const float z = (f == 1u ? cq1 : cq0) * (float)X;
+    const int sn = (z < wk) ? 1 : -1;
+    const int c = (so - sn) << a.eshift;       // 0 or +-2^(eshift+1) <= 2^30
+    x.e_loc += (long long)(DIAG ? X - Xd : X) * (long long)c;
+    s[k] = (int8_t)sn;
+#ifdef NLMC_STAMPS
+    asm volatile("" :: "v"(sn));
+    NLMC_CLK(u4)
+    if (x.st) { x.st[0] += u1 - u0; x.st[1] += u4 - u1; x.st[4] += 1; }
+#endif
 }
 
 // uniforms of one sweep for every spin of this chain -> LDS.  One Philox4x32-10 call serves 4 (f32) / 2 (f64) spins:
-//   f32: u(k) = 24 high bits of word (k & 3) of philox(k >> 2, t, chain, UNIFORM)
+//   f32: W(k) = threshold_spec(word (k & 3) of philox(k >> 2, t, chain, UNIFORM))
 //   f64: u(k) = 53 bits from words (2(k&1), 2(k&1)+1) of philox(k >> 1, t, chain, UNIFORM)
 __device__ __forceinline__ void fill_uniforms(float *ur, int n, uint32_t tt, uint32_t gc, uint32_t k0, uint32_t k1, int tid, int nt)
 {
-    for (int b = tid; b < (n + 3) / 4; b += nt) {
+    for (int b = tid; b < (n + 3) / 4; b += nt) {   // "f32" mode: the table holds the logistic thresholds W(r)
         const u32x4 r = philox4x32_10((uint32_t)b, tt, gc, NLMC_TAG_UNIFORM, k0, k1);
         float4 v;
-        v.x = (float)(r.x >> 8) * 5.9604644775390625e-08f;
-        v.y = (float)(r.y >> 8) * 5.9604644775390625e-08f;
-        v.z = (float)(r.z >> 8) * 5.9604644775390625e-08f;
-        v.w = (float)(r.w >> 8) * 5.9604644775390625e-08f;
+        v.x = threshold_spec(r.x);
+        v.y = threshold_spec(r.y);
+        v.z = threshold_spec(r.z);
+        v.w = threshold_spec(r.w);
         reinterpret_cast<float4 *>(ur)[b] = v;     // ur has (n+3)/4*4 entries
     }
 }
@@ -852,10 +922,14 @@ __device__ __forceinline__ void fill_uniforms(double *ur, int n, uint32_t tt, ui
 
 // The pipelined level loop of one sweep (see k_sweep_philox).  TAIL: this wave may hold rows longer than 8 entries and
 // therefore also loads / folds the second half of the 16-entry row window.
-template <typename T, bool DIAG, bool TAIL, bool FUSED = false>
+struct NoGen { __device__ __forceinline__ void operator()(int) const {} };
+
+template <typename T, bool DIAG, bool TAIL, bool FUSED = false, typename Gen = NoGen>
 __device__ __forceinline__ void run_levels(const SweepArgs &a, ChainCtx &x, const T *ur, const int *loff, size_t so, int nl,
-                                           int n_bar, T cb0, T cb1, double esc, int n_items = 0)
+                                           int n_bar, T cb0, T cb1, double esc, int n_items = 0, Gen gen = Gen())
 {
+    // gen(l): per-level side job of this wave, run before the level's update (k_sweep_fused: every wave produces its
+    // share of the threshold table of the sweep after next while the schedule items of the next level are in flight)
     // n_bar: levels [0, n_bar) end with a workgroup barrier; levels [n_bar, nl) are at most one wave wide and belong
     // to wave 0 alone, which runs them back to back (LDS executes one wave's accesses in order, so its own writes are
     // visible to its own later reads) while the other waves already prepare the next sweep (k_sweep_philox).
@@ -900,20 +974,53 @@ __device__ __forceinline__ void run_levels(const SweepArgs &a, ChainCtx &x, cons
 #else
 #define NLMC_LVL_STAMP(lv)
 #endif
+#if defined(NLMC_V_FETCH_AFTER)
+#define NLMC_STAGE(lv, pnext, vnext, inext, pcur, vcur, icur) \
+    if (vcur) update_spin<T, DIAG, TAIL, FUSED>(a, x, ur, pcur, so, icur, cb0, cb1, esc); \
+    fetch((lv) + 1, pnext, vnext, inext); gen(lv);
+#elif defined(NLMC_V_GEN_AFTER)
+#define NLMC_STAGE(lv, pnext, vnext, inext, pcur, vcur, icur) \
+    fetch((lv) + 1, pnext, vnext, inext); \
+    if (vcur) update_spin<T, DIAG, TAIL, FUSED>(a, x, ur, pcur, so, icur, cb0, cb1, esc); \
+    gen(lv);
+#else
+#define NLMC_STAGE(lv, pnext, vnext, inext, pcur, vcur, icur) \
+    fetch((lv) + 1, pnext, vnext, inext); gen(lv); \
+    if (vcur) update_spin<T, DIAG, TAIL, FUSED>(a, x, ur, pcur, so, icur, cb0, cb1, esc);
+#endif
+#ifdef NLMC_STAMPS
+    // diagnostic build: per-wave cycle split of a level -- work (fetch issue + side job + update) vs barrier wait
+    long long sw0, sw1, sw2, st_work = 0, st_bar = 0;
+#define NLMC_W0 NLMC_CLK(sw0)
+#define NLMC_W1 NLMC_CLK(sw1)
+#define NLMC_W2 NLMC_CLK(sw2) st_work += sw1 - sw0; st_bar += sw2 - sw1;
+#else
+#define NLMC_W0
+#define NLMC_W1
+#define NLMC_W2
+#endif
     for (; l < n_live; l += 2) {
-        fetch(l + 1, pfb, vb, ib);
-        if (va) update_spin<T, DIAG, TAIL, FUSED>(a, x, ur, pfa, so, ia, cb0, cb1, esc);
+        NLMC_W0
+        NLMC_STAGE(l, pfb, vb, ib, pfa, va, ia)
+        NLMC_W1
         if (l < n_bar) __syncthreads();
+        NLMC_W2
         NLMC_LVL_STAMP(l)
         if (l + 1 < nl) {
-            fetch(l + 2, pfa, va, ia);
-            if (vb) update_spin<T, DIAG, TAIL, FUSED>(a, x, ur, pfb, so, ib, cb0, cb1, esc);
+            NLMC_W0
+            NLMC_STAGE(l + 1, pfa, va, ia, pfb, vb, ib)
+            NLMC_W1
             if (l + 1 < n_bar) __syncthreads();
+            NLMC_W2
             NLMC_LVL_STAMP(l + 1)
         }
     }
+#ifdef NLMC_STAMPS
+    if (x.st) { x.st[5] += st_work; x.st[6] += st_bar; }
+#endif
+#undef NLMC_STAGE
     l = min(l, n_bar);
-    for (; l < n_bar; ++l) __syncthreads();    // retired: this wave has no item in any remaining barrier level
+    for (; l < n_bar; ++l) { gen(l); __syncthreads(); }   // retired: this wave has no item in any remaining barrier level
 }
 
 template <typename T, bool DIAG>
@@ -946,8 +1053,9 @@ __global__ void k_sweep_philox(SweepArgs a)
         const int oid = a.per_chain ? (c * a.n_sweeps + t) : t;
         const int32_t *__restrict__ off = a.lvl_off + (size_t)oid * (n + 1);
         const int nl = a.nlev[oid];
-        const T cb0 = (T)a.tab[(size_t)row * a.tab_cs + (size_t)t * a.tab_ss];
-        const T cb1 = (T)a.tab[(size_t)row * a.tab_cs + (size_t)t * a.tab_ss + 1];
+        // "f32" mode: z = cb * (X 2^-qs) with the int32 field X -> fold the exact power of two into the coefficient
+        const T cb0 = scale_cb((T)a.tab[(size_t)row * a.tab_cs + (size_t)t * a.tab_ss], a.qinv);
+        const T cb1 = scale_cb((T)a.tab[(size_t)row * a.tab_cs + (size_t)t * a.tab_ss + 1], a.qinv);
         const uint32_t tt = a.sweep0 + (uint32_t)t;
         const int pb = dbuf ? (t & 1) : 0;
         ur = reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(ur0) + (size_t)pb * a.lds_u_stride);
@@ -1063,7 +1171,7 @@ __global__ void k_sweep_fused(SweepArgs a)
     const int row = a.slot_of_chain ? a.slot_of_chain[gc] : c;
     const double esc = __longlong_as_double((long long)(1023 + a.escale) << 52);
     const int Tn = a.n_sweeps, nl = a.nlev[0];
-    const T cb0 = (T)a.tab[(size_t)row * a.tab_cs], cb1 = (T)a.tab[(size_t)row * a.tab_cs + 1];
+    const T cb0 = scale_cb((T)a.tab[(size_t)row * a.tab_cs], a.qinv), cb1 = scale_cb((T)a.tab[(size_t)row * a.tab_cs + 1], a.qinv);
 
     // prologue: uniforms of the first three sweeps, level offsets, sweep ends
     for (int t = 0; t < min(3, Tn); ++t)
@@ -1073,20 +1181,59 @@ __global__ void k_sweep_fused(SweepArgs a)
     for (int t = tid; t < Tn; t += nt) send[t] = a.fsend[t];
     __syncthreads();
 
+    // Every wave produces thresholds: block b of sweep u (4 thresholds from one Philox call) belongs to lane b mod nt.
+    // The table slot u mod 3 is free once sweep u-3 has ended (level send[u-3]) and must be complete before the first
+    // item of sweep u, which k_levelize_fused places after send[u-2]: the nj calls of a lane are spread over that range.
+    struct Gen {
+        const SweepArgs &a;
+        const int *send;
+        float *ur;
+        uint32_t gc;
+        int tid, nt, nblk, nj, Tn;
+        mutable int u;                              // next sweep whose table has to be produced
+        __device__ __forceinline__ void operator()(int l) const
+        {
+            if (u < Tn && l > send[u - 3]) {
+                const int w0 = send[u - 3], wlen = send[u - 2] - w0;          // levels (w0, w0 + wlen] are ours
+                const int per = (nj + wlen - 1) / wlen, step = l - w0 - 1;
+                float *dst = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(ur) + (size_t)(u % 3) * a.lds_u_stride);
+                for (int j = step * per; j < min(nj, (step + 1) * per); ++j) {
+                    const int b = tid + j * nt;
+                    if (b < nblk) {
+                        const u32x4 r = philox4x32_10((uint32_t)b, a.sweep0 + (uint32_t)u, gc, NLMC_TAG_UNIFORM, a.seed_lo, a.seed_hi);
+                        float4 v;
+                        v.x = threshold_spec(r.x);
+                        v.y = threshold_spec(r.y);
+                        v.z = threshold_spec(r.z);
+                        v.w = threshold_spec(r.w);
+                        reinterpret_cast<float4 *>(dst)[b] = v;
+                    }
+                }
+                if (l == send[u - 2]) ++u;          // complete before the first item of sweep u (k_levelize_fused floor)
+            }
+        }
+    };
+#ifdef NLMC_STAMPS
+    long long st_u[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // gather wait, math+write, -, -, calls, level work, barrier wait, total
+    x.st = st_u;
+    x.lvl_t = (a.dbg && c == 0) ? a.dbg + (size_t)gridDim.x * 16 * 8 : nullptr;
+    const long long st_begin = (long long)__builtin_readcyclecounter();
+#endif
+    const int nblk = (n + 3) / 4;
+    const Gen gen{a, send, ur, gc, tid, nt, nblk, (nblk + nt - 1) / nt, Tn, 3};
     const int wbase = tid & ~63;
     if (wbase < a.f_workers * 64) {
         const bool role_long = wbase < a.hi_max[0];
-        if (role_long) run_levels<T, DIAG, true, true>(a, x, ur, loff, 0, nl, nl, cb0, cb1, esc, Tn * n);
-        else run_levels<T, DIAG, false, true>(a, x, ur, loff, 0, nl, nl, cb0, cb1, esc, Tn * n);
+        if (role_long) run_levels<T, DIAG, true, true, const Gen &>(a, x, ur, loff, 0, nl, nl, cb0, cb1, esc, Tn * n, gen);
+        else run_levels<T, DIAG, false, true, const Gen &>(a, x, ur, loff, 0, nl, nl, cb0, cb1, esc, Tn * n, gen);
     } else {
+        // Waves without schedule items: their share of the thresholds, and they pull the NEXT window's schedule towards
+        // the chip.  A window's schedule (72 B per update actually touched) is read once per launch and sits in HBM
+        // when many windows were planned ahead; the workers prefetch one level ahead, which does not cover a cold miss
+        // that every chain of an XCD then waits on.  The chains of a launch share the work: one dword per 128-byte line
+        // of the head array and of planes 0-3, striped over chains and helper lanes, one load per level, retired a
+        // level later.
         const int hid = tid - a.f_workers * 64, hcnt = nt - a.f_workers * 64;
-        const int nblk = (n + 3) / 4, nj = (nblk + hcnt - 1) / hcnt;      // Philox calls per helper lane and sweep
-        // Second job of the helpers: pull the NEXT window's schedule towards the chip.  A window's schedule (72 B per
-        // update actually touched) is read once per launch and sits in HBM when many windows were planned ahead; the
-        // workers prefetch one level (~1 us) ahead, which does not cover a cold miss that every chain of an XCD then
-        // waits on (measured: 236 us per launch cold vs 191 us when the window is still in the memory-side cache).
-        // The chains of a launch share the work: one dword per 128-byte line of the head array and of planes 0-3,
-        // striped over chains and helper lanes, one load per level, retired a level later.
         const unsigned warm_lines = a.warm_head ? (unsigned)(((size_t)Tn * n * 8 + 127) / 128) : 0u;       // head
         const unsigned warm_lines_p = a.warm_head ? (unsigned)(((size_t)Tn * n * 16 * 4 + 127) / 128) : 0u; // planes 0-3
         unsigned warm_at = (unsigned)c * (unsigned)hcnt + (unsigned)hid;
@@ -1101,35 +1248,21 @@ __global__ void k_sweep_fused(SweepArgs a)
                 warm_at += warm_step;
             }
         };
-        auto fill_step = [&](int l, int &u) {
-            if (u < Tn && l > send[u - 3]) {        // slot u mod 3 is free: sweep u-3 has ended
-                const int w0 = send[u - 3], wlen = send[u - 2] - w0;          // levels (w0, w0 + wlen] are ours
-                const int per = (nj + wlen - 1) / wlen, step = l - w0 - 1;
-                T *dst = reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(ur) + (size_t)(u % 3) * a.lds_u_stride);
-                for (int j = step * per; j < min(nj, (step + 1) * per); ++j) {
-                    const int b = hid + j * hcnt;
-                    if (b < nblk) {
-                        const u32x4 r = philox4x32_10((uint32_t)b, a.sweep0 + (uint32_t)u, gc, NLMC_TAG_UNIFORM, a.seed_lo, a.seed_hi);
-                        float4 v;
-                        v.x = (float)(r.x >> 8) * 5.9604644775390625e-08f;
-                        v.y = (float)(r.y >> 8) * 5.9604644775390625e-08f;
-                        v.z = (float)(r.z >> 8) * 5.9604644775390625e-08f;
-                        v.w = (float)(r.w >> 8) * 5.9604644775390625e-08f;
-                        reinterpret_cast<float4 *>(dst)[b] = v;
-                    }
-                }
-                if (l == send[u - 2]) ++u;          // complete before the first item of sweep u (k_levelize_fused floor)
-            }
-        };
-        int u = 3;                                  // next sweep whose table has to be produced
         for (int l = 0; l < nl; ++l) {
             warm_next();
-            fill_step(l, u);
+            gen(l);
             __syncthreads();
         }
         while (warm_at < warm_lines + warm_lines_p) warm_next();     // few chains: the rest of this chain's share
         asm volatile("" :: "v"(wv) : "memory");
     }
+#ifdef NLMC_STAMPS
+    if (a.dbg && (tid & 63) == 0) {
+        long long *d = a.dbg + ((size_t)c * 16 + (tid >> 6)) * 8;
+        for (int i = 0; i < 7; ++i) d[i] = st_u[i];
+        d[7] = (long long)__builtin_readcyclecounter() - st_begin;
+    }
+#endif
     chain_store(a, x);
 }
 

@@ -164,8 +164,8 @@ __device__ __forceinline__ int icm_find(int32_t *lab, int k)
 {
     int r = lab[k];
     while (true) { const int up = lab[r]; if (up == r) break; r = up; }
-    lab[k] = r;                                        // path compression (benign race: any value written is an ancestor)
-    return r;
+    if (r != k) atomicMin(&lab[k], r);                 // path compression; atomicMin: a concurrent hook of k onto a smaller
+    return r;                                          // root (atomicMin on lab[k] as well) can never be overwritten
 }
 
 __global__ void k_icm_components(IcmArgs a)
@@ -189,6 +189,7 @@ __global__ void k_icm_components(IcmArgs a)
     // Hook rounds over the candidates only.  Neighbour lists come from the 16-bit adjacency table (two 16-byte loads
     // per spin, absent slots hold the spin itself) when every stored coupling is non-zero -- the common case --
     // otherwise from the CSR entries with the reference's `val != 0` test (NPT/apt_ICM.py:129).
+    bool converged = false;                // (workgroup-uniform)
     for (int it = 0; it <= n; ++it) {
         int changed = 0;
         for (int idx = tid; idx < nc; idx += nt) {
@@ -210,20 +211,20 @@ __global__ void k_icm_components(IcmArgs a)
                 for (int e = rs + NLMC_FZ_ADJ; e < rs + deg; ++e) hook(a.g.col[e]);
             } else {
                 const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
-                EdgeF ed[8];
+                EdgeQ ed[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) ed[q] = a.g.edge32[rs + q];
                 rk = icm_find(lab, k);
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    if (q < deg && (ed[q].val != 0.0f || a.g.val64[rs + q] != 0.0)) hook(ed[q].col);
+                    if (q < deg && (ed[q].q != 0 || a.g.val64[rs + q] != 0.0)) hook(ed[q].col);
                 for (int e = rs + 8; e < rs + deg; ++e) {
-                    const EdgeF t = a.g.edge32[e];
-                    if (t.val != 0.0f || a.g.val64[e] != 0.0) hook(t.col);
+                    const EdgeQ t = a.g.edge32[e];
+                    if (t.q != 0 || a.g.val64[e] != 0.0) hook(t.col);
                 }
             }
         }
-        if (!__syncthreads_or(changed)) break;
+        if (!__syncthreads_or(changed)) { converged = true; break; }
     }
     int cnt = 0;
     int32_t *out = a.label + (size_t)p * n;
@@ -235,7 +236,8 @@ __global__ void k_icm_components(IcmArgs a)
     }
     if (cnt) atomicAdd(&nroots, cnt);
     __syncthreads();
-    if (tid == 0) { a.info[2 * p] = nroots; a.info[2 * p + 1] = 0; }
+    // n_components = -1: the hook rounds hit their iteration cap (cannot happen for a finite graph; the host reports it)
+    if (tid == 0) { a.info[2 * p] = converged ? nroots : -1; a.info[2 * p + 1] = 0; }
 }
 
 // Houdayer pairing on the device (NPT/apt_ICM.py:216-222): for every temperature slot r the K ladders (sub-replicas)
@@ -279,7 +281,7 @@ __global__ void k_icm_move(IcmMoveArgs a)
     __shared__ int sh_root, sh_size;
     const int n = a.g.n, tid = threadIdx.x, nt = blockDim.x, p = blockIdx.x;
     const int ncomp = a.info[2 * p];
-    if (ncomp == 0) return;
+    if (ncomp <= 0) return;
     const int ca = a.pairs[2 * p], cb = a.pairs[2 * p + 1];
     int8_t *sa = a.spins + (size_t)ca * a.g.n_pad;
     int8_t *sb = a.spins + (size_t)cb * a.g.n_pad;

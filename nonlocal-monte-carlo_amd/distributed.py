@@ -53,18 +53,23 @@ class ShardedTempering:
     def set_spins(self, spins_global):
         self.eng.set_spins(np.asarray(spins_global)[self.base:self.base + self.count])
 
-    def plan(self, n_sweeps, n_rounds=0):
-        """Build the level schedules of the next n_sweeps sweeps and the pair selections of the next n_rounds swap
-        rounds ahead of time (both depend on the RNG only)."""
+    def plan(self, n_sweeps, n_rounds=0, chunk_rounds=None, lazy=False):
+        """Level schedules of the next n_sweeps sweeps and pair selections of the next n_rounds swap rounds (both depend
+        on the RNG only).  They are built a bounded chunk of rounds at a time (`chunk_rounds`, and a memory budget);
+        with `lazy` nothing is built here: every chunk, the first one included, is planned by the round() that first
+        needs it, so that the planning work lies inside whatever the caller times (the reference draws its permutation
+        inside the sweep loop, NMC/nmc.py:62-71)."""
         self._planner = None
         if n_rounds > 0 and n_sweeps % n_rounds == 0 and hasattr(self.eng, "plan_philox_fused"):
             # rounds of equal length: fused-window level lists where the instance qualifies (same bits, fuller levels)
             self._planner = RoundPlanner(self.eng, self.sweeps_done, n_rounds, n_sweeps // n_rounds, self.seed,
-                                         precision=self.precision, budget_bytes=16 << 30)
+                                         precision=self.precision, budget_bytes=16 << 30, chunk_rounds=chunk_rounds,
+                                         pt_pairs=self.n_pairs, pt_round0=self.rounds_done)
             self._planner_round0 = self.rounds_done
-            self._planner._plan(0, True)
-        else:
-            self.eng.plan_philox(self.sweeps_done, n_sweeps, self.seed, precision=self.precision)
+            if not lazy:
+                self._planner._plan(0, True)
+            return
+        self.eng.plan_philox(self.sweeps_done, n_sweeps, self.seed, precision=self.precision)
         if n_rounds > 0 and self.n_pairs > 0 and hasattr(self.eng, "pt_plan"):
             self.eng.pt_plan(self.rounds_done, n_rounds, self.seed, self.n_pairs)
 

@@ -69,6 +69,7 @@ class Engine:
         self._ctx = h_
         self.ladder_len = 0
         self.energy_scale = int(self._L.nlmc_energy_scale(self._ctx))
+        self.field_scale = int(self._L.nlmc_field_scale(self._ctx))      # qs of the "f32" path: Jq = rint(J 2^qs)
 
     # -- lifetime ---------------------------------------------------------------------------------------
     def close(self):
@@ -329,19 +330,28 @@ class RoundPlanner:
     """Level schedules planned ahead for `n_rounds` rounds of `sweeps_per_round` sweeps each (they depend on the RNG
     only), a bounded number of rounds at a time.  Rounds whose sweeps need no per-sweep output run on the fused-window
     schedule when the instance qualifies (one or more launches of `window` sweeps), everything else on the
-    sweep-by-sweep schedule; the results are the same bits either way."""
+    sweep-by-sweep schedule; the results are the same bits either way.  With `pt_pairs` > 0 the pair selections of the
+    swap rounds `pt_round0 + ii` (they depend on the RNG only, too) are planned with every chunk."""
 
     BYTES_PER_UPDATE = 140              # packed schedule: head 8 + row window 128 + scratch
 
-    def __init__(self, eng, sweep0, n_rounds, sweeps_per_round, seed, precision="f32", budget_bytes=1 << 30):
+    def __init__(self, eng, sweep0, n_rounds, sweeps_per_round, seed, precision="f32", budget_bytes=1 << 30,
+                 chunk_rounds=None, pt_pairs=0, pt_round0=0):
         self.eng, self.sweep0, self.R, self.S, self.seed, self.precision = eng, int(sweep0), int(n_rounds), int(sweeps_per_round), int(seed), precision
         self.window = fused_window(self.S) if precision == "f32" else 0
         per_round = max(1, self.S * eng.n * self.BYTES_PER_UPDATE)
         self.chunk = max(1, min(self.R, int(budget_bytes // per_round)))
+        if chunk_rounds:
+            self.chunk = max(1, min(self.chunk, int(chunk_rounds)))
+        self.pt_pairs, self.pt_round0 = int(pt_pairs), int(pt_round0)
         self._fused_from = self._fused_to = self._plain_from = self._plain_to = 0      # planned round ranges
+        self.chunks_planned = 0
 
     def _plan(self, ii, want_fused):
         r0, r1 = ii, min(self.R, ii + self.chunk)
+        self.chunks_planned += 1
+        if self.pt_pairs > 0 and hasattr(self.eng, "pt_plan"):
+            self.eng.pt_plan(self.pt_round0 + r0, r1 - r0, self.seed, self.pt_pairs)
         if want_fused and self.window:
             k = self.eng.plan_philox_fused(self.sweep0 + r0 * self.S, (r1 - r0) * (self.S // self.window), self.window, self.seed)
             if k == (r1 - r0) * (self.S // self.window):

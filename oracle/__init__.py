@@ -56,6 +56,12 @@ def lib():
         L.nlo_exp2_f32.argtypes = [ctypes.c_float]
         L.nlo_exp2_f64.restype = ctypes.c_double
         L.nlo_exp2_f64.argtypes = [ctypes.c_double]
+        L.nlo_field_scale.restype = ctypes.c_int
+        L.nlo_field_scale.argtypes = [ctypes.c_int, _i32p, _f64p, _f64p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        L.nlo_threshold_f32.restype = ctypes.c_float
+        L.nlo_threshold_f32.argtypes = [ctypes.c_uint32]
+        L.nlo_threshold_count.restype = ctypes.c_uint64
+        L.nlo_threshold_count.argtypes = [ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]
         L.nlo_sweeps_philox.restype = ctypes.c_int
         L.nlo_sweeps_philox.argtypes = [ctypes.c_int, _i32p, _i32p, _f64p, _f64p, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_uint32, _f64p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
@@ -133,6 +139,30 @@ def philox(c0, c1, c2, c3, k0, k1):
 LOG2E = 1.4426950408889634
 
 
+def field_scale(csr, h):
+    """(qs, escale) of the "f32" throughput mode: couplings are held as rint(J 2^qs) (24-bit fixed point), energies as
+    integers in units of 2^-escale (restated from nlmc_create)."""
+    qs, es = ctypes.c_int(0), ctypes.c_int(0)
+    lib().nlo_field_scale(csr.n, csr.indptr, csr.data, np.ascontiguousarray(h, dtype=np.float64).reshape(-1),
+                          ctypes.byref(qs), ctypes.byref(es))
+    return int(qs.value), int(es.value)
+
+
+def threshold(r):
+    """W(r) ~= log2((1-u)/u), u = (r + 1/2) / 2^32: the logistic threshold of the "f32" throughput mode."""
+    return float(lib().nlo_threshold_f32(int(r) & 0xFFFFFFFF))
+
+
+def threshold_count(z, r0=0, r1=1 << 32, stride=1):
+    """Number of r on the lattice r0, r0 + stride, ... < r1 with z < W(r)  (s' = +1 at that z)."""
+    return int(lib().nlo_threshold_count(float(z), int(r0), int(r1), int(stride)))
+
+
+def threshold_cdf(z, stride=1):
+    """P(s' = +1 | z) estimated on every `stride`-th of the 2^32 values of r."""
+    return threshold_count(z, 0, 1 << 32, stride) / float(-(-(1 << 32) // stride))
+
+
 def cb_pair(beta, temp_x=1.0, use_f64=False):
     """(T)(-2 log2(e) beta) for normal and `scaled` spins, rounded like the product does at upload."""
     a = -2.0 * LOG2E * float(beta)
@@ -153,8 +183,10 @@ def sweeps_philox(csr, h, s_start, cb_run, seed, chain_id, order_group=0, sweep0
     M = np.empty((S, n), dtype=np.int8) if want_M else None
     tr = np.empty(S, dtype=np.int64)
     fl = None if flags is None else np.ascontiguousarray(flags, dtype=np.uint8)
-    lib().nlo_sweeps_philox(n, csr.indptr, csr.indices, csr.data, np.ascontiguousarray(h, dtype=np.float64).reshape(-1),
-                            int(bool(use_f64)), S, int(sweep0), cb_run, int(seed) & 0xFFFFFFFF,
-                            (int(seed) >> 32) & 0xFFFFFFFF, int(chain_id), int(order_group), _ptr(fl), int(escale),
-                            s, ef, _ptr(M), _ptr(tr))
+    rc = lib().nlo_sweeps_philox(n, csr.indptr, csr.indices, csr.data, np.ascontiguousarray(h, dtype=np.float64).reshape(-1),
+                                 int(bool(use_f64)), S, int(sweep0), cb_run, int(seed) & 0xFFFFFFFF,
+                                 (int(seed) >> 32) & 0xFFFFFFFF, int(chain_id), int(order_group), _ptr(fl), int(escale),
+                                 s, ef, _ptr(M), _ptr(tr))
+    if rc != 0:
+        raise ValueError("escale outside [qs, qs + 29] of this instance (oracle.field_scale)")
     return M, s, tr

@@ -16,8 +16,11 @@
  *   nlo_clusters        NPT/apt_ICM.py:116-143: connected components of the disagreement sub-graph,
  *                       ordered by ascending smallest member.
  *   nlo_sweeps_philox   NOT a reference function: the sequential *specification* of the product's throughput
- *                       mode (Philox4x32-10 order keys + uniforms, fp32/fp64 field, base-2 logistic test).
- *                       The HIP kernels run a level-parallel schedule that must reproduce it bit for bit.
+ *                       mode (Philox4x32-10 order keys + uniforms; "f32": 24-bit fixed-point couplings, exact int32
+ *                       field, logistic threshold drawn from 32 random bits; "f64": fp64 field, base-2 logistic test
+ *                       on a 53-bit uniform).  The HIP kernels run a level-parallel schedule that must reproduce it
+ *                       bit for bit.  Its LAW is tied to the reference by tests/test_law_cpu.py (exhaustive check of
+ *                       the threshold distribution) and by the reference-derived statistics under tests/golden/.
  */
 #include <math.h>
 #include <stdint.h>
@@ -184,6 +187,102 @@ static inline double exp2_spec_f64(double z)
 float nlo_exp2_f32(float z) { return exp2_spec_f32(z); }
 double nlo_exp2_f64(double z) { return exp2_spec_f64(z); }
 
+/* ------------------------------------------------------------------------------------------------ */
+/* "f32" throughput mode: fixed-point couplings and the logistic threshold                            */
+/* ------------------------------------------------------------------------------------------------ */
+/* Field scale qs and energy scale escale of an instance (restated from nlmc_create, csrc/nlmc.hip):
+ *   Jq_e = rint(J_e 2^qs), hq_k = rint(h_k 2^qs) with qs the largest exponent such that every |Jq_e| <= 2^23 - 1
+ *   (signed 24-bit multiplier) and every row sum  sum_e |Jq_e| + |hq_k| <= 2^31 - 1  (the field is an exact int32);
+ *   escale0 = clamp(60 - ceil_log2(sum|J|/2 + sum|h|), 0, 52);  qs <= escale0;  escale = min(escale0, qs + 29)
+ *   (an energy delta is the int32 field times +-2^(escale - qs + 1), one 32 x 32 -> 64 bit multiply-add). */
+static int64_t rint_scaled(double v, int qs) { return (int64_t)llrint(ldexp(v, qs)); }
+
+int nlo_field_scale(int n, const int32_t *rowptr, const double *val, const double *h, int *qs_out, int *escale_out)
+{
+    const int64_t nnz = rowptr[n];
+    double maxabs = 0.0, bound = 0.0;
+    for (int64_t e = 0; e < nnz; ++e) { maxabs = fmax(maxabs, fabs(val[e])); bound += fabs(val[e]) * 0.5; }
+    double maxh = 0.0;
+    for (int k = 0; k < n; ++k) { maxh = fmax(maxh, fabs(h[k])); bound += fabs(h[k]); }
+    int exb = 0;
+    frexp(fmax(bound, 1.0), &exb);
+    int escale0 = 60 - exb;
+    if (escale0 < 0) escale0 = 0;
+    if (escale0 > 52) escale0 = 52;
+    int qs = 0;
+    const double ref = maxabs > 0.0 ? maxabs : maxh;
+    if (ref > 0.0) {
+        int ex = 0;
+        frexp(ref, &ex);
+        qs = 23 - ex;
+        if (qs > escale0) qs = escale0;
+        for (;;) {
+            int ok = 1;
+            for (int k = 0; k < n && ok; ++k) {
+                int64_t row = llabs(rint_scaled(h[k], qs));
+                for (int e = rowptr[k]; e < rowptr[k + 1]; ++e) {
+                    const int64_t q = llabs(rint_scaled(val[e], qs));
+                    if (q > 8388607) ok = 0;
+                    row += q;
+                }
+                if (row > 2147483647LL) ok = 0;
+            }
+            if (ok) break;
+            --qs;
+        }
+    }
+    int escale = escale0 < qs + 29 ? escale0 : qs + 29;
+    if (qs_out) *qs_out = qs;
+    if (escale_out) *escale_out = escale;
+    return 0;
+}
+
+/* log2(1.5 + t) on |t| <= 0.5: degree-7 minimax fit, fmaf Horner (max error 3.8e-7) */
+static inline float log2_15_spec(float t)
+{
+    float p = 0x1.e444e6p-7f;
+    p = fmaf(p, t, -0x1.9b9e5ap-6f);
+    p = fmaf(p, t, 0x1.32e57ap-5f);
+    p = fmaf(p, t, -0x1.2122a4p-4f);
+    p = fmaf(p, t, 0x1.23e4dep-3f);
+    p = fmaf(p, t, -0x1.4853d8p-2f);
+    p = fmaf(p, t, 0x1.ec7086p-1f);
+    p = fmaf(p, t, 0x1.2b803ep-1f);
+    return p;
+}
+
+/* Logistic threshold of one update from 32 random bits r:  W(r) ~= log2((1 - u) / u),  u = (r + 1/2) / 2^32.
+ * The heat-bath rule  s' = +1  iff  u < 1 / (1 + exp(-2 beta x))  (NMC/nmc.py:87 with the centred uniform) reads
+ * s' = +1  iff  z < W(r),  z = -2 log2(e) beta x.  Built from v = min(u, 1 - u) so that W(~r) == -W(r) exactly
+ * (the law is symmetric under a global spin flip); IEEE single operations only, identical bits on CPU and GPU. */
+static inline float threshold_spec_f32(uint32_t r)
+{
+    const uint32_t m = (uint32_t)((int32_t)r >> 31);      /* all ones iff u > 1/2 */
+    const uint32_t a = r ^ m;                             /* v = (a + 1/2) / 2^32 in (0, 1/2) */
+    const float v = fmaf((float)a, 0x1p-32f, 0x1p-33f);
+    union { float f; uint32_t u; } b;
+    b.f = v;
+    const float ef = (float)((int32_t)(b.u >> 23) - 126); /* v = mant 2^(ef - 1), mant in [1, 2) */
+    b.u = (b.u & 0x7FFFFFu) | 0x3F800000u;
+    const float t1 = b.f - 1.5f;                          /* log2 v       = (ef - 1) + log2(1.5 + t1) */
+    const float t2 = fmaf(v, -2.0f, 0.5f);                /* log2 (1 - v) = -1 + log2(1.5 + t2)       */
+    const float w = (log2_15_spec(t2) - log2_15_spec(t1)) - ef;
+    union { float f; uint32_t u; } o;
+    o.f = w;
+    o.u = (o.u & 0x7FFFFFFFu) | (r & 0x80000000u);        /* |w| with the sign of (u - 1/2) */
+    return o.f;
+}
+
+float nlo_threshold_f32(uint32_t r) { return threshold_spec_f32(r); }
+
+/* number of r in [r0, r1) on the lattice r0 + i*stride with z < W(r)  (tests/test_law_cpu.py) */
+uint64_t nlo_threshold_count(float z, uint64_t r0, uint64_t r1, uint32_t stride)
+{
+    uint64_t cnt = 0;
+    for (uint64_t r = r0; r < r1; r += stride) cnt += (z < threshold_spec_f32((uint32_t)r));
+    return cnt;
+}
+
 typedef struct { uint32_t key; int32_t idx; } keyed_t;
 static int keyed_cmp(const void *a, const void *b)
 {
@@ -194,14 +293,16 @@ static int keyed_cmp(const void *a, const void *b)
 
 /* Sequential specification of the product's throughput mode, one chain.
  *   order of sweep t   : spins sorted by (philox(k, t, order_group, ORDER)[0], k)
- *   uniform of (t, k)  : f32: 24 high bits of word (k&3) of philox(k>>2, t, chain_id, UNIFORM);
- *                        f64: 53 bits from words (2(k&1), 2(k&1)+1) of philox(k>>1, t, chain_id, UNIFORM)
- *   field              : x = ((0 + J_e0 s_c0) + J_e1 s_c1 ...) + h_k     in precision T
- *   test               : z = cb * x ; e = exp2_spec(z) ; s' = (fma(u, e, u) < 1) ? +1 : -1
- *                        cb = (T)(-2 log2(e) beta), beta = flags==1 ? beta_scaled : beta  (rounded by the caller)
  *   flags[k]           : 0 normal, 1 scaled (cluster spin at beta/temp_x), 2/3 frozen (never updated)
- *   energy             : fixed point, E_fix += llrint(-(s'-s) * x * 2^escale) on every flip
- * val/h are given in double and rounded to T here (the product rounds the same way at upload).
+ *   "f32" (use_f64 = 0): couplings in 24-bit fixed point (nlo_field_scale), field X = hq_k + sum_e Jq_e s_c(e) exact
+ *                        in int32 (any summation order);  z = cbq * (float)X,  cbq = (float)cb * 2^-qs;
+ *                        s' = +1 iff z < W(r),  r = word (k&3) of philox(k>>2, t, chain_id, UNIFORM) (threshold_spec_f32);
+ *                        energy: E_fix += (s - s') * X_offdiag * 2^(escale - qs) on every flip (exact).
+ *   "f64" (use_f64 = 1): field x = ((0 + J_e0 s_c0) + J_e1 s_c1 ...) + h_k in double;  u = 53 bits from words
+ *                        (2(k&1), 2(k&1)+1) of philox(k>>1, t, chain_id, UNIFORM);  z = cb * x;
+ *                        s' = (fma(u, exp2_spec(z), u) < 1) ? +1 : -1;  E_fix += llrint(-(s'-s) * x * 2^escale).
+ *   cb = (T)(-2 log2(e) beta), beta = flags==1 ? beta_scaled : beta  (rounded by the caller)
+ * Returns -1 when escale is not in [qs, qs + 29] in f32 mode.
  */
 int nlo_sweeps_philox(int n, const int32_t *rowptr, const int32_t *col, const double *val, const double *h,
                       int use_f64, int num_sweeps, uint32_t sweep0, const double *cb_run /*[num_sweeps][2]*/,
@@ -210,13 +311,16 @@ int nlo_sweeps_philox(int n, const int32_t *rowptr, const int32_t *col, const do
                       int8_t *M_out /*nullable [num_sweeps][n]*/, int64_t *efix_trace /*nullable [num_sweeps]*/)
 {
     keyed_t *ord = (keyed_t *)malloc(sizeof(keyed_t) * (size_t)(n > 0 ? n : 1));
-    float *valf = NULL, *hf = NULL;
+    int32_t *valq = NULL, *hq = NULL;
     const int64_t nnz = rowptr[n];
+    int qs = 0;
     if (!use_f64) {
-        valf = (float *)malloc(sizeof(float) * (size_t)(nnz > 0 ? nnz : 1));
-        hf = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
-        for (int64_t e = 0; e < nnz; ++e) valf[e] = (float)val[e];
-        for (int k = 0; k < n; ++k) hf[k] = (float)h[k];
+        nlo_field_scale(n, rowptr, val, h, &qs, NULL);
+        if (escale < qs || escale > qs + 29) { free(ord); return -1; }
+        valq = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1));
+        hq = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+        for (int64_t e = 0; e < nnz; ++e) valq[e] = (int32_t)rint_scaled(val[e], qs);
+        for (int k = 0; k < n; ++k) hq[k] = (int32_t)rint_scaled(h[k], qs);
     }
     int64_t efix = efix_io ? *efix_io : 0;
     const double esc = ldexp(1.0, escale);
@@ -236,7 +340,8 @@ int nlo_sweeps_philox(int n, const int32_t *rowptr, const int32_t *col, const do
             /* one Philox call serves 4 (f32) / 2 (f64) consecutive spins */
             philox4x32_10((uint32_t)(use_f64 ? (k >> 1) : (k >> 2)), tt, chain_id, NLMC_TAG_UNIFORM, seed_lo, seed_hi, r);
             int accept;
-            double xd;
+            double xd = 0.0;
+            int32_t Xq = 0;
             if (use_f64) {
                 double x = 0.0, xdg = 0.0; /* xdg: diagonal term, excluded from the energy delta */
                 for (int e = rowptr[k]; e < rowptr[k + 1]; ++e) {
@@ -252,22 +357,21 @@ int nlo_sweeps_philox(int n, const int32_t *rowptr, const int32_t *col, const do
                 const double ee = exp2_spec_f64(z);
                 accept = fma(u, ee, u) < 1.0;
             } else {
-                float x = 0.0f, xdg = 0.0f;
+                int32_t X = hq[k], Xdg = 0;
                 for (int e = rowptr[k]; e < rowptr[k + 1]; ++e) {
-                    const float tm = valf[e] * (float)s[col[e]];
-                    x += tm;
-                    if (col[e] == k) xdg += tm;
+                    const int32_t tm = valq[e] * (int32_t)s[col[e]];
+                    X += tm;
+                    if (col[e] == k) Xdg += tm;
                 }
-                xd = (double)((x - xdg) + hf[k]);
-                x = x + hf[k];
-                const float u = (float)(r[k & 3] >> 8) * 5.9604644775390625e-08f;
-                const float z = (float)cb_run[2 * t + (fl == 1u)] * x;
-                const float ee = exp2_spec_f32(z);
-                accept = fmaf(u, ee, u) < 1.0f;
+                Xq = X - Xdg;
+                const float cbq = ldexpf((float)cb_run[2 * t + (fl == 1u)], -qs);
+                const float z = cbq * (float)X;
+                accept = z < threshold_spec_f32(r[k & 3]);
             }
             const int8_t sn = accept ? 1 : -1;
             if (sn != s[k]) {
-                efix += llrint(-(double)(sn - s[k]) * xd * esc);
+                if (use_f64) efix += llrint(-(double)(sn - s[k]) * xd * esc);
+                else efix += (int64_t)(s[k] - sn) * (int64_t)Xq * ((int64_t)1 << (escale - qs));
                 s[k] = sn;
             }
         }
@@ -276,7 +380,7 @@ int nlo_sweeps_philox(int n, const int32_t *rowptr, const int32_t *col, const do
     }
     if (efix_io) *efix_io = efix;
     free(ord);
-    free(valf);
-    free(hf);
+    free(valq);
+    free(hq);
     return 0;
 }

@@ -7,7 +7,6 @@ import numpy as np
 
 import oracle
 from oracle import pt as opt
-from helpers import energy_scale
 
 
 class OracleEngine:
@@ -15,7 +14,7 @@ class OracleEngine:
         self.csr = oracle.Csr.from_parts(inst.n, inst.indptr, inst.indices, inst.data)
         self.h = inst.h
         self.n, self.n_chains, self.chain_base, self.G = inst.n, n_chains, chain_base, n_chains_global
-        self.esc = energy_scale(inst.data, inst.h)
+        self.esc = oracle.field_scale(self.csr, inst.h)[1]
         self.spins = np.ones((n_chains, inst.n), np.int8)
         self.efix = np.zeros(n_chains, np.int64)
 

@@ -37,10 +37,11 @@ def init_spins(R, N, base=1000):
     return out
 
 
-def energy_scale(data, h):
-    bound = float(np.sum(np.abs(data)) * 0.5 + np.sum(np.abs(h)))
-    ex = math.frexp(max(bound, 1.0))[1]
-    return max(0, min(52, 60 - ex))
+def energy_scale(csr, h):
+    """log2 of the engine's fixed-point energy scale for oracle.Csr `csr` (nlmc_create's rule, restated in
+    oracle/nlo.c:nlo_field_scale)."""
+    import oracle
+    return oracle.field_scale(csr, h)[1]
 
 
 def draw_stream(R, S, N):
