@@ -42,13 +42,14 @@ struct nlmc_ctx {
     int64_t nnz = 0;
     int n_chains = 0, chain_base = 0, n_chains_global = 0;
     int escale = 32;
+    bool compact16 = false;            // every Jq fits 16 bits: fused-window schedules use 4-byte entries
     int qs = 0;                        // field scale of the fixed-point ("f32") path: Jq = rint(J 2^qs)
     double *energy_sink = nullptr;     // device buffer the sweep kernels also write the tracked energies to
     double temp_x = 1.0;
     bool has_flags = false;
     bool has_diag = false;
     bool has_zero_vals = false;   // a stored entry is 0.0 (or underflows to 0 in fp32)
-    size_t lds_opt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // dynamic-LDS opt-in already granted per kernel
+    size_t lds_opt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // dynamic-LDS opt-in already granted per kernel
 
     DevBuf<int32_t> rowptr, col;
     DevBuf<double> val64, h64;
@@ -100,7 +101,10 @@ struct nlmc_ctx {
     uint32_t fz_sweep0 = 0;
     int fz_windows = 0, fz_T = 0, fz_workers = 13;
     uint64_t fz_seed = 0;
-    std::vector<int32_t> fz_nlev_host;
+    std::vector<int32_t> fz_nlev_host, fz_npos_host;
+    int fz_pstride = 0, fz_gen0 = 0;
+    bool fz_compact = false;          // the current fused plan was written with 4-byte entries
+    DevBuf<int32_t> fz_npos;
     DevBuf<uint16_t> fz_glv;
     DevBuf<uint32_t> fz_perm;
     DevBuf<uint16_t> fz_adj;
@@ -261,23 +265,30 @@ int fused_workers(int nt)
     return 13;
 }
 
-// LDS of k_sweep_fused: spins | flags | 3 uniform tables | level offsets | sweep ends | reduction scratch
-struct FusedLds { int flags_off, u_off, u_bytes, loff_off, send_off, red_off; size_t total; };
+// LDS of k_sweep_fused: spins (+16: scratch spin of the dummy items) | flags (+16) | 3 threshold tables | reduction scratch
+struct FusedLds { int flags_off, u_off, u_bytes, red_off; size_t total; };
 FusedLds fused_lds(int n, int n_pad, bool has_flags, int T)
 {
+    (void)T;
     FusedLds L{};
-    L.flags_off = n_pad;
-    int cur = n_pad * (has_flags ? 2 : 1);
+    L.flags_off = n_pad + 16;
+    int cur = (n_pad + 16) * (has_flags ? 2 : 1);
     cur = (cur + 15) / 16 * 16;
     L.u_off = cur;
     L.u_bytes = (((n + 3) / 4 * 4) * 4 + 15) / 16 * 16;
     cur += 3 * L.u_bytes;
-    L.loff_off = cur; cur += (NLMC_LCAP + 1) * 4;
-    cur = (cur + 15) / 16 * 16;
-    L.send_off = cur; cur += ((T + 3) / 4 * 4) * 4;
     L.red_off = cur;
     L.total = (size_t)cur + 16;
     return L;
+}
+
+int fused_pstride(int n, int T) { return (int)((((size_t)T * n + 63) / 64 + NLMC_LCAP) * 64); }
+
+// first wave that produces thresholds (NLMC_FUSED_GEN0: tuning knob)
+int fused_gen0(int nt)
+{
+    if (const char *s = getenv("NLMC_FUSED_GEN0")) { const int v = atoi(s); if (v >= 0 && v < nt / 64) return v; }
+    return 0;
 }
 
 // Instances the fused kernels are built for: a sweep workgroup of at least 4 waves (3 workers + 1 helper), degree in 14 bits, three
@@ -287,17 +298,23 @@ bool fused_supported(const nlmc_ctx *c, int T)
     if (getenv("NLMC_NO_FUSED")) return false;
     if (c->n < 256 || c->n > NLMC_FZ_SPT * 1024 || c->max_deg > 0x3FFF || T < 3 || T > NLMC_FUSED_TMAX) return false;
     if ((size_t)T * c->n > ((size_t)1 << 22)) return false;            // 32-bit buffer offsets of the packed planes
-    return fused_lds(c->n, c->n_pad, true, T).total <= (size_t)150 * 1024;
+    if (c->n_pad + 16 > 0x3FFF) return false;                          // spin address in 14 bits of the item head
+    const FusedLds L = fused_lds(c->n, c->n_pad, true, T);
+    if (3 * L.u_bytes / 4 > 0xFFFF) return false;                      // threshold word index in 16 bits
+    return L.total <= (size_t)150 * 1024;
 }
 
 int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *tab_dev, int tab_cs, bool use_slots)
 {
     const int R = c->n_chains, n = c->n, T = c->fz_T;
-    const size_t TN = (size_t)T * n;
+    const size_t PS = (size_t)c->fz_pstride;
     const FusedLds L = fused_lds(c->n, c->n_pad, c->has_flags, T);
-    const void *kfun = c->has_diag ? reinterpret_cast<const void *>(k_sweep_fused<true>)
-                                   : reinterpret_cast<const void *>(k_sweep_fused<false>);
-    { int rc = ensure_lds(c, c->has_diag ? 9 : 8, kfun, L.total); if (rc) return rc; }
+    const int variant = (c->has_diag ? 2 : 0) + (c->has_flags ? 1 : 0);
+    const void *kfun = variant == 0 ? reinterpret_cast<const void *>(k_sweep_fused<false, false>)
+                       : variant == 1 ? reinterpret_cast<const void *>(k_sweep_fused<false, true>)
+                       : variant == 2 ? reinterpret_cast<const void *>(k_sweep_fused<true, false>)
+                                      : reinterpret_cast<const void *>(k_sweep_fused<true, true>);
+    { int rc = ensure_lds(c, 8 + variant, kfun, L.total); if (rc) return rc; }
     hipEvent_t e0 = next_event(c), e1 = next_event(c), e2 = next_event(c);
     if (!e0 || !e1 || !e2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
     HIP_TRY(c, hipEventRecord(e0, c->stream));
@@ -311,14 +328,21 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
     a.lvl_off = c->fz_loff.p + (size_t)w * (NLMC_LCAP + 1);
     a.nlev = c->fz_nlev.p + w;
     a.hi_max = c->fz_himax.p + w;
-    a.ell32 = c->fz_ell.p + (size_t)w * TN * NLMC_ELL_W32;
-    a.head32 = c->fz_head.p + (size_t)w * TN;
+    a.ell32 = c->fz_ell.p + (size_t)w * PS * NLMC_ELL_W32;
+    a.head32 = c->fz_head.p + (size_t)w * PS;
     a.fsend = c->fz_send.p + (size_t)w * T;
+    a.fz_pstride = c->fz_pstride;
+    a.fz_compact = c->fz_compact ? 1 : 0;
     if (w + 1 < c->fz_windows && c->fz_nlev_host[(size_t)w + 1] > 0 && !getenv("NLMC_NO_WARM")) {
-        a.warm_head = c->fz_head.p + (size_t)(w + 1) * TN;
-        a.warm_ell = c->fz_ell.p + (size_t)(w + 1) * TN * NLMC_ELL_W32;
+        a.warm_head = c->fz_head.p + (size_t)(w + 1) * PS;
+        a.warm_ell = c->fz_ell.p + (size_t)(w + 1) * PS * NLMC_ELL_W32;
+        a.fz_npos_next = c->fz_npos_host[(size_t)w + 1];
     }
     a.f_workers = c->fz_workers;
+    a.f_gen0 = c->fz_gen0;
+#ifdef NLMC_DEBUG_KNOBS
+    if (const char *e = getenv("NLMC_DBG_FLAGS")) a.dbg_flags = atoi(e);
+#endif
     a.n_sweeps = T;
     a.sweep0 = sweep0;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
@@ -332,16 +356,19 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
     a.trace_sweeps = T;
     a.rec_stride = 1;
     a.argmin = c->argmin.p;
-    a.lds_flags_off = L.flags_off; a.lds_u_off = L.u_off; a.lds_u_stride = L.u_bytes; a.lds_loff_off = L.loff_off;
-    a.lds_send_off = L.send_off; a.lds_red_off = L.red_off;
+    a.lds_flags_off = L.flags_off; a.lds_u_off = L.u_off; a.lds_u_stride = L.u_bytes; a.lds_red_off = L.red_off;
 #ifdef NLMC_STAMPS
     HIP_TRY(c, c->dbg.reserve((size_t)R * 16 * 8 + 96));
     HIP_TRY(c, hipMemsetAsync(c->dbg.p, 0, ((size_t)R * 16 * 8 + 96) * sizeof(long long), c->stream));
     a.dbg = c->dbg.p;
 #endif
     const int nt = fused_block(n);
-    if (c->has_diag) hipLaunchKernelGGL((k_sweep_fused<true>), dim3(R), dim3(nt), L.total, c->stream, a);
-    else hipLaunchKernelGGL((k_sweep_fused<false>), dim3(R), dim3(nt), L.total, c->stream, a);
+    switch (variant) {
+    case 0: hipLaunchKernelGGL((k_sweep_fused<false, false>), dim3(R), dim3(nt), L.total, c->stream, a); break;
+    case 1: hipLaunchKernelGGL((k_sweep_fused<false, true>), dim3(R), dim3(nt), L.total, c->stream, a); break;
+    case 2: hipLaunchKernelGGL((k_sweep_fused<true, false>), dim3(R), dim3(nt), L.total, c->stream, a); break;
+    default: hipLaunchKernelGGL((k_sweep_fused<true, true>), dim3(R), dim3(nt), L.total, c->stream, a); break;
+    }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(e2, c->stream));
     c->launches_sweep++;
@@ -674,13 +701,25 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
             if (ok) break;
             --qs;
         }
+        for (;;) {       // canonical form: drop the power of two common to every Jq and hq (+-J instances: Jq = +-1)
+            bool even = true, any = false;
+            for (int64_t e = 0; e < nnz && even; ++e) { const int64_t q = rq(vals[e], qs); if (q & 1) even = false; if (q) any = true; }
+            for (int k = 0; k < n && even; ++k) { const int64_t q = rq(h[k], qs); if (q & 1) even = false; if (q) any = true; }
+            if (!even || !any) break;
+            --qs;
+        }
     }
     c->qs = qs;
     c->escale = std::min(escale0, qs + 29);
 
     std::vector<EdgeQ> e32((size_t)std::max<int64_t>(nnz, 1));
     std::vector<int32_t> hq((size_t)n);
-    for (int64_t e = 0; e < nnz; ++e) { e32[e].col = colidx[e]; e32[e].q = (int32_t)rq(vals[e], qs); }
+    bool fits16 = n <= 65535;        // compact schedule entries of the fused windows: col << 16 | (Jq & 0xFFFF)
+    for (int64_t e = 0; e < nnz; ++e) {
+        e32[e].col = colidx[e]; e32[e].q = (int32_t)rq(vals[e], qs);
+        if (e32[e].q > 32767 || e32[e].q < -32768) fits16 = false;
+    }
+    c->compact16 = fits16 && !getenv("NLMC_NO_COMPACT");
     for (int k = 0; k < n; ++k) hq[k] = (int32_t)rq(h[k], qs);
 
     CT(c->rowptr.reserve((size_t)n + 1));
@@ -746,7 +785,7 @@ void nlmc_destroy(nlmc_ctx *c)
     c->argmin.release(); c->energy.release(); c->tab.release(); c->ustream.release(); c->etrace_d.release();
     c->keys.release(); c->strace.release(); c->cfg.release(); c->scratch.release(); c->plan.release();
     c->fz_glv.release(); c->fz_perm.release(); c->fz_adj.release(); c->fz_stats.release(); c->fz_head.release(); c->fz_ell.release(); c->fz_loff.release(); c->fz_nlev.release();
-    c->fz_himax.release(); c->fz_send.release();
+    c->fz_himax.release(); c->fz_send.release(); c->fz_npos.release();
     c->lbp_src.release(); c->lbp_rev.release(); c->lbp_flag.release(); c->lbp_out_i.release(); c->lbp_tJ.release();
     c->lbp_eps.release(); c->lbp_ms.release(); c->lbp_lams.release(); c->lbp_w0.release(); c->lbp_w1.release();
     c->lbp_hm.release(); c->lbp_tot.release(); c->lbp_mag.release(); c->lbp_mag_all.release();
@@ -989,13 +1028,16 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     if (n_windows == 0 || !fused_supported(c, window)) return NLMC_OK;
     const int n = c->n, T = window;
     const size_t W = (size_t)n_windows, TN = (size_t)T * n;
+    c->fz_pstride = fused_pstride(n, T);
+    const size_t PS = (size_t)c->fz_pstride;
     HIP_TRY(c, c->fz_glv.reserve(W * TN));
-    HIP_TRY(c, c->fz_perm.reserve(W * TN));
+    HIP_TRY(c, c->fz_perm.reserve(W * PS));
     { int rc = ensure_adjacency(c); if (rc) return rc; }
-    HIP_TRY(c, c->fz_head.reserve(W * TN));
-    HIP_TRY(c, c->fz_ell.reserve(W * TN * NLMC_ELL_W32));
+    HIP_TRY(c, c->fz_head.reserve(W * PS));
+    HIP_TRY(c, c->fz_ell.reserve(W * PS * NLMC_ELL_W32));
     HIP_TRY(c, c->fz_loff.reserve(W * (NLMC_LCAP + 1)));
     HIP_TRY(c, c->fz_nlev.reserve(W));
+    HIP_TRY(c, c->fz_npos.reserve(W));
     HIP_TRY(c, c->fz_himax.reserve(W));
     HIP_TRY(c, c->fz_send.reserve(W * T));
     FusedLevelizeArgs a{};
@@ -1003,12 +1045,18 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     a.T = T;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.sweep0 = sweep0;
     c->fz_workers = fused_workers(fused_block(c->n));
+    c->fz_gen0 = fused_gen0(fused_block(c->n));
     a.level_cap = c->fz_workers * 64;
+    a.pstride = c->fz_pstride;
+    a.tab_words = fused_lds(c->n, c->n_pad, true, T).u_bytes / 4;
+    a.k_dummy = c->n_pad;
+    a.compact = c->compact16 ? 1 : 0;
+    c->fz_compact = c->compact16;
     a.adj = reinterpret_cast<const uint4 *>(c->fz_adj.p); a.glv = c->fz_glv.p; a.perm = c->fz_perm.p; a.head = c->fz_head.p; a.ell = c->fz_ell.p; a.loff = c->fz_loff.p; a.nlev = c->fz_nlev.p;
-    a.hi_max = c->fz_himax.p; a.send = c->fz_send.p;
+    a.hi_max = c->fz_himax.p; a.send = c->fz_send.p; a.npos = c->fz_npos.p;
     const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
     const size_t lds = (size_t)n * 8 + n4 * 2 + n4 + n4 * 2 + 2 * (size_t)(NLMC_LCAP + 2) * 4 + 16;
-    { int rc = ensure_lds(c, 10, reinterpret_cast<const void *>(k_levelize_fused), lds); if (rc) return rc; }
+    { int rc = ensure_lds(c, 12, reinterpret_cast<const void *>(k_levelize_fused), lds); if (rc) return rc; }
     const bool fz_diag = getenv("NLMC_FZ_STATS") != nullptr;     // diagnostic: phase cycle counts of window 0 on stderr
     if (fz_diag) { HIP_TRY(c, c->fz_stats.reserve(W * 8)); a.stats = c->fz_stats.p; }
     // planning time counts as levelize time of the accumulating timer (nlmc_timing_total): an event triple whose
@@ -1023,7 +1071,9 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     HIP_TRY(c, hipGetLastError());
     if (pe0) { HIP_TRY(c, hipEventRecord(pe1, c->stream)); HIP_TRY(c, hipEventRecord(pe2, c->stream)); }
     c->fz_nlev_host.assign(W, 0);
+    c->fz_npos_host.assign(W, 0);
     HIP_TRY(c, hipMemcpyAsync(c->fz_nlev_host.data(), c->fz_nlev.p, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->fz_npos_host.data(), c->fz_npos.p, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (fz_diag) {
         long long st[8] = {0};

@@ -211,16 +211,21 @@ struct FusedLevelizeArgs {
     int T;                    // sweeps per window
     uint32_t seed_lo, seed_hi, sweep0;     // window w covers sweeps sweep0 + w T ... + T - 1 (shared order, group 0)
     int level_cap;            // 64 x worker waves of k_sweep_fused
+    int pstride;              // schedule positions reserved per window (multiple of 64, >= T n + 64 NLMC_LCAP)
+    int tab_words;            // 4-byte words per threshold table of k_sweep_fused (its LDS stride / 4)
+    int k_dummy;              // LDS address of the scratch spin that dummy (padding) items update: n_pad
+    int compact;              // every Jq fits 16 bits: planes hold 4 entries of 4 bytes, col << 16 | (Jq & 0xFFFF)
     const uint4 *adj;         // [n][2]: the first 16 neighbours of every spin as 16-bit indices (k_fused_adjacency)
     uint16_t *glv;            // scratch [n_windows][T][n]: level of update (t, k), 1-based
-    uint32_t *perm;           // scratch [n_windows][T n]: item id k | t << 16 at its position
+    uint32_t *perm;           // scratch [n_windows][pstride]: item id k | t << 16 at its position, ~0 = padding
     long long *stats;         // diagnostic (NLMC_FZ_STATS): [n_windows][8] cycles keys / init / passes, pass count, place 1 / 2
-    int2 *head;               // [n_windows][T n]   { k | deg << 16 | (t mod 3) << 30, hq_k }
-    EdgeQ *ell;               // [n_windows][8][T n][2]   row window planes, position-minor
-    int32_t *loff;            // [n_windows][NLMC_LCAP + 1] published level offsets
+    int2 *head;               // [n_windows][pstride]   { k | LONG << 14 | threshold word << 16, hq_k }
+    EdgeQ *ell;               // [n_windows][8][pstride][2]   row window planes, position-minor
+    int32_t *loff;            // [n_windows][NLMC_LCAP + 1] published level offsets, in chunks of 64 positions
     int32_t *nlev;            // [n_windows] published levels; 0 = deeper than NLMC_LCAP - 1 (caller falls back)
-    int32_t *hi_max;          // [n_windows] most rows longer than 8 entries in any level
+    int32_t *hi_max;          // [n_windows] leading chunks of a level that may hold rows longer than 8 entries
     int32_t *send;            // [n_windows][T] published index of the last level that holds an item of sweep t
+    int32_t *npos;            // [n_windows] schedule positions in use (multiple of 64)
 };
 
 // 16-bit neighbour lists, 32 B per spin (absent slots hold the spin's own index, which every consumer skips): one
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
     uint32_t *hist = reinterpret_cast<uint32_t *>(queue + n4);
     uint32_t *histL = hist + NLMC_LCAP + 2;
     __shared__ int sh_lmax[NLMC_FUSED_TMAX];
-    __shared__ int sh_max, sh_fail, sh_nlev, sh_qn;
+    __shared__ int sh_max, sh_fail, sh_nlev, sh_qn, sh_npos;
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int k = tid; k < n; k += nt) g[k] = 0;
     for (int l = tid; l < 2 * (NLMC_LCAP + 2); l += nt) hist[l] = 0u;      // hist and histL are adjacent
@@ -363,7 +368,11 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
         __syncthreads();
     }
 
-    // publish offsets: levels 1..L in order, each split into chunks of level_cap; hist[lv] becomes the level's start
+    // publish offsets.  Positions are handed out in CHUNKS of 64 (one wave's items of one level): every level starts on
+    // a chunk boundary and its last chunk is padded with dummy items, so that the sweep kernel never deals with a
+    // partly filled wave (no per-lane validity: a wave either holds a chunk of a level or it does not).  Levels wider
+    // than level_cap (a multiple of 64) are split.  off[] counts chunks; hist[lv] becomes the level's first position,
+    // histL[lv] (was: its number of long rows) the position behind its last real item.
     if (tid == 0) {
         const int L = sh_lmax[T - 1];
         int32_t *off = a.loff + (size_t)w * (NLMC_LCAP + 1);
@@ -372,30 +381,34 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
             for (int lv = 1; lv <= L; ++lv) {
                 const int cnt = (int)hist[lv];
                 hist[lv] = (uint32_t)run;
-                himax = max(himax, (int)histL[lv]);
-                for (int p = 0; p < cnt; p += a.level_cap) { if (m < NLMC_LCAP) off[m] = run + p; ++m; }
-                run += cnt;
+                himax = max(himax, ((int)histL[lv] + 63) >> 6);
+                histL[lv] = (uint32_t)(run + cnt);
+                for (int p = 0; p < cnt; p += a.level_cap) { if (m < NLMC_LCAP) off[m] = (run + p) >> 6; ++m; }
+                run += (cnt + 63) & ~63;
                 while (t_next < T && sh_lmax[t_next] == lv) a.send[(size_t)w * T + t_next++] = m - 1;
             }
-            hist[L + 1] = (uint32_t)run;
-            if (m >= NLMC_LCAP) sh_fail = 1; else off[m] = run;
+            if (m >= NLMC_LCAP || run > a.pstride) sh_fail = 1; else off[m] = run >> 6;
         }
         sh_nlev = sh_fail ? 0 : m;
+        sh_npos = run;
         a.nlev[w] = sh_nlev;
-        a.hi_max[w] = himax;
+        a.npos[w] = run;
+        a.hi_max[w] = min(himax, a.level_cap >> 6);
     }
     __syncthreads();
     if (sh_nlev == 0) return;
 
-    // placement: rows longer than 8 entries from the front of their level, the others from the back
-    for (int l = tid; l <= NLMC_LCAP; l += nt) histL[l] = hist[l + 1];     // back cursor of level l = start of level l+1
-    __syncthreads();
+    // placement: rows longer than 8 entries from the front of their level, the others from the back of its real items.
     // Two steps so that the 136 B per update are written with coalesced stores: (1) scatter the 4-byte item ids to
     // their positions, (2) position-major: lane p gathers row k(p) (CSR is cache resident) and writes head[p] and the
     // planes [q][p] next to its neighbours' -- a direct scatter of 16-byte pieces ran at a tenth of the bandwidth.
-    const size_t TN = (size_t)T * n;
+    const int npos = sh_npos;
+    const size_t PS = (size_t)a.pstride;
     long long p0 = (long long)__builtin_readcyclecounter();
-    uint32_t *perm = a.perm + (size_t)w * TN;
+    uint32_t *perm = a.perm + (size_t)w * PS;
+    for (int pos = tid; pos < npos; pos += nt) perm[pos] = 0xFFFFFFFFu;       // padding = dummy items
+    __threadfence_block();
+    __syncthreads();
     for (int t = 0; t < T; ++t) {
         for (int k = tid; k < n; k += nt) {
             const int lv = (int)glv[(size_t)t * n + k];
@@ -408,21 +421,45 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
     __syncthreads();
     long long p1 = (long long)__builtin_readcyclecounter();
     st[4] = p1 - p0;
-    int2 *head = a.head + (size_t)w * TN;
-    int4 *ell = reinterpret_cast<int4 *>(a.ell) + (size_t)w * (NLMC_ELL_W32 / 2) * TN;
-    for (size_t pos = tid; pos < TN; pos += nt) {
+    // head.x = k | LONG << 14 | thr << 16: k = LDS address of the spin, LONG = row longer than the 16-entry window,
+    // thr = word index of the update's threshold in the three LDS tables (slot t mod 3); head.y = hq_k.
+    // A dummy item updates the scratch spin behind the real ones from an all-zero row: harmless by construction.
+    int2 *head = a.head + (size_t)w * PS;
+    int4 *ell = reinterpret_cast<int4 *>(a.ell) + (size_t)w * (NLMC_ELL_W32 / 2) * PS;
+    for (int pos = tid; pos < npos; pos += nt) {
         const uint32_t it = perm[pos];
+        const uint32_t dpack = (uint32_t)a.k_dummy << 16;
+        if (it == 0xFFFFFFFFu) {
+            head[pos] = make_int2(a.k_dummy, 0);
+            if (a.compact) {
+#pragma unroll
+                for (int q = 0; q < NLMC_ELL_W32 / 4; ++q) ell[(size_t)q * PS + pos] = make_int4((int)dpack, (int)dpack, (int)dpack, (int)dpack);
+            } else {
+#pragma unroll
+                for (int q = 0; q < NLMC_ELL_W32; q += 2) ell[(size_t)(q / 2) * PS + pos] = make_int4(a.k_dummy, 0, a.k_dummy, 0);
+            }
+            continue;
+        }
         const int k = (int)(it & 0xFFFFu), t = (int)(it >> 16);
         const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
-        head[pos] = make_int2(k | (deg << 16) | ((t % 3) << 30), a.g.hq[k]);
+        head[pos] = make_int2(k | (deg > NLMC_ELL_W32 ? 0x4000 : 0) | (((t % 3) * a.tab_words + k) << 16), a.g.hq[k]);
         EdgeQ ed[NLMC_ELL_W32];
 #pragma unroll
         for (int q = 0; q < NLMC_ELL_W32; ++q) ed[q] = a.g.edge32[rs + q];     // unconditional (the array is padded by
-#pragma unroll                                                                  // a full window): independent loads
-        for (int q = 0; q < NLMC_ELL_W32; q += 2) {
-            const EdgeQ z{0, 0};
-            const EdgeQ e0 = q < deg ? ed[q] : z, e1 = q + 1 < deg ? ed[q + 1] : z;
-            ell[(size_t)(q / 2) * TN + pos] = make_int4(e0.col, e0.q, e1.col, e1.q);
+        if (a.compact) {                                                        // a full window): independent loads
+            uint32_t pk[NLMC_ELL_W32];
+#pragma unroll
+            for (int q = 0; q < NLMC_ELL_W32; ++q) pk[q] = q < deg ? ((uint32_t)ed[q].col << 16) | ((uint32_t)ed[q].q & 0xFFFFu) : dpack;
+#pragma unroll
+            for (int q = 0; q < NLMC_ELL_W32; q += 4)
+                ell[(size_t)(q / 4) * PS + pos] = make_int4((int)pk[q], (int)pk[q + 1], (int)pk[q + 2], (int)pk[q + 3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NLMC_ELL_W32; q += 2) {
+                const EdgeQ z{a.k_dummy, 0};
+                const EdgeQ e0 = q < deg ? ed[q] : z, e1 = q + 1 < deg ? ed[q + 1] : z;
+                ell[(size_t)(q / 2) * PS + pos] = make_int4(e0.col, e0.q, e1.col, e1.q);
+            }
         }
     }
     if (a.stats && tid == 0) {
@@ -438,6 +475,23 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
 #define NLMC_CLK(v) { __builtin_amdgcn_sched_barrier(0); v = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
 #else
 #define NLMC_CLK(v)
+#endif
+
+#ifdef NLMC_DEBUG_KNOBS
+#define NLMC_DBG_NOLOAD && !(a.dbg_flags & 4)
+#else
+#define NLMC_DBG_NOLOAD
+#endif
+#ifdef NLMC_STAMPS
+#define NLMC_FW0 NLMC_CLK(sw0)
+#define NLMC_FW1 NLMC_CLK(sw1)
+#define NLMC_FW2 NLMC_CLK(sw2) st_work += sw1 - sw0; st_bar += sw2 - sw1;
+#define NLMC_FCALL st_calls += 1;
+#else
+#define NLMC_FW0
+#define NLMC_FW1
+#define NLMC_FW2
+#define NLMC_FCALL
 #endif
 
 struct SweepArgs {
@@ -484,8 +538,13 @@ struct SweepArgs {
     const int32_t *fsend;     // [n_sweeps] published index of the last level holding an item of sweep t
     const int2 *warm_head;    // head / plane arrays of the NEXT planned window (or nullptr): pulled towards the chip by
     const EdgeQ *warm_ell;    // the helper waves while this window runs
-    int f_workers;            // waves that take schedule items; the remaining waves prepare uniforms
+    int f_workers;            // waves that take schedule items
+    int f_gen0;               // first wave that produces thresholds (waves [f_gen0, nt/64) share that work)
+    int fz_pstride;           // schedule positions reserved per window (plane stride of ell32, length of head32)
+    int fz_npos_next;         // positions the NEXT window actually uses (for the warm-up touches)
+    int fz_compact;           // 4-byte schedule entries (col << 16 | Jq & 0xFFFF), see FusedItem
     int lds_send_off;
+    int dbg_flags;            // -DNLMC_DEBUG_KNOBS builds only (NLMC_DBG_FLAGS): 1 = no threshold production, 2 = no updates, 4 = no item loads
 };
 
 // ---- pieces shared by the two sweep kernels ------------------------------------------------------------
@@ -1150,82 +1209,241 @@ __global__ void k_sweep_philox(SweepArgs a)
 // updates it depends on -- earlier neighbours of sweep t+1, every neighbour's and its own update of sweep t -- are
 // done, so the narrow tail of sweep t overlaps the wide head of sweep t+1 and every level is ~0.07 n wide.  The
 // sequential semantics (and therefore every result bit) are those of the sweep-by-sweep schedule.  At most two sweeps
-// are live in any level (k_levelize_fused floors sweep t+2 behind the end of sweep t), uniforms live in three LDS
-// tables (slot = t mod 3): while sweeps t, t+1 run, the helper waves fill the table of sweep t+2 (its slot was freed
-// when sweep t-1 ended).  Worker waves [0, f_workers) take the items (level cap = 64 f_workers), helper waves only
-// generate uniforms; all execute the same number of barriers.  No per-sweep epilogue: used when the caller wants
-// neither per-sweep energies, nor recorded configurations, nor the running minimum, and beta is constant.
-template <bool DIAG>
-__global__ void k_sweep_fused(SweepArgs a)
-{
-    typedef float T;
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    ChainCtx x;
-    chain_load(a, lds_raw, x);
-    if ((unsigned)reinterpret_cast<size_t>(lds_raw) != 0u) __builtin_trap();   // see k_sweep_philox
-    const int n = x.n, tid = x.tid, nt = x.nt, c = x.c;
-    T *ur = reinterpret_cast<T *>(lds_raw + a.lds_u_off);
-    int *loff = reinterpret_cast<int *>(lds_raw + a.lds_loff_off);
-    int *send = reinterpret_cast<int *>(lds_raw + a.lds_send_off);
-    const uint32_t gc = (uint32_t)(a.chain_base + c);
-    const int row = a.slot_of_chain ? a.slot_of_chain[gc] : c;
-    const double esc = __longlong_as_double((long long)(1023 + a.escale) << 52);
-    const int Tn = a.n_sweeps, nl = a.nlev[0];
-    const T cb0 = scale_cb((T)a.tab[(size_t)row * a.tab_cs], a.qinv), cb1 = scale_cb((T)a.tab[(size_t)row * a.tab_cs + 1], a.qinv);
+// are live in any level (k_levelize_fused floors sweep t+2 behind the end of sweep t); thresholds live in three LDS
+// tables (slot = t mod 3): while sweeps t, t+1 run, the table of sweep t+2 is produced (its slot was freed when sweep
+// t-1 ended).
+//
+// The level loop is the hot loop of the whole path and is written for instruction count: a level is a list of CHUNKS
+// of 64 items (padded with dummy items), wave w of the f_workers worker waves takes chunk w of the level if there is
+// one -- no per-lane validity, no divergent branches; the chunk's position rides in the scalar offset of the buffer
+// loads (one 8-byte head + 4 or 8 16-byte planes, fully coalesced, issued one level ahead into ping-pong registers);
+// the update is straight-line: 10 LDS reads, 8 multiply-adds on the int32 field, one compare with the prepared
+// threshold, one 64-bit multiply-add for the energy, one LDS write, one s_barrier.  Waves [f_gen0, nt/64) produce the
+// thresholds (Philox + logit), the waves behind the workers also pull the next window's schedule towards the chip.
+// No per-sweep epilogue: used when the caller wants neither per-sweep energies, nor recorded configurations, nor the
+// running minimum, and beta is constant.
+template <bool COMPACT, bool TAIL> struct FusedItem {
+    // planes of the row window: wide = { col(2q), Jq(2q), col(2q+1), Jq(2q+1) }, 8 entries in 4 planes (16 in 8);
+    // compact = 4 entries of col << 16 | (Jq & 0xFFFF) per plane, 8 entries in 2 planes (16 in 4)
+    static constexpr int NE = TAIL ? NLMC_ELL_W32 : 8;
+    static constexpr int NP = COMPACT ? NE / 4 : NE / 2;
+    nlmc_i2 hd;                   // { k | LONG << 14 | threshold word << 16, hq_k }
+    nlmc_i4 pk[NP];
+    __device__ __forceinline__ int word(int i) const { const int p = i >> 2, j = i & 3; return j == 0 ? pk[p].x : j == 1 ? pk[p].y : j == 2 ? pk[p].z : pk[p].w; }
+    __device__ __forceinline__ unsigned col(int q) const { return COMPACT ? (unsigned)word(q) >> 16 : (unsigned)word(2 * q); }
+    __device__ __forceinline__ int val(int q) const { return COMPACT ? (int)(short)(word(q) & 0xFFFF) : word(2 * q + 1); }
+};
 
-    // prologue: uniforms of the first three sweeps, level offsets, sweep ends
-    for (int t = 0; t < min(3, Tn); ++t)
-        fill_uniforms(reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(ur) + (size_t)t * a.lds_u_stride), n,
-                      a.sweep0 + (uint32_t)t, gc, a.seed_lo, a.seed_hi, tid, nt);
-    for (int l = tid; l <= nl; l += nt) loff[l] = a.lvl_off[l];
-    for (int t = tid; t < Tn; t += nt) send[t] = a.fsend[t];
-    __syncthreads();
-
-    // Every wave produces thresholds: block b of sweep u (4 thresholds from one Philox call) belongs to lane b mod nt.
-    // The table slot u mod 3 is free once sweep u-3 has ended (level send[u-3]) and must be complete before the first
-    // item of sweep u, which k_levelize_fused places after send[u-2]: the nj calls of a lane are spread over that range.
-    struct Gen {
-        const SweepArgs &a;
-        const int *send;
-        float *ur;
-        uint32_t gc;
-        int tid, nt, nblk, nj, Tn;
-        mutable int u;                              // next sweep whose table has to be produced
-        __device__ __forceinline__ void operator()(int l) const
-        {
-            if (u < Tn && l > send[u - 3]) {
-                const int w0 = send[u - 3], wlen = send[u - 2] - w0;          // levels (w0, w0 + wlen] are ours
-                const int per = (nj + wlen - 1) / wlen, step = l - w0 - 1;
-                float *dst = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(ur) + (size_t)(u % 3) * a.lds_u_stride);
-                for (int j = step * per; j < min(nj, (step + 1) * per); ++j) {
-                    const int b = tid + j * nt;
-                    if (b < nblk) {
-                        const u32x4 r = philox4x32_10((uint32_t)b, a.sweep0 + (uint32_t)u, gc, NLMC_TAG_UNIFORM, a.seed_lo, a.seed_hi);
-                        float4 v;
-                        v.x = threshold_spec(r.x);
-                        v.y = threshold_spec(r.y);
-                        v.z = threshold_spec(r.z);
-                        v.w = threshold_spec(r.w);
-                        reinterpret_cast<float4 *>(dst)[b] = v;
-                    }
+struct FusedGen {                 // threshold producer of one wave (all members but the lane ids are wave-uniform)
+    const SweepArgs &a;
+    float *ur;
+    uint32_t gc;
+    int gtid, gnt, nblk, nj, Tn;
+    int u, w0, wend, per;
+    __device__ __forceinline__ void arm()
+    {
+        if (u < Tn) {
+            w0 = a.fsend[u - 3];
+            wend = a.fsend[u - 2];
+            const int wlen = max(1, wend - w0);       // levels (w0, wend] are the production window of sweep u
+            per = (nj + wlen - 1) / wlen;
+        } else w0 = 0x7FFFFFFF;
+    }
+    __device__ __forceinline__ void operator()(int l)
+    {
+#ifdef NLMC_DEBUG_KNOBS
+        if (a.dbg_flags & 1) return;                 // timing experiment: no threshold production
+#endif
+        if (l > w0) {
+            const int step = l - w0 - 1;
+            float *dst = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(ur) + (size_t)(u % 3) * a.lds_u_stride);
+            for (int j = step * per; j < min(nj, (step + 1) * per); ++j) {
+                const int b = gtid + j * gnt;
+                if (b < nblk) {
+                    const u32x4 r = philox4x32_10((uint32_t)b, a.sweep0 + (uint32_t)u, gc, NLMC_TAG_UNIFORM, a.seed_lo, a.seed_hi);
+                    float4 v;
+                    v.x = threshold_spec(r.x);
+                    v.y = threshold_spec(r.y);
+                    v.z = threshold_spec(r.z);
+                    v.w = threshold_spec(r.w);
+                    reinterpret_cast<float4 *>(dst)[b] = v;
                 }
-                if (l == send[u - 2]) ++u;          // complete before the first item of sweep u (k_levelize_fused floor)
+            }
+            if (l == wend) { ++u; arm(); }          // complete before the first item of sweep u (k_levelize_fused floor)
+        }
+    }
+};
+
+template <bool DIAG, bool FLAGS, bool TAIL, bool GEN, bool COMPACT>
+__device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *lds_raw, int wv, int lane, int nl, float cq0,
+                                             float cq1, long long &e_loc, FusedGen &gen)
+{
+    typedef FusedItem<COMPACT, TAIL> Item;
+    constexpr int NP = Item::NP, NE = Item::NE;
+    const int plane_bytes = a.fz_pstride * 16;
+    const __amdgpu_buffer_rsrc_t r_ell = __builtin_amdgcn_make_buffer_rsrc(const_cast<EdgeQ *>(a.ell32), 0, (NLMC_ELL_W32 / 2) * plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_head = __builtin_amdgcn_make_buffer_rsrc(const_cast<int2 *>(a.head32), 0, a.fz_pstride * 8, 0x00020000);
+    // level offsets in chunks, read with SCALAR loads (uniform index): no VGPR, no VALU, no vector-memory slot
+    // (constant address space: the plan is read-only while sweep kernels run, and a uniform index then gives s_load_dword)
+    typedef const int32_t __attribute__((address_space(4))) *const_i32;
+    const const_i32 loffp = (const_i32)(uintptr_t)a.lvl_off;
+    auto loff = [&](int i) { return loffp[i]; };
+    const int lane16 = lane * 16, oob = 0x7FF00000;        // oob: past both buffers (the hardware range check drops the load)
+    typedef const int8_t __attribute__((address_space(3))) *lds_i8;
+    typedef int8_t __attribute__((address_space(3))) *lds_i8w;
+    typedef const uint8_t __attribute__((address_space(3))) *lds_u8;
+    typedef const float __attribute__((address_space(3))) *lds_f32;
+
+    // chunk `c` of the plan -> registers; has == false: every lane out of range (no memory traffic, registers = 0)
+    auto issue = [&](Item &it, int c, bool has) {
+        const int v16 = has ? lane16 : oob;
+        it.hd = __builtin_amdgcn_raw_buffer_load_b64(r_head, v16 >> 1, c * 512, 0);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) it.pk[q] = __builtin_amdgcn_raw_buffer_load_b128(r_ell, v16, c * 1024 + q * plane_bytes, 0);
+    };
+    auto update = [&](const Item &it) {
+#ifdef NLMC_DEBUG_KNOBS
+        if (a.dbg_flags & 2) { asm volatile("" :: "v"(it.hd.x), "v"(it.pk[0].x), "v"(it.pk[3].x)); return; }   // timing experiment: loads only
+#endif
+        const int hx = it.hd.x;
+        const unsigned ka = (unsigned)hx & 0x3FFFu;                               // LDS address of the spin
+        const float wk = *(lds_f32)(uintptr_t)((((unsigned)hx >> 16) << 2) + (unsigned)a.lds_u_off);
+        const int so = (int)*(lds_i8)(uintptr_t)ka;
+        unsigned f = 0u;
+        if (FLAGS) f = (unsigned)*(lds_u8)(uintptr_t)(ka + (unsigned)a.lds_flags_off);
+        int sj[NLMC_ELL_W32];
+#pragma unroll
+        for (int q = 0; q < NE; ++q) sj[q] = (int)*(lds_i8)(uintptr_t)it.col(q);   // all reads in flight
+        int X0 = it.hd.y, X1 = 0, Xd = 0;
+#pragma unroll
+        for (int q = 0; q < NE; q += 2) {
+            X0 += __mul24(it.val(q), sj[q]);
+            X1 += __mul24(it.val(q + 1), sj[q + 1]);
+        }
+        if (DIAG) {
+#pragma unroll
+            for (int q = 0; q < NE; ++q) Xd += (it.col(q) == ka) ? __mul24(it.val(q), sj[q]) : 0;
+        }
+        // a row longer than the 16-entry window (such rows sit in the leading chunks of a level: TAIL waves only)
+        if (TAIL && __builtin_amdgcn_ballot_w64((hx & 0x4000) != 0) != 0ull) {
+            if (hx & 0x4000) {
+                const int rs = a.g.rowptr[ka], re = a.g.rowptr[ka + 1];
+#pragma clang loop vectorize(disable) unroll(disable)
+                for (int e = rs + NLMC_ELL_W32; e < re; ++e) {
+                    const EdgeQ t = a.g.edge32[e];
+                    const int pr = __mul24(t.q, (int)*(lds_i8)(uintptr_t)(unsigned)t.col);
+                    X0 += pr;
+                    if (DIAG && (unsigned)t.col == ka) Xd += pr;
+                }
             }
         }
+        const int X = X0 + X1;
+        const float z = ((FLAGS && f == 1u) ? cq1 : cq0) * (float)X;
+        int sn = (z < wk) ? 1 : -1;
+        if (FLAGS) sn = (f >= 2u) ? so : sn;                                        // frozen: unchanged
+        e_loc += (long long)(DIAG ? X - Xd : X) * (long long)((so - sn) << a.eshift);
+        *(lds_i8w)(uintptr_t)ka = (int8_t)sn;
     };
+
+    // q0..q3 = offsets of levels l..l+3 (scalar registers, fetched two levels ahead of their first use)
+    auto lo = [&](int i) { return loff(min(i, nl)); };
+    Item A, B;
+    int q0 = lo(0), q1 = lo(1), q2 = lo(2), q3 = lo(3);
+    bool hasA = q0 + wv < q1, hasB;
+    issue(A, q0 + wv, hasA);
 #ifdef NLMC_STAMPS
-    long long st_u[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // gather wait, math+write, -, -, calls, level work, barrier wait, total
-    x.st = st_u;
-    x.lvl_t = (a.dbg && c == 0) ? a.dbg + (size_t)gridDim.x * 16 * 8 : nullptr;
+    long long sw0, sw1, sw2, st_work = 0, st_bar = 0, st_calls = 0;
+#endif
+    // Order inside a level: update first, THEN the loads of the next level.  The vector-memory path of the CU is the
+    // scarcest resource of this loop (a 1 KB wave load occupies it ~16 cycles; ~65 of them per level): a wave that
+    // issues its loads first blocks on the full queue with its LDS reads still behind them (measured: 245 vs 184 us
+    // per launch).  A wave without a chunk in the next level issues nothing (wave-uniform branch).
+    for (int l = 0; l < nl; l += 2) {
+        const int q4 = lo(l + 4), q5 = lo(l + 5);
+        NLMC_FW0
+        hasB = (l + 1 < nl) && (q1 + wv < q2);             // level l from A; level l+1 into B
+        if (GEN) gen(l);
+        if (hasA) { update(A); NLMC_FCALL }
+        if (hasB NLMC_DBG_NOLOAD) issue(B, q1 + wv, true);
+        NLMC_FW1
+        __syncthreads();
+        NLMC_FW2
+        if (l + 1 < nl) {
+            NLMC_FW0
+            hasA = (l + 2 < nl) && (q2 + wv < q3);
+            if (GEN) gen(l + 1);
+            if (hasB) { update(B); NLMC_FCALL }
+            if (hasA NLMC_DBG_NOLOAD) issue(A, q2 + wv, true);
+            NLMC_FW1
+            __syncthreads();
+            NLMC_FW2
+        }
+        q0 = q2; q1 = q3; q2 = q4; q3 = q5;
+    }
+#ifdef NLMC_STAMPS
+    if (a.dbg && lane == 0) {
+        long long *d = a.dbg + ((size_t)blockIdx.x * 16 + wv) * 8;
+        d[4] = st_calls; d[5] = st_work; d[6] = st_bar;
+    }
+#endif
+}
+
+template <bool DIAG, bool FLAGS>
+__global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    if ((unsigned)reinterpret_cast<size_t>(lds_raw) != 0u) __builtin_trap();   // spins at LDS offset 0: column == address
+    const int n = a.g.n, n_pad = a.g.n_pad, tid = threadIdx.x, nt = blockDim.x, c = blockIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    float *ur = reinterpret_cast<float *>(lds_raw + a.lds_u_off);
+    long long *red = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);
+    const uint32_t gc = (uint32_t)(a.chain_base + c);
+    const int row = a.slot_of_chain ? a.slot_of_chain[gc] : c;
+    const int Tn = a.n_sweeps, nl = a.nlev[0];
+#ifdef NLMC_STAMPS
     const long long st_begin = (long long)__builtin_readcyclecounter();
 #endif
-    const int nblk = (n + 3) / 4;
-    const Gen gen{a, send, ur, gc, tid, nt, nblk, (nblk + nt - 1) / nt, Tn, 3};
-    const int wbase = tid & ~63;
-    if (wbase < a.f_workers * 64) {
-        const bool role_long = wbase < a.hi_max[0];
-        if (role_long) run_levels<T, DIAG, true, true, const Gen &>(a, x, ur, loff, 0, nl, nl, cb0, cb1, esc, Tn * n, gen);
-        else run_levels<T, DIAG, false, true, const Gen &>(a, x, ur, loff, 0, nl, nl, cb0, cb1, esc, Tn * n, gen);
+    // "f32" mode: z = cb * (X 2^-qs) with the int32 field X -> the exact power of two is folded into the coefficient
+    const float cq0 = (float)a.tab[(size_t)row * a.tab_cs] * a.qinv, cq1 = (float)a.tab[(size_t)row * a.tab_cs + 1] * a.qinv;
+
+    // spins (+ the scratch spin of the dummy items behind them), phase flags
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(a.spins + (size_t)c * n_pad);
+        int4 *dst = reinterpret_cast<int4 *>(lds_raw);
+        for (int i = tid; i < n_pad / 16; i += nt) dst[i] = src[i];
+        if (tid < 4) reinterpret_cast<int *>(lds_raw + n_pad)[tid] = 0x01010101;
+        if (FLAGS) {
+            const int4 *fsrc = reinterpret_cast<const int4 *>(a.flags + (size_t)c * n_pad);
+            int4 *fdst = reinterpret_cast<int4 *>(lds_raw + a.lds_flags_off);
+            for (int i = tid; i < n_pad / 16; i += nt) fdst[i] = fsrc[i];
+            if (tid < 4) reinterpret_cast<int *>(lds_raw + a.lds_flags_off + n_pad)[tid] = 0;
+        }
+        if (tid == 0) red[0] = 0;
+    }
+    // thresholds of the first three sweeps
+    for (int t = 0; t < min(3, Tn); ++t)
+        fill_uniforms(reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(ur) + (size_t)t * a.lds_u_stride), n,
+                      a.sweep0 + (uint32_t)t, gc, a.seed_lo, a.seed_hi, tid, nt);
+    __syncthreads();
+
+    const int g0 = a.f_gen0 * 64, nblk = (n + 3) / 4, gnt = nt - g0;
+    FusedGen gen{a, ur, gc, tid - g0, gnt, nblk, (nblk + gnt - 1) / gnt, Tn, 3, 0, 0, 1};
+    gen.arm();
+    const bool is_gen = tid >= g0;
+    long long e_loc = 0;
+    if (wv < a.f_workers) {
+        const bool role_long = wv < a.hi_max[0];           // chunks that may hold rows longer than 8 entries come first
+        const int variant = (role_long ? 4 : 0) + (is_gen ? 2 : 0) + (a.fz_compact ? 1 : 0);
+        switch (variant) {
+        case 0: fused_levels<DIAG, FLAGS, false, false, false>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gen); break;
+        case 1: fused_levels<DIAG, FLAGS, false, false, true>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gen); break;
+        case 2: fused_levels<DIAG, FLAGS, false, true, false>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gen); break;
+        case 3: fused_levels<DIAG, FLAGS, false, true, true>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gen); break;
+        case 4: fused_levels<DIAG, FLAGS, true, false, false>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gen); break;
+        case 5: fused_levels<DIAG, FLAGS, true, false, true>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gen); break;
+        case 6: fused_levels<DIAG, FLAGS, true, true, false>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gen); break;
+        default: fused_levels<DIAG, FLAGS, true, true, true>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gen); break;
+        }
     } else {
         // Waves without schedule items: their share of the thresholds, and they pull the NEXT window's schedule towards
         // the chip.  A window's schedule (72 B per update actually touched) is read once per launch and sits in HBM
@@ -1234,36 +1452,52 @@ __global__ void k_sweep_fused(SweepArgs a)
         // of the head array and of planes 0-3, striped over chains and helper lanes, one load per level, retired a
         // level later.
         const int hid = tid - a.f_workers * 64, hcnt = nt - a.f_workers * 64;
-        const unsigned warm_lines = a.warm_head ? (unsigned)(((size_t)Tn * n * 8 + 127) / 128) : 0u;       // head
-        const unsigned warm_lines_p = a.warm_head ? (unsigned)(((size_t)Tn * n * 16 * 4 + 127) / 128) : 0u; // planes 0-3
+        const unsigned warm_lines = a.warm_head ? (unsigned)(((size_t)a.fz_npos_next * 8 + 127) / 128) : 0u;       // head
+        const unsigned warm_lines_p = a.warm_head ? (unsigned)(((size_t)a.fz_pstride * 16 + 127) / 128) : 0u;     // lines per plane
+        const unsigned warm_used_p = a.warm_head ? (unsigned)(((size_t)a.fz_npos_next * 16 + 127) / 128) : 0u;     // touched lines per plane
+        const unsigned warm_total = warm_lines + (a.fz_compact ? 2u : 4u) * warm_used_p;
         unsigned warm_at = (unsigned)c * (unsigned)hcnt + (unsigned)hid;
         const unsigned warm_step = gridDim.x * (unsigned)hcnt;
-        unsigned wv = 0u;
+        unsigned wvv = 0u;
         auto warm_next = [&]() {
-            asm volatile("" :: "v"(wv) : "memory");          // retire the previous one before reusing its register
-            if (warm_at < warm_lines + warm_lines_p) {
-                const char *p = warm_at < warm_lines ? reinterpret_cast<const char *>(a.warm_head) + (size_t)warm_at * 128
-                                                     : reinterpret_cast<const char *>(a.warm_ell) + (size_t)(warm_at - warm_lines) * 128;
-                wv = *reinterpret_cast<const unsigned *>(p);
+            asm volatile("" :: "v"(wvv) : "memory");          // retire the previous one before reusing its register
+            if (warm_at < warm_total) {
+                const char *p;
+                if (warm_at < warm_lines) p = reinterpret_cast<const char *>(a.warm_head) + (size_t)warm_at * 128;
+                else {
+                    const unsigned r = warm_at - warm_lines, q = r / warm_used_p, i = r - q * warm_used_p;
+                    p = reinterpret_cast<const char *>(a.warm_ell) + ((size_t)q * warm_lines_p + i) * 128;
+                }
+                wvv = *reinterpret_cast<const unsigned *>(p);
                 warm_at += warm_step;
             }
         };
         for (int l = 0; l < nl; ++l) {
             warm_next();
-            gen(l);
+            if (is_gen) gen(l);
             __syncthreads();
         }
-        while (warm_at < warm_lines + warm_lines_p) warm_next();     // few chains: the rest of this chain's share
-        asm volatile("" :: "v"(wv) : "memory");
+        while (warm_at < warm_total) warm_next();     // few chains: the rest of this chain's share
+        asm volatile("" :: "v"(wvv) : "memory");
+    }
+
+    // energy of the final state, spins back to HBM
+    {
+        const long long w = wave_sum_i64(e_loc);
+        if (lane == 0 && w != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&red[0]), (unsigned long long)w);
+        __syncthreads();
+        int4 *dst = reinterpret_cast<int4 *>(a.spins + (size_t)c * n_pad);
+        const int4 *src = reinterpret_cast<const int4 *>(lds_raw);
+        for (int i = tid; i < n_pad / 16; i += nt) dst[i] = src[i];
+        if (tid == 0) {
+            const long long E = a.efix[c] + red[0];
+            a.efix[c] = E;
+            if (a.energy_sink) a.energy_sink[c] = (double)E * __longlong_as_double((long long)(1023 - a.escale) << 52);
+        }
     }
 #ifdef NLMC_STAMPS
-    if (a.dbg && (tid & 63) == 0) {
-        long long *d = a.dbg + ((size_t)c * 16 + (tid >> 6)) * 8;
-        for (int i = 0; i < 7; ++i) d[i] = st_u[i];
-        d[7] = (long long)__builtin_readcyclecounter() - st_begin;
-    }
+    if (a.dbg && lane == 0) a.dbg[((size_t)c * 16 + wv) * 8 + 7] = (long long)__builtin_readcyclecounter() - st_begin;
 #endif
-    chain_store(a, x);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -192,7 +192,8 @@ double nlo_exp2_f64(double z) { return exp2_spec_f64(z); }
 /* ------------------------------------------------------------------------------------------------ */
 /* Field scale qs and energy scale escale of an instance (restated from nlmc_create, csrc/nlmc.hip):
  *   Jq_e = rint(J_e 2^qs), hq_k = rint(h_k 2^qs) with qs the largest exponent such that every |Jq_e| <= 2^23 - 1
- *   (signed 24-bit multiplier) and every row sum  sum_e |Jq_e| + |hq_k| <= 2^31 - 1  (the field is an exact int32);
+ *   (signed 24-bit multiplier) and every row sum  sum_e |Jq_e| + |hq_k| <= 2^31 - 1  (the field is an exact int32),
+ *   then lowered by the number of trailing zero bits common to every Jq and hq (canonical form; no value changes);
  *   escale0 = clamp(60 - ceil_log2(sum|J|/2 + sum|h|), 0, 52);  qs <= escale0;  escale = min(escale0, qs + 29)
  *   (an energy delta is the int32 field times +-2^(escale - qs + 1), one 32 x 32 -> 64 bit multiply-add). */
 static int64_t rint_scaled(double v, int qs) { return (int64_t)llrint(ldexp(v, qs)); }
@@ -228,6 +229,14 @@ int nlo_field_scale(int n, const int32_t *rowptr, const double *val, const doubl
                 if (row > 2147483647LL) ok = 0;
             }
             if (ok) break;
+            --qs;
+        }
+        /* canonical form: drop the power of two common to every Jq and hq (+-J instances: Jq = +-1, qs = 0) */
+        for (;;) {
+            int even = 1, any = 0;
+            for (int64_t e = 0; e < nnz && even; ++e) { const int64_t q = rint_scaled(val[e], qs); if (q & 1) even = 0; if (q) any = 1; }
+            for (int k = 0; k < n && even; ++k) { const int64_t q = rint_scaled(h[k], qs); if (q & 1) even = 0; if (q) any = 1; }
+            if (!even || !any) break;
             --qs;
         }
     }

@@ -20,9 +20,7 @@ d = raw[:R * 16 * 8].reshape(R, 16, 8)
 lv = raw[R * 16 * 8:]
 print(f"{nl} levels in the window; chain 0, wave 0: barrier-to-barrier cycles of the first 48 levels (width:cycles):")
 print("  " + "  ".join(f"{int(lv[48 + i])}:{lv[i]:.0f}" for i in range(48) if lv[48 + i] > 0))
-print("per wave (median over chains), cycles per level: update = gather-wait + math/write per call; level = work + barrier wait")
+print("per wave (median over chains), cycles per level: work (fetch issue + threshold production + update) vs barrier wait")
 for w in range(16):
-    calls = np.maximum(d[:, w, 4], 1)
     m = lambda j: np.median(d[:, w, j])
-    print(f" wave {w:2d}: calls {m(4):5.0f}  gather-wait/call {np.median(d[:, w, 0] / calls):6.0f}  math+write/call {np.median(d[:, w, 1] / calls):6.0f}  "
-          f"| per level: work {m(5) / nl:6.0f}  barrier-wait {m(6) / nl:6.0f}  | kernel total {m(7):9.0f} cycles = {m(7) / nl:6.0f} per level")
+    print(f" wave {w:2d}: chunks {m(4):5.0f}  | per level: work {m(5) / nl:6.0f}  barrier-wait {m(6) / nl:6.0f}  | kernel total {m(7):9.0f} cycles = {m(7) / nl:6.0f} per level")
