@@ -76,12 +76,13 @@ def cpu_baseline(J, h, seconds=12.0):
     chunk = 20
     cb = np.tile(np.array(oracle.cb_pair(1.0)), (chunk, 1))
     oracle.sweeps_philox(csr, h, s, cb[:1], PHILOX_SEED, 0, want_M=False)     # warm-up / page-in
+    esc = oracle.field_scale(csr, h)[1]
     done, t0, emin, ef = 0, time.perf_counter(), None, 0
-    ef = int(np.rint(oracle.energy(csr, h, s) * 2.0 ** 32))
+    ef = int(np.rint(oracle.energy(csr, h, s) * 2.0 ** esc))
     while time.perf_counter() - t0 < seconds:
-        _, s, tr = oracle.sweeps_philox(csr, h, s, cb, PHILOX_SEED, 0, sweep0=done, escale=32, efix0=ef, want_M=False)
+        _, s, tr = oracle.sweeps_philox(csr, h, s, cb, PHILOX_SEED, 0, sweep0=done, escale=esc, efix0=ef, want_M=False)
         ef = int(tr[-1])
-        emin = min(float(tr.min()) * 2.0 ** -32, emin) if emin is not None else float(tr.min()) * 2.0 ** -32
+        emin = min(float(tr.min()) * 2.0 ** -esc, emin) if emin is not None else float(tr.min()) * 2.0 ** -esc
         done += chunk
     dt = time.perf_counter() - t0
     return {"value": done * csr.n / dt, "unit": "spin-updates/s", "cores": 1, "kind": "port",

@@ -71,6 +71,8 @@ int nlmc_set_flags(nlmc_ctx *ctx, const uint8_t *flags, double temp_x);
 int nlmc_energy(nlmc_ctx *ctx, double *out /*[n_chains]*/);
 /* Same, result left in device memory (for an RCCL all-gather issued by the caller). */
 int nlmc_energy_dev(nlmc_ctx *ctx, double *dev_out /*[n_chains], device pointer*/);
+/* The incrementally tracked energies of the current states (no recomputation), to the host. */
+int nlmc_energy_tracked(nlmc_ctx *ctx, double *out /*[n_chains]*/);
 /* Persistent variant: every later sweep call also stores the tracked energies of its final states there (the send
  * buffer of the per-round all-gather, NPT/npt.py:657-658 energies) -- no extra launch.  NULL switches it off. */
 int nlmc_set_energy_sink(nlmc_ctx *ctx, double *dev_out /*[n_chains], device pointer or NULL*/);
@@ -138,10 +140,25 @@ int nlmc_pt_apply_swap(nlmc_ctx *ctx, int ladder, int slot_a, int slot_b);
  *   own current energies (single GPU).  out_pairs [n_ladders][n_pairs][2] slots, out_accepted [n_ladders][n_pairs]. */
 int nlmc_pt_swap_philox(nlmc_ctx *ctx, uint32_t round, uint64_t seed, int n_pairs, const double *energies_all_dev,
                         int32_t *out_pairs, uint8_t *out_accepted);
+/* Same round with the all-gathered energies handed over in HOST memory (several contexts driven by one process,
+ * NPT.run(device_ids=...): no device-to-device path is assumed between them). */
+int nlmc_pt_swap_philox_host(nlmc_ctx *ctx, uint32_t round, uint64_t seed, int n_pairs, const double *energies_all_host,
+                             int32_t *out_pairs, uint8_t *out_accepted);
 /* Optional: the pair selection depends on the RNG only, so the selections of rounds [round0, round0+n_rounds) can be
  * computed ahead of time (one wave per round and ladder).  Later nlmc_pt_swap_philox calls in that range with the same
  * seed and n_pairs are left with the parallel acceptance test.  Results are identical with or without a plan. */
 int nlmc_pt_plan(nlmc_ctx *ctx, uint32_t round0, int n_rounds, uint64_t seed, int n_pairs);
+/* Device-side swap log of rounds [round0, round0 + n_rounds): rounds of nlmc_pt_swap_philox(_host) called WITHOUT host
+ * output pointers keep their pairs and decisions on the device; nlmc_pt_log_read copies the whole log in one go
+ * (out_pairs [n_rounds][n_ladders][n_pairs][2], -1 where a round did not run; out_accepted [n_rounds][n_ladders][n_pairs])
+ * and reports pair exhaustion like nlmc_pt_check.  Replaces the reference's per-round prints (NPT/npt.py:662-674). */
+int nlmc_pt_log_begin(nlmc_ctx *ctx, uint32_t round0, int n_rounds, int n_pairs);
+int nlmc_pt_log_read(nlmc_ctx *ctx, int32_t *out_pairs, uint8_t *out_accepted);
+/* NLMC_ERR_ARG ("Cannot find non-overlapping pairs.", the reference's ValueError of NPT/npt.py:526) if the greedy
+ * selection of any device-decided round since the last check ran out of pairs; such a round attempts no swap.  Rounds
+ * that return their log, and planned rounds (at nlmc_pt_plan time), report it themselves; call this after a run of
+ * unplanned rounds without logs.  One stream synchronisation. */
+int nlmc_pt_check(nlmc_ctx *ctx);
 
 /* Houdayer iso-cluster move (NPT/apt_ICM.py:116-143, 215-246) between the current states of local chains a and
  * b: connected components of the disagreement sub-graph, pick component number `pick_index mod n_components`

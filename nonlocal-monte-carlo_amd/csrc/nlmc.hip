@@ -118,13 +118,17 @@ struct nlmc_ctx {
     bool pt_tab_valid = false;
     double pt_tab_temp_x = 1.0;
     std::vector<double> beta_list;
-    DevBuf<double> pt_tab, pt_beta;
+    DevBuf<double> pt_tab, pt_beta, pt_energies_all;
     DevBuf<int32_t> slot_of_chain, chain_of_slot, pt_pairs, pt_status, pt_plan_pairs, pt_plan_ok;
     bool pt_plan_valid = false;
     uint32_t pt_plan_round0 = 0;
     int pt_plan_rounds = 0, pt_plan_npairs = 0;
     uint64_t pt_plan_seed = 0;
-    DevBuf<uint8_t> pt_acc;
+    DevBuf<uint8_t> pt_acc, pt_log_acc;
+    DevBuf<int32_t> pt_log_pairs;
+    bool pt_log_on = false;
+    uint32_t pt_log_round0 = 0;
+    int pt_log_rounds = 0, pt_log_npairs = 0;
     std::vector<uint8_t> stage_in, stage_out;      // padded host staging for row copies
     // ICM
     DevBuf<int32_t> icm_label, icm_info, icm_pairs;
@@ -262,7 +266,7 @@ int fused_workers(int nt)
     const int waves = nt / 64;
     if (waves < 16) return waves - 1;
     if (const char *s = getenv("NLMC_FUSED_WORKERS")) { const int v = atoi(s); if (v >= 8 && v <= 16) return v; }
-    return 13;
+    return 14;
 }
 
 // LDS of k_sweep_fused: spins (+16: scratch spin of the dummy items) | flags (+16) | 3 threshold tables | reduction scratch
@@ -284,11 +288,13 @@ FusedLds fused_lds(int n, int n_pad, bool has_flags, int T)
 
 int fused_pstride(int n, int T) { return (int)((((size_t)T * n + 63) / 64 + NLMC_LCAP) * 64); }
 
-// first wave that produces thresholds (NLMC_FUSED_GEN0: tuning knob)
+// first wave that produces thresholds (NLMC_FUSED_GEN0: tuning knob): the trailing half of the workgroup -- the
+// waves that rarely or never hold a chunk
 int fused_gen0(int nt)
 {
-    if (const char *s = getenv("NLMC_FUSED_GEN0")) { const int v = atoi(s); if (v >= 0 && v < nt / 64) return v; }
-    return 0;
+    const int waves = nt / 64;
+    if (const char *s = getenv("NLMC_FUSED_GEN0")) { const int v = atoi(s); if (v >= 0 && v < waves) return v; }
+    return waves / 2;
 }
 
 // Instances the fused kernels are built for: a sweep workgroup of at least 4 waves (3 workers + 1 helper), degree in 14 bits, three
@@ -340,6 +346,7 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
     }
     a.f_workers = c->fz_workers;
     a.f_gen0 = c->fz_gen0;
+    a.f_gen_prio = getenv("NLMC_FUSED_NOPRIO") ? 0 : 1;
 #ifdef NLMC_DEBUG_KNOBS
     if (const char *e = getenv("NLMC_DBG_FLAGS")) a.dbg_flags = atoi(e);
 #endif
@@ -614,6 +621,7 @@ void rows_to_host_finish(nlmc_ctx *c, void *dst_host, int rows)
 extern "C" {
 
 static int ensure_adjacency(nlmc_ctx *c);
+int nlmc_pt_check(nlmc_ctx *c);
 
 int nlmc_abi_version(void) { return 1; }
 
@@ -789,9 +797,9 @@ void nlmc_destroy(nlmc_ctx *c)
     c->lbp_src.release(); c->lbp_rev.release(); c->lbp_flag.release(); c->lbp_out_i.release(); c->lbp_tJ.release();
     c->lbp_eps.release(); c->lbp_ms.release(); c->lbp_lams.release(); c->lbp_w0.release(); c->lbp_w1.release();
     c->lbp_hm.release(); c->lbp_tot.release(); c->lbp_mag.release(); c->lbp_mag_all.release();
-    c->pt_tab.release(); c->pt_beta.release();
+    c->pt_tab.release(); c->pt_beta.release(); c->pt_energies_all.release();
     c->slot_of_chain.release(); c->chain_of_slot.release(); c->pt_pairs.release(); c->pt_status.release();
-    c->pt_acc.release(); c->pt_plan_pairs.release(); c->pt_plan_ok.release(); c->icm_label.release(); c->icm_info.release(); c->icm_pairs.release();
+    c->pt_acc.release(); c->pt_log_acc.release(); c->pt_log_pairs.release(); c->pt_plan_pairs.release(); c->pt_plan_ok.release(); c->icm_label.release(); c->icm_info.release(); c->icm_pairs.release();
     delete c;
 }
 
@@ -858,6 +866,19 @@ int nlmc_energy_dev(nlmc_ctx *c, double *dev_out)
     hipLaunchKernelGGL(k_efix_to_double, dim3((c->n_chains + 255) / 256), dim3(256), 0, c->stream, c->efix.p, dev_out,
                        c->n_chains, c->escale);
     HIP_TRY(c, hipGetLastError());
+    return NLMC_OK;
+}
+
+int nlmc_energy_tracked(nlmc_ctx *c, double *out)
+{
+    if (!c || !out) return fail(c, NLMC_ERR_ARG, "nlmc_energy_tracked: NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->n_chains == 0) return NLMC_OK;
+    std::vector<long long> e((size_t)c->n_chains);
+    HIP_TRY(c, hipMemcpyAsync(e.data(), c->efix.p, sizeof(long long) * e.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const double inv = std::ldexp(1.0, -c->escale);
+    for (size_t i = 0; i < e.size(); ++i) out[i] = (double)e[i] * inv;
     return NLMC_OK;
 }
 
@@ -1202,6 +1223,13 @@ int nlmc_pt_plan(nlmc_ctx *c, uint32_t round0, int n_rounds, uint64_t seed, int 
     a.plan_pairs = c->pt_plan_pairs.p; a.plan_ok = c->pt_plan_ok.p;
     hipLaunchKernelGGL(k_pt_select, dim3(n_rounds * nl), dim3(64), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
+    // the selection depends on the RNG only: an exhausted greedy selection (NPT/npt.py:526 raises ValueError in that
+    // round) is known now -- report it here instead of silently skipping that round's swaps later
+    std::vector<int32_t> ok((size_t)n_rounds * nl);
+    HIP_TRY(c, hipMemcpyAsync(ok.data(), c->pt_plan_ok.p, sizeof(int32_t) * ok.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int32_t v : ok)
+        if (!v) return fail(c, NLMC_ERR_ARG, "Cannot find non-overlapping pairs.");
     c->pt_plan_valid = true;
     c->pt_plan_round0 = round0; c->pt_plan_rounds = n_rounds; c->pt_plan_npairs = n_pairs; c->pt_plan_seed = seed;
     return NLMC_OK;
@@ -1271,6 +1299,12 @@ int nlmc_pt_swap_philox(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs,
     a.escale = c->escale;
     a.slot_of_chain = c->slot_of_chain.p; a.chain_of_slot = c->chain_of_slot.p;
     a.out_pairs = c->pt_pairs.p; a.out_acc = c->pt_acc.p; a.status = c->pt_status.p;
+    if (c->pt_log_on && c->pt_log_npairs == n_pairs && round >= c->pt_log_round0 &&
+        round < c->pt_log_round0 + (uint32_t)c->pt_log_rounds && !out_pairs && !out_accepted) {
+        const size_t r = round - c->pt_log_round0;       // device-side log: read back once (nlmc_pt_log_read)
+        a.out_pairs = c->pt_log_pairs.p + r * (size_t)nl * n_pairs * 2;
+        a.out_acc = c->pt_log_acc.p + r * (size_t)nl * n_pairs;
+    }
     if (c->pt_plan_valid && c->pt_plan_seed == seed && c->pt_plan_npairs == n_pairs && round >= c->pt_plan_round0 &&
         round < c->pt_plan_round0 + (uint32_t)c->pt_plan_rounds) {
         const size_t r = round - c->pt_plan_round0;
@@ -1289,6 +1323,63 @@ int nlmc_pt_swap_philox(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs,
             HIP_TRY(c, hipMemset(c->pt_status.p, 0, sizeof(int32_t)));
             return fail(c, NLMC_ERR_ARG, "Cannot find non-overlapping pairs.");
         }
+    }
+    return NLMC_OK;
+}
+
+int nlmc_pt_swap_philox_host(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs, const double *energies_all_host,
+                             int32_t *out_pairs, uint8_t *out_accepted)
+{
+    if (!c || !energies_all_host) return fail(c, NLMC_ERR_ARG, "nlmc_pt_swap_philox_host: NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, c->pt_energies_all.reserve((size_t)c->n_chains_global));
+    HIP_TRY(c, hipMemcpyAsync(c->pt_energies_all.p, energies_all_host, sizeof(double) * (size_t)c->n_chains_global,
+                              hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the caller's buffer may go away after the call
+    return nlmc_pt_swap_philox(c, round, seed, n_pairs, c->pt_energies_all.p, out_pairs, out_accepted);
+}
+
+int nlmc_pt_log_begin(nlmc_ctx *c, uint32_t round0, int n_rounds, int n_pairs)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (c->ladder_len == 0) return fail(c, NLMC_ERR_STATE, "nlmc_pt_log_begin: call nlmc_pt_init first");
+    if (n_rounds < 0 || n_pairs < 0) return fail(c, NLMC_ERR_ARG, "nlmc_pt_log_begin: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t nl = (size_t)(c->n_chains_global / c->ladder_len), tot = (size_t)n_rounds * nl * (size_t)n_pairs;
+    c->pt_log_on = false;
+    if (tot == 0) return NLMC_OK;
+    HIP_TRY(c, c->pt_log_pairs.reserve(tot * 2));
+    HIP_TRY(c, c->pt_log_acc.reserve(tot));
+    HIP_TRY(c, hipMemsetAsync(c->pt_log_pairs.p, 0xFF, sizeof(int32_t) * tot * 2, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->pt_log_acc.p, 0, tot, c->stream));
+    c->pt_log_on = true;
+    c->pt_log_round0 = round0; c->pt_log_rounds = n_rounds; c->pt_log_npairs = n_pairs;
+    return NLMC_OK;
+}
+
+int nlmc_pt_log_read(nlmc_ctx *c, int32_t *out_pairs, uint8_t *out_accepted)
+{
+    if (!c || !out_pairs || !out_accepted) return fail(c, NLMC_ERR_ARG, "nlmc_pt_log_read: NULL argument");
+    if (!c->pt_log_on) return fail(c, NLMC_ERR_STATE, "nlmc_pt_log_read: no log was begun");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t nl = (size_t)(c->n_chains_global / c->ladder_len), tot = (size_t)c->pt_log_rounds * nl * (size_t)c->pt_log_npairs;
+    HIP_TRY(c, hipMemcpyAsync(out_pairs, c->pt_log_pairs.p, sizeof(int32_t) * tot * 2, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out_accepted, c->pt_log_acc.p, tot, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return nlmc_pt_check(c);
+}
+
+int nlmc_pt_check(nlmc_ctx *c)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (c->ladder_len == 0) return NLMC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int32_t st = 0;
+    HIP_TRY(c, hipMemcpyAsync(&st, c->pt_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (st != 0) {
+        HIP_TRY(c, hipMemset(c->pt_status.p, 0, sizeof(int32_t)));
+        return fail(c, NLMC_ERR_ARG, "Cannot find non-overlapping pairs.");
     }
     return NLMC_OK;
 }

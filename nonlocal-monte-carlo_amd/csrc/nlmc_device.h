@@ -18,15 +18,36 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = h1 ^ c1 ^ k0;
-        const uint32_t n2 = h0 ^ c3 ^ k1;
-        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        // one 32 x 32 -> 64 bit multiply (v_mad_u64_u32) yields both halves
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
     return u32x4{c0, c1, c2, c3};
+}
+
+// two independent calls side by side: their dependent multiply chains interleave in one wave's instruction stream
+// (a lone producing wave gets no latency hiding from its SIMD neighbours, which sit in barriers most of the time)
+__device__ __forceinline__ void philox4x32_10_x2(uint32_t a0, uint32_t b0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                 uint32_t k1, u32x4 &ra, u32x4 &rb)
+{
+    uint32_t x0 = a0, x1 = c1, x2 = c2, x3 = c3, y0 = b0, y1 = c1, y2 = c2, y3 = c3;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * x0, p1 = (unsigned long long)0xCD9E8D57u * x2;
+        const unsigned long long q0 = (unsigned long long)0xD2511F53u * y0, q1 = (unsigned long long)0xCD9E8D57u * y2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1;
+        const uint32_t m0 = (uint32_t)(q1 >> 32) ^ y1 ^ k0, m2 = (uint32_t)(q0 >> 32) ^ y3 ^ k1;
+        x0 = n0; x1 = (uint32_t)p1; x2 = n2; x3 = (uint32_t)p0;
+        y0 = m0; y1 = (uint32_t)q1; y2 = m2; y3 = (uint32_t)q0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    ra = u32x4{x0, x1, x2, x3};
+    rb = u32x4{y0, y1, y2, y3};
 }
 
 // 2^z from IEEE basic operations only (clamp, rint, fma chain, exponent add): same bits on host and device.

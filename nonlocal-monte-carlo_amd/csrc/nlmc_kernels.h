@@ -479,8 +479,12 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
 
 #ifdef NLMC_DEBUG_KNOBS
 #define NLMC_DBG_NOLOAD && !(a.dbg_flags & 4)
+#define NLMC_DBG_BARRIER if (!(a.dbg_flags & 64)) __syncthreads();
+#define NLMC_DBG_NOPROLOGUE && !(a.dbg_flags & 256)
 #else
+#define NLMC_DBG_NOPROLOGUE
 #define NLMC_DBG_NOLOAD
+#define NLMC_DBG_BARRIER __syncthreads();
 #endif
 #ifdef NLMC_STAMPS
 #define NLMC_FW0 NLMC_CLK(sw0)
@@ -539,6 +543,7 @@ struct SweepArgs {
     const int2 *warm_head;    // head / plane arrays of the NEXT planned window (or nullptr): pulled towards the chip by
     const EdgeQ *warm_ell;    // the helper waves while this window runs
     int f_workers;            // waves that take schedule items
+    int f_gen_prio;           // raise the issue priority of the producing waves
     int f_gen0;               // first wave that produces thresholds (waves [f_gen0, nt/64) share that work)
     int fz_pstride;           // schedule positions reserved per window (plane stride of ell32, length of head32)
     int fz_npos_next;         // positions the NEXT window actually uses (for the warm-up touches)
@@ -699,6 +704,7 @@ __global__ void k_sweep_stream(SweepArgs a)
 template <typename T> struct Pf;            // one schedule item: k, degree, h_k and the packed window of row k
 typedef int nlmc_i4 __attribute__((ext_vector_type(4)));
 typedef int nlmc_i2 __attribute__((ext_vector_type(2)));
+typedef float nlmc_f4 __attribute__((ext_vector_type(4)));
 template <> struct Pf<float> {
     static constexpr int W = NLMC_ELL_W32;
     nlmc_i4 pk[W / 2];            // plane q: { col(2q), Jq(2q), col(2q+1), Jq(2q+1) }   (fixed-point couplings)
@@ -953,19 +959,19 @@ __device__ __forceinline__ void update_spin_q(const SweepArgs &a, ChainCtx &x, c
 #endif
 }
 
+__device__ __forceinline__ float4 thresholds4(const u32x4 &r);
+
 // uniforms of one sweep for every spin of this chain -> LDS.  One Philox4x32-10 call serves 4 (f32) / 2 (f64) spins:
 //   f32: W(k) = threshold_spec(word (k & 3) of philox(k >> 2, t, chain, UNIFORM))
 //   f64: u(k) = 53 bits from words (2(k&1), 2(k&1)+1) of philox(k >> 1, t, chain, UNIFORM)
 __device__ __forceinline__ void fill_uniforms(float *ur, int n, uint32_t tt, uint32_t gc, uint32_t k0, uint32_t k1, int tid, int nt)
 {
-    for (int b = tid; b < (n + 3) / 4; b += nt) {   // "f32" mode: the table holds the logistic thresholds W(r)
-        const u32x4 r = philox4x32_10((uint32_t)b, tt, gc, NLMC_TAG_UNIFORM, k0, k1);
-        float4 v;
-        v.x = threshold_spec(r.x);
-        v.y = threshold_spec(r.y);
-        v.z = threshold_spec(r.z);
-        v.w = threshold_spec(r.w);
-        reinterpret_cast<float4 *>(ur)[b] = v;     // ur has (n+3)/4*4 entries
+    const int nblk = (n + 3) / 4;                    // "f32" mode: the table holds the logistic thresholds W(r)
+    for (int b = tid; b < nblk; b += 2 * nt) {       // two blocks per step: interleaved Philox calls
+        u32x4 r0, r1;
+        philox4x32_10_x2((uint32_t)b, (uint32_t)(b + nt), tt, gc, NLMC_TAG_UNIFORM, k0, k1, r0, r1);
+        reinterpret_cast<float4 *>(ur)[b] = thresholds4(r0);     // ur has (n+3)/4*4 entries
+        if (b + nt < nblk) reinterpret_cast<float4 *>(ur)[b + nt] = thresholds4(r1);
     }
 }
 __device__ __forceinline__ void fill_uniforms(double *ur, int n, uint32_t tt, uint32_t gc, uint32_t k0, uint32_t k1, int tid, int nt)
@@ -1234,60 +1240,84 @@ template <bool COMPACT, bool TAIL> struct FusedItem {
     __device__ __forceinline__ int val(int q) const { return COMPACT ? (int)(short)(word(q) & 0xFFFF) : word(2 * q + 1); }
 };
 
-struct FusedGen {                 // threshold producer of one wave (all members but the lane ids are wave-uniform)
-    const SweepArgs &a;
-    float *ur;
-    uint32_t gc;
-    int gtid, gnt, nblk, nj, Tn;
-    int u, w0, wend, per;
-    __device__ __forceinline__ void arm()
-    {
-        if (u < Tn) {
-            w0 = a.fsend[u - 3];
-            wend = a.fsend[u - 2];
-            const int wlen = max(1, wend - w0);       // levels (w0, wend] are the production window of sweep u
-            per = (nj + wlen - 1) / wlen;
-        } else w0 = 0x7FFFFFFF;
-    }
-    __device__ __forceinline__ void operator()(int l)
-    {
+__device__ __forceinline__ float4 thresholds4(const u32x4 &r)
+{
+    float4 v;
+    v.x = threshold_spec(r.x);
+    v.y = threshold_spec(r.y);
+    v.z = threshold_spec(r.z);
+    v.w = threshold_spec(r.w);
+    return v;
+}
+
+// Threshold producer of one wave.  Block b of sweep u (4 thresholds from one Philox call) belongs to lane b mod gnt of
+// the producing lanes.  The table slot u mod 3 is free once sweep u-3 has ended (level send[u-3]; sweep 2: from the
+// start) and must be complete before the first item of sweep u, which k_levelize_fused places after send[u-2].  A call
+// is cut into TWO steps -- the Philox rounds, then the four logits and the store -- and the 2 nj steps of a lane are
+// spread evenly over that range of levels: integer multiplies are slow on this chip and a level lasts as long as its
+// slowest wave.  The state is a set of LOCAL variables of the function that runs the level loop (a struct handed
+// around by reference ended up in scratch memory: two global-memory round trips per level).
+struct FusedGenParams { uint32_t gc; int gtid, gnt, nblk, nj, Tn; };
 #ifdef NLMC_DEBUG_KNOBS
-        if (a.dbg_flags & 1) return;                 // timing experiment: no threshold production
+#define NLMC_GEN_DBG_OFF_COND (a.dbg_flags & 1)
+#define NLMC_GEN_DBG_PHILOX if (a.dbg_flags & 8) g_r = u32x4{(uint32_t)b * 2654435761u, (uint32_t)b ^ gp.gc, (uint32_t)g_u * 40503u + (uint32_t)b, ~(uint32_t)b}; else
+#define NLMC_GEN_DBG_LOGIT if (a.dbg_flags & 16) dst[b] = nlmc_f4{__uint_as_float(g_r.x & 0x3FFFFFFFu), __uint_as_float(g_r.y & 0x3FFFFFFFu), __uint_as_float(g_r.z & 0x3FFFFFFFu), __uint_as_float(g_r.w & 0x3FFFFFFFu)}; else
+#else
+#define NLMC_GEN_DBG_OFF_COND false
+#define NLMC_GEN_DBG_PHILOX
+#define NLMC_GEN_DBG_LOGIT
 #endif
-        if (l > w0) {
-            const int step = l - w0 - 1;
-            float *dst = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(ur) + (size_t)(u % 3) * a.lds_u_stride);
-            for (int j = step * per; j < min(nj, (step + 1) * per); ++j) {
-                const int b = gtid + j * gnt;
-                if (b < nblk) {
-                    const u32x4 r = philox4x32_10((uint32_t)b, a.sweep0 + (uint32_t)u, gc, NLMC_TAG_UNIFORM, a.seed_lo, a.seed_hi);
-                    float4 v;
-                    v.x = threshold_spec(r.x);
-                    v.y = threshold_spec(r.y);
-                    v.z = threshold_spec(r.z);
-                    v.w = threshold_spec(r.w);
-                    reinterpret_cast<float4 *>(dst)[b] = v;
-                }
-            }
-            if (l == wend) { ++u; arm(); }          // complete before the first item of sweep u (k_levelize_fused floor)
-        }
+// (plain macros over local variables: with lambdas the captured state was kept in scratch memory)
+#define NLMC_GEN_STATE int g_u = 2, g_slot = 2, g_w0 = 0, g_wend = 0, g_per = 1, g_sidx = 0; u32x4 g_r{0u, 0u, 0u, 0u};
+#define NLMC_GEN_ARM(a, gp)                                                                                             \
+    {                                                                                                                   \
+        typedef const int32_t __attribute__((address_space(4))) *const_i32_;                                            \
+        g_sidx = 0;                                                                                                     \
+        if (g_u < gp.Tn) {                                                                                              \
+            const const_i32_ send_ = (const_i32_)(uintptr_t)a.fsend;                                                    \
+            g_w0 = g_u >= 3 ? __builtin_amdgcn_readfirstlane(send_[g_u - 3]) : -1;                                     \
+            g_wend = __builtin_amdgcn_readfirstlane(send_[g_u - 2]);                                                    \
+            const int wlen_ = max(1, g_wend - g_w0);     /* levels (w0, wend] are the production window of sweep u */   \
+            g_per = (2 * gp.nj + wlen_ - 1) / wlen_;                                                                    \
+        } else g_w0 = 0x7FFFFFFF;                                                                                       \
     }
-};
+#define NLMC_GEN_STEP(a, gp)                                                                                            \
+    {                                                                                                                   \
+        const int b = gp.gtid + (g_sidx >> 1) * gp.gnt;                                                                 \
+        if ((g_sidx & 1) == 0) {                                                                                        \
+            NLMC_GEN_DBG_PHILOX                                                                                         \
+            g_r = philox4x32_10((uint32_t)b, a.sweep0 + (uint32_t)g_u, gp.gc, NLMC_TAG_UNIFORM, a.seed_lo, a.seed_hi);  \
+        } else if (b < gp.nblk) {                                                                                       \
+            typedef nlmc_f4 __attribute__((address_space(3))) *lds_f4_;    /* LDS offsets, no generic pointers */         \
+            const lds_f4_ dst = (lds_f4_)(uintptr_t)(unsigned)(a.lds_u_off + g_slot * a.lds_u_stride);                  \
+            NLMC_GEN_DBG_LOGIT                                                                                          \
+            { const float4 t4 = thresholds4(g_r); dst[b] = nlmc_f4{t4.x, t4.y, t4.z, t4.w}; }                           \
+        }                                                                                                               \
+        ++g_sidx;                                                                                                       \
+    }
+#define NLMC_GEN(a, gp, l)                                                                                              \
+    if (!(NLMC_GEN_DBG_OFF_COND) && (l) > g_w0) {                                                                       \
+        for (int i_ = 0; i_ < g_per && g_sidx < 2 * gp.nj; ++i_) NLMC_GEN_STEP(a, gp)                                   \
+        if ((l) == g_wend) { ++g_u; g_slot = g_slot == 2 ? 0 : g_slot + 1; NLMC_GEN_ARM(a, gp) }                        \
+    }
 
 template <bool DIAG, bool FLAGS, bool TAIL, bool GEN, bool COMPACT>
 __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *lds_raw, int wv, int lane, int nl, float cq0,
-                                             float cq1, long long &e_loc, FusedGen &gen)
+                                             float cq1, long long &e_loc, const FusedGenParams gp)
 {
+    NLMC_GEN_STATE
+    NLMC_GEN_ARM(a, gp)
     typedef FusedItem<COMPACT, TAIL> Item;
     constexpr int NP = Item::NP, NE = Item::NE;
     const int plane_bytes = a.fz_pstride * 16;
     const __amdgpu_buffer_rsrc_t r_ell = __builtin_amdgcn_make_buffer_rsrc(const_cast<EdgeQ *>(a.ell32), 0, (NLMC_ELL_W32 / 2) * plane_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_head = __builtin_amdgcn_make_buffer_rsrc(const_cast<int2 *>(a.head32), 0, a.fz_pstride * 8, 0x00020000);
     // level offsets in chunks, read with SCALAR loads (uniform index): no VGPR, no VALU, no vector-memory slot
-    // (constant address space: the plan is read-only while sweep kernels run, and a uniform index then gives s_load_dword)
+    // (constant address space: the plan is read-only while sweep kernels run, and a uniform index then gives s_load_dword;
+    // a register-resident window of offsets picked with v_readlane measured slower)
     typedef const int32_t __attribute__((address_space(4))) *const_i32;
     const const_i32 loffp = (const_i32)(uintptr_t)a.lvl_off;
-    auto loff = [&](int i) { return loffp[i]; };
+    auto lo = [&](int i) __attribute__((always_inline)) { return loffp[min(i, nl)]; };
     const int lane16 = lane * 16, oob = 0x7FF00000;        // oob: past both buffers (the hardware range check drops the load)
     typedef const int8_t __attribute__((address_space(3))) *lds_i8;
     typedef int8_t __attribute__((address_space(3))) *lds_i8w;
@@ -1295,13 +1325,16 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
     typedef const float __attribute__((address_space(3))) *lds_f32;
 
     // chunk `c` of the plan -> registers; has == false: every lane out of range (no memory traffic, registers = 0)
-    auto issue = [&](Item &it, int c, bool has) {
+    auto issue = [&](Item &it, int c, bool has) __attribute__((always_inline)) {
+#ifdef NLMC_DEBUG_KNOBS
+        if (a.dbg_flags & 32) return;                // timing experiment: no vector-memory instructions at all
+#endif
         const int v16 = has ? lane16 : oob;
         it.hd = __builtin_amdgcn_raw_buffer_load_b64(r_head, v16 >> 1, c * 512, 0);
 #pragma unroll
         for (int q = 0; q < NP; ++q) it.pk[q] = __builtin_amdgcn_raw_buffer_load_b128(r_ell, v16, c * 1024 + q * plane_bytes, 0);
     };
-    auto update = [&](const Item &it) {
+    auto update = [&](const Item &it) __attribute__((always_inline)) {
 #ifdef NLMC_DEBUG_KNOBS
         if (a.dbg_flags & 2) { asm volatile("" :: "v"(it.hd.x), "v"(it.pk[0].x), "v"(it.pk[3].x)); return; }   // timing experiment: loads only
 #endif
@@ -1345,40 +1378,68 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
         *(lds_i8w)(uintptr_t)ka = (int8_t)sn;
     };
 
-    // q0..q3 = offsets of levels l..l+3 (scalar registers, fetched two levels ahead of their first use)
-    auto lo = [&](int i) { return loff(min(i, nl)); };
-    Item A, B;
-    int q0 = lo(0), q1 = lo(1), q2 = lo(2), q3 = lo(3);
-    bool hasA = q0 + wv < q1, hasB;
-    issue(A, q0 + wv, hasA);
+    // Order inside a level: update first, THEN loads.  The vector-memory path of the CU is the scarcest resource of
+    // this loop (a 1 KB wave load occupies it ~16 cycles): a wave that issues its loads first blocks on the full queue
+    // with its LDS reads still behind them (measured: 245 vs 184 us per launch).  The loads issued in level l are
+    // those of level l+2 (three register sets, rotated by a 3x unrolled loop), so that they have the whole of level
+    // l+1 to arrive; every wave issues the same number of loads in every level (all lanes out of range when it has no
+    // chunk: the hardware drops them), which keeps the counted vmcnt waits static.
 #ifdef NLMC_STAMPS
     long long sw0, sw1, sw2, st_work = 0, st_bar = 0, st_calls = 0;
 #endif
-    // Order inside a level: update first, THEN the loads of the next level.  The vector-memory path of the CU is the
-    // scarcest resource of this loop (a 1 KB wave load occupies it ~16 cycles; ~65 of them per level): a wave that
-    // issues its loads first blocks on the full queue with its LDS reads still behind them (measured: 245 vs 184 us
-    // per launch).  A wave without a chunk in the next level issues nothing (wave-uniform branch).
-    for (int l = 0; l < nl; l += 2) {
-        const int q4 = lo(l + 4), q5 = lo(l + 5);
-        NLMC_FW0
-        hasB = (l + 1 < nl) && (q1 + wv < q2);             // level l from A; level l+1 into B
-        if (GEN) gen(l);
-        if (hasA) { update(A); NLMC_FCALL }
-        if (hasB NLMC_DBG_NOLOAD) issue(B, q1 + wv, true);
-        NLMC_FW1
-        __syncthreads();
-        NLMC_FW2
-        if (l + 1 < nl) {
+    if constexpr (TAIL && !COMPACT) {
+        // 16-entry rows with 8-byte entries: two register sets of 34 are what the register file allows (depth 1)
+        Item A, B;
+        int q0 = lo(0), q1 = lo(1), q2 = lo(2), q3 = lo(3);
+        bool hasA = q0 + wv < q1, hasB;
+        issue(A, q0 + wv, hasA);
+        for (int l = 0; l < nl; l += 2) {
+            const int q4 = lo(l + 4), q5 = lo(l + 5);
             NLMC_FW0
-            hasA = (l + 2 < nl) && (q2 + wv < q3);
-            if (GEN) gen(l + 1);
-            if (hasB) { update(B); NLMC_FCALL }
-            if (hasA NLMC_DBG_NOLOAD) issue(A, q2 + wv, true);
+            hasB = (l + 1 < nl) && (q1 + wv < q2);             // level l from A; level l+1 into B
+            if (GEN) NLMC_GEN(a, gp, l)
+            if (hasA) { update(A); NLMC_FCALL }
+            issue(B, q1 + wv, hasB NLMC_DBG_NOLOAD);
             NLMC_FW1
             __syncthreads();
             NLMC_FW2
+            if (l + 1 < nl) {
+                NLMC_FW0
+                hasA = (l + 2 < nl) && (q2 + wv < q3);
+                if (GEN) NLMC_GEN(a, gp, l + 1)
+                if (hasB) { update(B); NLMC_FCALL }
+                issue(A, q2 + wv, hasA NLMC_DBG_NOLOAD);
+                NLMC_FW1
+                __syncthreads();
+                NLMC_FW2
+            }
+            q0 = q2; q1 = q3; q2 = q4; q3 = q5;
         }
-        q0 = q2; q1 = q3; q2 = q4; q3 = q5;
+    } else {
+        Item I0, I1, I2;
+        int r0 = lo(0), r1 = lo(1), r2 = lo(2), r3 = lo(3), r4 = lo(4), r5 = lo(5);    // offsets of levels l .. l+5
+        bool h0 = r0 + wv < r1, h1 = (1 < nl) && (r1 + wv < r2), h2;
+        issue(I0, r0 + wv, h0);
+        issue(I1, r1 + wv, h1);
+#define NLMC_FSTAGE(lv, cur, hcur, nxt, hnxt, b2, b3)                                       \
+        {                                                                                   \
+            NLMC_FW0                                                                        \
+            hnxt = ((lv) + 2 < nl) && ((b2) + wv < (b3));                                   \
+            if (GEN) NLMC_GEN(a, gp, lv)                                                    \
+            if (hcur) { update(cur); NLMC_FCALL }                                           \
+            issue(nxt, (b2) + wv, hnxt NLMC_DBG_NOLOAD);                                    \
+            NLMC_FW1                                                                        \
+            NLMC_DBG_BARRIER                                                                \
+            NLMC_FW2                                                                        \
+        }
+        for (int l = 0; l < nl; l += 3) {
+            const int n3 = lo(l + 6), n4 = lo(l + 7), n5 = lo(l + 8);
+            NLMC_FSTAGE(l, I0, h0, I2, h2, r2, r3)
+            if (l + 1 < nl) NLMC_FSTAGE(l + 1, I1, h1, I0, h0, r3, r4)
+            if (l + 2 < nl) NLMC_FSTAGE(l + 2, I2, h2, I1, h1, r4, r5)
+            r0 = r3; r1 = r4; r2 = r5; r3 = n3; r4 = n4; r5 = n5;
+        }
+#undef NLMC_FSTAGE
     }
 #ifdef NLMC_STAMPS
     if (a.dbg && lane == 0) {
@@ -1399,7 +1460,12 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
     long long *red = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);
     const uint32_t gc = (uint32_t)(a.chain_base + c);
     const int row = a.slot_of_chain ? a.slot_of_chain[gc] : c;
-    const int Tn = a.n_sweeps, nl = a.nlev[0];
+    const int Tn = a.n_sweeps;
+#ifdef NLMC_DEBUG_KNOBS
+    const int nl = (a.dbg_flags & 128) ? 0 : a.nlev[0];      // timing experiment: prologue + epilogue only
+#else
+    const int nl = a.nlev[0];
+#endif
 #ifdef NLMC_STAMPS
     const long long st_begin = (long long)__builtin_readcyclecounter();
 #endif
@@ -1420,29 +1486,31 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
         }
         if (tid == 0) red[0] = 0;
     }
-    // thresholds of the first three sweeps
-    for (int t = 0; t < min(3, Tn); ++t)
+    // thresholds of the first two sweeps (the third table is produced inside the level loop like all later ones)
+    for (int t = 0; t < min(2, Tn) NLMC_DBG_NOPROLOGUE; ++t)
         fill_uniforms(reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(ur) + (size_t)t * a.lds_u_stride), n,
                       a.sweep0 + (uint32_t)t, gc, a.seed_lo, a.seed_hi, tid, nt);
     __syncthreads();
 
     const int g0 = a.f_gen0 * 64, nblk = (n + 3) / 4, gnt = nt - g0;
-    FusedGen gen{a, ur, gc, tid - g0, gnt, nblk, (nblk + gnt - 1) / gnt, Tn, 3, 0, 0, 1};
-    gen.arm();
+    const FusedGenParams gp{gc, tid - g0, gnt, nblk, (nblk + gnt - 1) / gnt, Tn};
     const bool is_gen = tid >= g0;
+    // The producing waves are the youngest of their SIMDs and would get the issue slots the older worker waves leave
+    // over (measured: a 150-instruction call stretched to ~3000 cycles while the workers waited at the barrier).
+    if (is_gen && a.f_gen_prio) __builtin_amdgcn_s_setprio(2);
     long long e_loc = 0;
     if (wv < a.f_workers) {
         const bool role_long = wv < a.hi_max[0];           // chunks that may hold rows longer than 8 entries come first
         const int variant = (role_long ? 4 : 0) + (is_gen ? 2 : 0) + (a.fz_compact ? 1 : 0);
         switch (variant) {
-        case 0: fused_levels<DIAG, FLAGS, false, false, false>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gen); break;
-        case 1: fused_levels<DIAG, FLAGS, false, false, true>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gen); break;
-        case 2: fused_levels<DIAG, FLAGS, false, true, false>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gen); break;
-        case 3: fused_levels<DIAG, FLAGS, false, true, true>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gen); break;
-        case 4: fused_levels<DIAG, FLAGS, true, false, false>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gen); break;
-        case 5: fused_levels<DIAG, FLAGS, true, false, true>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gen); break;
-        case 6: fused_levels<DIAG, FLAGS, true, true, false>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gen); break;
-        default: fused_levels<DIAG, FLAGS, true, true, true>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gen); break;
+        case 0: fused_levels<DIAG, FLAGS, false, false, false>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
+        case 1: fused_levels<DIAG, FLAGS, false, false, true>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
+        case 2: fused_levels<DIAG, FLAGS, false, true, false>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
+        case 3: fused_levels<DIAG, FLAGS, false, true, true>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
+        case 4: fused_levels<DIAG, FLAGS, true, false, false>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
+        case 5: fused_levels<DIAG, FLAGS, true, false, true>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
+        case 6: fused_levels<DIAG, FLAGS, true, true, false>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
+        default: fused_levels<DIAG, FLAGS, true, true, true>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
         }
     } else {
         // Waves without schedule items: their share of the thresholds, and they pull the NEXT window's schedule towards
@@ -1451,6 +1519,8 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
         // that every chain of an XCD then waits on.  The chains of a launch share the work: one dword per 128-byte line
         // of the head array and of planes 0-3, striped over chains and helper lanes, one load per level, retired a
         // level later.
+        NLMC_GEN_STATE
+        NLMC_GEN_ARM(a, gp)
         const int hid = tid - a.f_workers * 64, hcnt = nt - a.f_workers * 64;
         const unsigned warm_lines = a.warm_head ? (unsigned)(((size_t)a.fz_npos_next * 8 + 127) / 128) : 0u;       // head
         const unsigned warm_lines_p = a.warm_head ? (unsigned)(((size_t)a.fz_pstride * 16 + 127) / 128) : 0u;     // lines per plane
@@ -1474,7 +1544,7 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
         };
         for (int l = 0; l < nl; ++l) {
             warm_next();
-            if (is_gen) gen(l);
+            if (is_gen) NLMC_GEN(a, gp, l)
             __syncthreads();
         }
         while (warm_at < warm_total) warm_next();     // few chains: the rest of this chain's share

@@ -10,7 +10,7 @@ of ranks.
 """
 import numpy as np
 
-from .engine import RoundPlanner
+from .engine import Engine, RoundPlanner
 
 
 def block_partition(n_global, world, rank):
@@ -105,4 +105,87 @@ class ShardedTempering:
         return out.cpu().numpy()
 
     def close(self):
-        self.eng.close()
+        try:
+            if self.n_pairs > 0 and hasattr(self.eng, "pt_check"):
+                self.eng.pt_check()          # a swap round whose pair selection ran out raises here at the latest
+        finally:
+            self.eng.close()
+
+
+class LocalTempering:
+    """The same sharded tempering driven by ONE process over several contexts -- one per entry of `device_ids`
+    (NPT.run(device_ids=...), APT_ICM.run(device_ids=...); the reference's knob is num_cores, NPT/npt.py:535-539,616).
+    Chains are cut into contiguous blocks like ShardedTempering; per round the tracked energies of every block pass
+    through host memory (G float64) and every context takes the identical Philox-keyed swap decision, so the trajectory
+    equals the single-context one bit for bit.  For one GPU per process over RCCL use ShardedTempering."""
+
+    def __init__(self, inst, beta_list, n_chains_global, seed, n_pairs, device_ids, precision="f32"):
+        self.G, self.seed, self.n_pairs, self.precision = int(n_chains_global), int(seed), int(n_pairs), precision
+        devs = list(device_ids)
+        self.parts = [block_partition(self.G, len(devs), r) for r in range(len(devs))]
+        self.engs = []
+        try:
+            for d, (base, count) in zip(devs, self.parts):
+                e = Engine(inst, None, count, device=int(d), chain_base=base, n_chains_global=self.G)
+                e.pt_init(np.asarray(beta_list, dtype=np.float64))
+                self.engs.append(e)
+        except Exception:
+            self.close()
+            raise
+        self.sweeps_done = self.rounds_done = 0
+        self._planners = None
+
+    def set_spins(self, spins_global):
+        for e, (base, count) in zip(self.engs, self.parts):
+            e.set_spins(np.asarray(spins_global)[base:base + count])
+
+    def plan(self, n_sweeps, n_rounds, chunk_rounds=None):
+        self._planners = [RoundPlanner(e, self.sweeps_done, n_rounds, n_sweeps // max(1, n_rounds), self.seed,
+                                       precision=self.precision, budget_bytes=8 << 30, chunk_rounds=chunk_rounds,
+                                       pt_pairs=self.n_pairs, pt_round0=self.rounds_done) for e in self.engs]
+        self._planner_round0 = self.rounds_done
+
+    def log_begin(self, n_rounds):
+        for e in self.engs:
+            e.pt_log_begin(self.rounds_done, n_rounds, self.n_pairs)
+
+    def round(self, n_sweeps, **outputs):
+        """Sweeps of every block (launched back to back: the devices work concurrently), then one swap round.  Returns
+        the per-context sweep outputs."""
+        ii = self.rounds_done - (self._planner_round0 if self._planners else 0)
+        outs = []
+        for k, e in enumerate(self.engs):
+            if self._planners and 0 <= ii < self._planners[k].R and n_sweeps == self._planners[k].S:
+                outs.append(self._planners[k].sweep(ii, **outputs))
+            else:
+                outs.append(e.sweep_philox(n_sweeps, self.seed, sweep0=self.sweeps_done, beta=None, precision=self.precision,
+                                           **outputs))
+        self.sweeps_done += n_sweeps
+        if self.n_pairs > 0:
+            if len(self.engs) == 1:
+                self.engs[0].pt_swap_philox(self.rounds_done, self.seed, self.n_pairs, want_log=False)
+            else:
+                E = np.concatenate([e.energy_tracked() for e in self.engs])
+                for e in self.engs:
+                    e.pt_swap_philox_host(self.rounds_done, self.seed, self.n_pairs, E)
+        self.rounds_done += 1
+        return outs
+
+    def slots(self):
+        return self.engs[0].pt_slots()
+
+    def swap_log(self):
+        return self.engs[0].pt_log_read()
+
+    def gather_spins(self):
+        return np.concatenate([e.get_spins() for e in self.engs])
+
+    def check(self):
+        if self.n_pairs > 0:
+            for e in self.engs:
+                e.pt_check()
+
+    def close(self):
+        for e in self.engs:
+            e.close()
+        self.engs = []

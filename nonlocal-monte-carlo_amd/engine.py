@@ -115,6 +115,12 @@ class Engine:
         self._ck(self._L.nlmc_energy(self._ctx, _abi.ptr(out)))
         return out
 
+    def energy_tracked(self):
+        """The incrementally tracked energies (no recomputation)."""
+        out = np.empty(self.n_chains, dtype=np.float64)
+        self._ck(self._L.nlmc_energy_tracked(self._ctx, _abi.ptr(out)))
+        return out
+
     def set_energy_sink(self, dev_ptr):
         """Later sweep calls also write the tracked energies of their final states to this device buffer (None: off)."""
         self._ck(self._L.nlmc_set_energy_sink(self._ctx, ctypes.c_void_p(int(dev_ptr)) if dev_ptr else None))
@@ -239,8 +245,34 @@ class Engine:
                                              _abi.ptr(acc)))
         return pairs, acc
 
+    def pt_swap_philox_host(self, round_idx, seed, n_pairs, energies_all, want_log=False):
+        """Swap round of a sharded context with the all-gathered energies in host memory."""
+        nl = self.n_chains_global // self.ladder_len
+        pairs = np.empty((nl, n_pairs, 2), np.int32) if want_log else None
+        acc = np.empty((nl, n_pairs), np.uint8) if want_log else None
+        e = _abi.as_c(energies_all, np.float64).reshape(self.n_chains_global)
+        self._ck(self._L.nlmc_pt_swap_philox_host(self._ctx, int(round_idx), int(seed), int(n_pairs), _abi.ptr(e),
+                                                  _abi.ptr(pairs), _abi.ptr(acc)))
+        return pairs, acc
+
     def pt_plan(self, round0, n_rounds, seed, n_pairs):
         self._ck(self._L.nlmc_pt_plan(self._ctx, int(round0), int(n_rounds), int(seed), int(n_pairs)))
+
+    def pt_log_begin(self, round0, n_rounds, n_pairs):
+        """Keep the swap log of the next rounds on the device (rounds called with want_log=False)."""
+        self._ck(self._L.nlmc_pt_log_begin(self._ctx, int(round0), int(n_rounds), int(n_pairs)))
+        self._pt_log_shape = (int(n_rounds), self.n_chains_global // self.ladder_len, int(n_pairs))
+
+    def pt_log_read(self):
+        r, nl, p = self._pt_log_shape
+        pairs, acc = np.empty((r, nl, p, 2), np.int32), np.empty((r, nl, p), np.uint8)
+        if r * nl * p:
+            self._ck(self._L.nlmc_pt_log_read(self._ctx, _abi.ptr(pairs), _abi.ptr(acc)))
+        return pairs, acc
+
+    def pt_check(self):
+        """ValueError("Cannot find non-overlapping pairs.") if a device-decided swap round ran out of pairs (NPT/npt.py:526)."""
+        self._ck(self._L.nlmc_pt_check(self._ctx))
 
     # -- iso-cluster move -------------------------------------------------------------------------------
     def icm_components(self, chain_a, chain_b):

@@ -67,8 +67,13 @@ class NPT(Common):
             num_swapping_pairs=1, num_cycles=10, full_update_frequency=1, M_skip=1, temp_x=20, global_beta=2.5,
             lambda_start=0.5, lambda_end=0.01, lambda_reduction_factor=0.9, threshold_initial=0.999999,
             threshold_cutoff=0.99999, max_iterations=100, tolerance=np.finfo(float).eps, use_hash_table=False,
-            num_cores=8, plot=False):
-        """Run the NPT algorithm (NPT/npt.py:535-700).  Returns (M [R*N, S_swap], Energy [R])."""
+            num_cores=8, plot=False, num_restarts=1, device_ids=None, return_trace="float64"):
+        """Run the NPT algorithm (NPT/npt.py:535-700).  Returns (M [R*N, S_swap], Energy [R]).
+
+        Additive keyword arguments (defaults = the reference's behaviour): `num_restarts` independent ladders advanced
+        together and `device_ids` (GPUs the chains are sharded over; the reference's knob is num_cores, NPT/npt.py:616)
+        -- both for rng="philox" runs without NMC replicas; M and Energy describe restart 0, `self.restart_energies`
+        [num_restarts, R] all of them.  `return_trace`: "float64" (reference dtype), "int8", or None (M is not built)."""
         self.num_replicas = num_replicas
         self.num_sweeps_MCMC = num_sweeps_MCMC
         self.num_sweeps_read = num_sweeps_read
@@ -87,14 +92,22 @@ class NPT(Common):
             raise ValueError("The length of doNMC does not match the number of replicas.")
         beta_list = np.asarray(beta_list, dtype=np.float64)
 
-        if self.rng == "philox" and not any(bool(v) for v in doNMC):
-            M, Energy = self._run_device_resident(beta_list)
+        if return_trace not in ("float64", "int8", None):
+            raise ValueError("return_trace must be 'float64', 'int8' or None")
+        device_resident = self.rng == "philox" and not any(bool(v) for v in doNMC)
+        if (int(num_restarts) != 1 or (device_ids is not None and len(list(device_ids)) > 1)) and not device_resident:
+            raise ValueError("num_restarts / device_ids need rng='philox' and no NMC replicas (the reference's own stream "
+                             "order has one ladder in one process)")
+        if int(num_restarts) < 1:
+            raise ValueError("num_restarts must be >= 1")
+        if device_resident:
+            M, Energy = self._run_device_resident(beta_list, int(num_restarts), device_ids, return_trace)
         else:
             M, Energy = self._run_host_managed(beta_list, num_cycles, full_update_frequency, M_skip, temp_x, global_beta,
                                                lambda_start, lambda_end, lambda_reduction_factor, threshold_initial,
                                                threshold_cutoff, max_iterations, tolerance)
         print(f"\nLatest energy from each replica = {Energy}")
-        if plot:
+        if plot and M is not None:
             self.plot_energies([self.replica_energy(M[r * self._n:(r + 1) * self._n, :], self.num_sweeps_read_per_swap)[1]
                                 for r in range(num_replicas)], beta_list)
         return M, Energy
@@ -243,57 +256,84 @@ class NPT(Common):
         return selected
 
     # ------------------------------------------------------------------------------------------------
-    def _run_device_resident(self, beta_list, n_restarts=1):
-        """Throughput path: all replicas (x restarts) in one context, label-exchange swaps decided on the device."""
+    def _run_device_resident(self, beta_list, n_restarts=1, device_ids=None, return_trace="float64"):
+        """Throughput path: all replicas (x restarts) stay on the device(s); label-exchange swaps decided by a kernel; the
+        swap log is kept on the device and read once; only the last round's trace comes back (as int8 until the
+        reference-shaped float64 M is asked for)."""
+        from .distributed import LocalTempering
         inst = self._cache.instance(self.J, self.h)
         R, N = self.num_replicas, inst.n
         self._n = N
         S = self.num_sweeps_MCMC_per_swap
         rounds = self.num_swap_attempts
         G = R * n_restarts
-        eng = Engine(inst, None, G, device=self._cache.device)
+        devs = [self._cache.device] if not device_ids else [int(d) for d in device_ids]
+        if G % len(devs):
+            raise ValueError("num_replicas * num_restarts must be a multiple of len(device_ids)")
+        lt = LocalTempering(inst, beta_list, G, self.seed, self.num_swapping_pairs, devs)
         try:
-            m0 = np.sign(2 * np.random.default_rng(self.seed).random((G, N)) - 1).astype(np.int8)
-            eng.set_spins(m0)
-            eng.pt_init(beta_list)
-            planner = RoundPlanner(eng, self._sweep_counter, rounds, S, self.seed)
+            m0 = np.sign(np.random.default_rng(self.seed).random((G, N)) - 0.5).astype(np.int8)   # == sign(2 u - 1)
+            lt.set_spins(m0)
+            lt.sweeps_done = self._sweep_counter
+            lt.plan(rounds * S, rounds)
             if self.num_swapping_pairs > 0:
-                eng.pt_plan(0, rounds, self.seed, self.num_swapping_pairs)
-            pairs_log, acc_log = [], []
-            last = None
-            slots_last = np.arange(G, dtype=np.int32) % R
+                lt.log_begin(rounds)
+            last, e_last, slots_last = None, None, np.arange(G, dtype=np.int32) % R
             for ii in range(rounds):
                 is_last = ii == rounds - 1
                 if is_last:
-                    slots_last = eng.pt_slots()
-                o = planner.sweep(ii, record_stride=1 if is_last else 0)
-                if is_last:
-                    last = o["spins"]
-                if self.num_swapping_pairs > 0:
-                    p, a = eng.pt_swap_philox(ii, self.seed, self.num_swapping_pairs, want_log=True)
-                    pairs_log.append(p)
-                    acc_log.append(a)
-            self._sweep_counter += rounds * S
-            M = np.zeros((R * N, S))
-            Energy = np.zeros(R)
-            if last is not None:
-                for c in range(R):                       # restart 0 is the one returned in the reference's shape
-                    r = int(slots_last[c])
-                    M[r * N:(r + 1) * N, :] = last[c].T
-                # replica_energy (NPT/npt.py:31-45, :685-692) of every replica: min over the FIRST R_swap columns --
-                # one batched energy call instead of one per replica
-                k = self.num_sweeps_read_per_swap
-                if k > 0:
-                    E_cols = eng.energy_of(np.ascontiguousarray(last[:R, :k]).reshape(R * k, N)).reshape(R, k)
-                    Energy[slots_last[:R]] = E_cols.min(axis=1)
+                    slots_last = lt.slots()
+                if not is_last:
+                    lt.round(S)
+                elif return_trace is not None:
+                    last = np.concatenate([o["spins"] for o in lt.round(S, record_stride=1)])       # [G, S, N] int8
                 else:
-                    for r in range(R):
-                        Energy[r] = self.replica_energy(M[r * N:(r + 1) * N, :], k)[0]     # np.min of nothing: ValueError
-            self.swap_pairs = (np.concatenate([p[0] for p in pairs_log]) + 1) if pairs_log else np.zeros((0, 2), np.int32)
-            self.swap_accepted = np.concatenate([a[0] for a in acc_log]).astype(np.int8) if acc_log else np.zeros(0, np.int8)
-            self.final_slots = eng.pt_slots()
+                    e_last = np.concatenate([o["energy"] for o in lt.round(S, want_energy=True)])   # [G, S] tracked
+            self._sweep_counter += rounds * S
+            Energy = np.zeros(R)
+            E_all = np.zeros((n_restarts, R))
+            k = self.num_sweeps_read_per_swap
+            if last is not None and S > 0:
+                # replica_energy (NPT/npt.py:31-45, :685-692) of every replica: min over the FIRST R_swap columns -- one
+                # batched energy call per context instead of one per replica
+                if k > 0:
+                    E_cols = np.concatenate([e.energy_of(np.ascontiguousarray(last[b:b + c, :k]).reshape(c * k, N)).reshape(c, k)
+                                             for e, (b, c) in zip(lt.engs, lt.parts)])
+                    E_min = E_cols.min(axis=1)
+                    for g in range(G):
+                        E_all[g // R, int(slots_last[g])] = E_min[g]
+                    Energy = E_all[0].copy()
+                else:
+                    Energy[0] = np.min(np.zeros(0))                              # np.min of nothing: ValueError (NPT/npt.py:43)
+            elif return_trace is None and S > 0 and rounds > 0:
+                # no trace comes back: the read-out uses the energies tracked by the sweep kernel (exact for the
+                # fixed-point couplings, within 2^-(qs+1) per coupling of the fp64 ones)
+                if k <= 0:
+                    Energy[0] = np.min(np.zeros(0))
+                E_min = e_last[:, :k].min(axis=1)
+                for g in range(G):
+                    E_all[g // R, int(slots_last[g])] = E_min[g]
+                Energy = E_all[0].copy()
+            M = None
+            if return_trace is not None:
+                dt = np.float64 if return_trace == "float64" else np.int8
+                if last is not None:                     # restart 0 is the one returned in the reference's shape
+                    M3 = np.empty((R, N, S), dtype=dt)   # block r = the replica at temperature slot r
+                    M3[slots_last[:R]] = last[:R].transpose(0, 2, 1)
+                    M = M3.reshape(R * N, S)
+                else:
+                    M = np.zeros((R * N, S), dtype=dt)
+            if self.num_swapping_pairs > 0 and rounds > 0:
+                p, a = lt.swap_log()                     # [rounds, ladders, pairs, 2] / [rounds, ladders, pairs]
+                self.swap_pairs = p[:, 0].reshape(-1, 2) + 1
+                self.swap_accepted = a[:, 0].reshape(-1).astype(np.int8)
+                self.swap_acceptance_per_restart = a.reshape(rounds, n_restarts, -1).mean(axis=(0, 2))
+            else:
+                self.swap_pairs, self.swap_accepted = np.zeros((0, 2), np.int32), np.zeros(0, np.int8)
+            self.final_slots = lt.slots()
+            self.restart_energies = E_all
         finally:
-            eng.close()
+            lt.close()
         return M, Energy
 
     def plot_energies(self, EE1_list, beta_list):

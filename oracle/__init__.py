@@ -172,10 +172,13 @@ def cb_pair(beta, temp_x=1.0, use_f64=False):
     return float(np.float32(a)), float(np.float32(b))
 
 
-def sweeps_philox(csr, h, s_start, cb_run, seed, chain_id, order_group=0, sweep0=0, flags=None, escale=32,
+def sweeps_philox(csr, h, s_start, cb_run, seed, chain_id, order_group=0, sweep0=0, flags=None, escale=None,
                   use_f64=False, efix0=0, want_M=True):
-    """Sequential spec of the throughput mode for ONE chain.  cb_run: [S,2] (normal, scaled)."""
+    """Sequential spec of the throughput mode for ONE chain.  cb_run: [S,2] (normal, scaled).  escale: log2 of the
+    fixed-point energy unit (default: the instance's own, field_scale)."""
     n = csr.n
+    if escale is None:
+        escale = field_scale(csr, h)[1]
     cb_run = np.ascontiguousarray(cb_run, dtype=np.float64).reshape(-1, 2)
     S = cb_run.shape[0]
     s = np.ascontiguousarray(np.asarray(s_start, dtype=np.int8).reshape(-1).copy())

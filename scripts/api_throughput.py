@@ -7,14 +7,17 @@ from helpers import make_instance
 P = load_product()
 for (N, R, sweeps, rounds, pairs) in ((10_000, 256, 1000, 100, 77), (1000, 32, 10_000, 100, 10)):
     J, h = make_instance(N)
-    obj = P.NPT(J, h, rng="philox", seed=1)
-    with contextlib.redirect_stdout(io.StringIO()):
-        t0 = time.perf_counter()
-        M, E = obj.run(np.geomspace(0.05, 4.0, R), R, [False] * R, num_sweeps_MCMC=sweeps, num_sweeps_read=sweeps,
-                       num_swap_attempts=rounds, num_swapping_pairs=pairs)
-        dt = time.perf_counter() - t0
-    print(f"NPT.run philox N={N} R={R} sweeps={sweeps} rounds={rounds}: {dt:.3f} s wall incl. instance upload, planning, "
-          f"read-out -> {R * N * sweeps / dt:.3e} updates/s ; min energy {E.min():.1f} ; swaps accepted {obj.swap_accepted.mean():.2f}", flush=True)
+    for trace in ("float64", "int8", None):
+        for rep in range(2):                                  # second call: library, caches and allocator are warm
+            obj = P.NPT(J, h, rng="philox", seed=1)
+            with contextlib.redirect_stdout(io.StringIO()):
+                t0 = time.perf_counter()
+                M, E = obj.run(np.geomspace(0.05, 4.0, R), R, [False] * R, num_sweeps_MCMC=sweeps, num_sweeps_read=sweeps,
+                               num_swap_attempts=rounds, num_swapping_pairs=pairs, return_trace=trace)
+                dt = time.perf_counter() - t0
+        print(f"NPT.run philox N={N} R={R} sweeps={sweeps} rounds={rounds} return_trace={trace}: {dt:.3f} s wall incl. instance "
+              f"upload, planning, read-out -> {R * N * sweeps / dt:.3e} updates/s ; min energy {E.min():.1f} ; swaps accepted "
+              f"{obj.swap_accepted.mean():.2f}", flush=True)
 
 # NMC(J, h, rng="philox").run(): single chain, the reference's headline call (NMC/examples/general_example.py)
 for (N, s0, s, cycles) in ((1000, 1000, 1000, 4), (10_000, 1000, 1000, 2)):

@@ -361,3 +361,43 @@ def test_chimera2048_known_answer_and_search(product):
     best = E.min() * nf
     assert best >= e_gs - 1e-3
     assert best <= e_gs * (1 - 0.005), (best, e_gs)
+
+
+@pytest.mark.gpu
+def test_npt_philox_restarts_devices_and_trace_kwargs(product):
+    """The additive run() keyword arguments (num_restarts, device_ids, return_trace; the reference's parallelism knob is
+    num_cores, NPT/npt.py:535-539,616): restart 0 does not notice the other restarts; sharding the chains over several
+    contexts (here: of the one device present) changes no bit, also when a ladder is cut in two; the swap log comes from
+    the device-side log."""
+    from helpers import make_instance
+    N, R = 300, 8
+    J, h = make_instance(N, seed=23, with_h=True, gaussian=True)
+    betas = np.geomspace(0.2, 2.5, R)
+
+    def go(rng="philox", **kw):
+        obj = product.NPT(J.toarray(), h, rng=rng, seed=5)
+        with quiet():
+            M, E = obj.run(betas, R, [False] * R, num_sweeps_MCMC=60, num_sweeps_read=60, num_swap_attempts=6,
+                           num_swapping_pairs=2, **kw)
+        return obj, M, E
+    o1, M1, E1 = go()
+    assert M1.shape == (R * N, 10) and M1.dtype == np.float64 and o1.swap_pairs.shape == (12, 2)
+    o2, M2, E2 = go(num_restarts=3)
+    assert np.array_equal(M1, M2) and np.array_equal(E1, E2)
+    assert o2.restart_energies.shape == (3, R) and np.array_equal(o2.restart_energies[0], E1)
+    assert np.array_equal(o1.swap_pairs, o2.swap_pairs) and np.array_equal(o1.swap_accepted, o2.swap_accepted)
+    assert not np.array_equal(o2.restart_energies[0], o2.restart_energies[1])
+    o3, M3, E3 = go(num_restarts=3, device_ids=[0, 0, 0])              # one ladder per context
+    o4, M4, E4 = go(num_restarts=3, device_ids=[0, 0, 0, 0, 0, 0])     # every ladder cut in two
+    for o, M, E in ((o3, M3, E3), (o4, M4, E4)):
+        assert np.array_equal(M, M2) and np.array_equal(E, E2) and np.array_equal(o.restart_energies, o2.restart_energies)
+        assert np.array_equal(o.swap_pairs, o2.swap_pairs) and np.array_equal(o.swap_accepted, o2.swap_accepted)
+        assert np.array_equal(o.final_slots, o2.final_slots)
+    _, M5, E5 = go(return_trace="int8")
+    assert M5.dtype == np.int8 and np.array_equal(M5, M1) and np.array_equal(E5, E1)
+    _, M6, E6 = go(return_trace=None)
+    assert M6 is None and np.allclose(E6, E1, rtol=0, atol=1e-4)       # read-out from the tracked energies
+    with pytest.raises(ValueError):
+        go(rng="numpy", num_restarts=2)
+    with pytest.raises(ValueError):
+        go(num_restarts=3, device_ids=[0, 0, 0, 0, 0])                 # 24 chains do not split over 5 contexts

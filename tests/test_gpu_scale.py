@@ -28,7 +28,7 @@ def test_c4_size_energy_consistency_and_oracle_sample(product):
         exact = eng.energy()
         esc = eng.energy_scale
     assert np.array_equal(tracked, exact)                     # integer-valued instance: no rounding anywhere
-    assert np.all(exact <= E0 + 1e-9) or True
+    assert np.all(exact[128:] < E0[128:])                      # the cold half of the ladder relaxed from its random start
     for c in (0, 77, 255):                                     # hot, middle, cold chain against the sequential spec
         cb = np.tile(np.array(oracle.cb_pair(betas[c])), (S, 1))
         _, s_fin, tr = oracle.sweeps_philox(csr, h, m0[c], cb, 0xA5A50000, c, escale=esc,
