@@ -269,20 +269,23 @@ int fused_workers(int nt)
     return 14;
 }
 
-// LDS of k_sweep_fused: spins (+16: scratch spin of the dummy items) | flags (+16) | 3 threshold tables | reduction scratch
-struct FusedLds { int flags_off, u_off, u_bytes, red_off; size_t total; };
-FusedLds fused_lds(int n, int n_pad, bool has_flags, int T)
+// LDS of k_sweep_fused: spins (+16: scratch spin of the dummy items) | flags (+16) | 3 threshold tables of n_pad words |
+// (per-sweep outputs only) 3 snapshot slots of n_pad bytes | reduction scratch
+struct FusedLds { int flags_off, u_off, u_bytes, snap_off, red_off; size_t total; };
+FusedLds fused_lds(int n, int n_pad, bool has_flags, bool with_out)
 {
-    (void)T;
+    (void)n;
     FusedLds L{};
     L.flags_off = n_pad + 16;
     int cur = (n_pad + 16) * (has_flags ? 2 : 1);
     cur = (cur + 15) / 16 * 16;
     L.u_off = cur;
-    L.u_bytes = (((n + 3) / 4 * 4) * 4 + 15) / 16 * 16;
+    L.u_bytes = n_pad * 4;               // threshold word of (slot, k) = slot * n_pad + k = its snapshot byte, too
     cur += 3 * L.u_bytes;
+    L.snap_off = cur;
+    if (with_out) cur += 3 * n_pad + 16;
     L.red_off = cur;
-    L.total = (size_t)cur + 16;
+    L.total = (size_t)cur + 32;
     return L;
 }
 
@@ -305,21 +308,41 @@ bool fused_supported(const nlmc_ctx *c, int T)
     if (c->n < 256 || c->n > NLMC_FZ_SPT * 1024 || c->max_deg > 0x3FFF || T < 3 || T > NLMC_FUSED_TMAX) return false;
     if ((size_t)T * c->n > ((size_t)1 << 22)) return false;            // 32-bit buffer offsets of the packed planes
     if (c->n_pad + 16 > 0x3FFF) return false;                          // spin address in 14 bits of the item head
-    const FusedLds L = fused_lds(c->n, c->n_pad, true, T);
+    (void)T;
+    const FusedLds L = fused_lds(c->n, c->n_pad, true, false);
     if (3 * L.u_bytes / 4 > 0xFFFF) return false;                      // threshold word index in 16 bits
     return L.total <= (size_t)150 * 1024;
 }
 
-int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *tab_dev, int tab_cs, bool use_slots)
+struct SweepOut {
+    int record_stride;
+    int8_t *out_spins;
+    double *out_energy;
+    double *out_min_energy;
+    int32_t *out_argmin;
+    int8_t *out_argmin_state;
+};
+
+// One fused window.  `outs` (nullable): the launch also produces per-sweep outputs into the context's device buffers
+// (etrace / emin / argmin / best / strace, sized by the caller) as sweeps [t0, t0 + T) of a call of n_total sweeps.
+int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *tab_dev, int tab_cs, int tab_ss, bool use_slots,
+              bool outs, bool want_energy, bool want_min, bool want_state, int rec, int t0, int n_total)
 {
     const int R = c->n_chains, n = c->n, T = c->fz_T;
     const size_t PS = (size_t)c->fz_pstride;
-    const FusedLds L = fused_lds(c->n, c->n_pad, c->has_flags, T);
-    const int variant = (c->has_diag ? 2 : 0) + (c->has_flags ? 1 : 0);
-    const void *kfun = variant == 0 ? reinterpret_cast<const void *>(k_sweep_fused<false, false>)
-                       : variant == 1 ? reinterpret_cast<const void *>(k_sweep_fused<false, true>)
-                       : variant == 2 ? reinterpret_cast<const void *>(k_sweep_fused<true, false>)
-                                      : reinterpret_cast<const void *>(k_sweep_fused<true, true>);
+    const FusedLds L = fused_lds(c->n, c->n_pad, c->has_flags, outs);
+    const int variant = (outs ? 4 : 0) + (c->has_diag ? 2 : 0) + (c->has_flags ? 1 : 0);
+    const void *kfun = nullptr;
+    switch (variant) {
+    case 0: kfun = reinterpret_cast<const void *>(k_sweep_fused<false, false, false>); break;
+    case 1: kfun = reinterpret_cast<const void *>(k_sweep_fused<false, true, false>); break;
+    case 2: kfun = reinterpret_cast<const void *>(k_sweep_fused<true, false, false>); break;
+    case 3: kfun = reinterpret_cast<const void *>(k_sweep_fused<true, true, false>); break;
+    case 4: kfun = reinterpret_cast<const void *>(k_sweep_fused<false, false, true>); break;
+    case 5: kfun = reinterpret_cast<const void *>(k_sweep_fused<false, true, true>); break;
+    case 6: kfun = reinterpret_cast<const void *>(k_sweep_fused<true, false, true>); break;
+    default: kfun = reinterpret_cast<const void *>(k_sweep_fused<true, true, true>); break;
+    }
     { int rc = ensure_lds(c, 8 + variant, kfun, L.total); if (rc) return rc; }
     hipEvent_t e0 = next_event(c), e1 = next_event(c), e2 = next_event(c);
     if (!e0 || !e1 || !e2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
@@ -353,17 +376,25 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
     a.n_sweeps = T;
     a.sweep0 = sweep0;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-    a.tab = tab_dev; a.tab_cs = tab_cs; a.tab_ss = 0;
+    a.tab = tab_dev; a.tab_cs = tab_cs; a.tab_ss = tab_ss;
     a.slot_of_chain = use_slots ? c->slot_of_chain.p : nullptr;
     a.efix = c->efix.p;
     a.energy_sink = c->energy_sink;
     a.escale = c->escale;
     a.eshift = c->escale - c->qs;
     a.qinv = std::ldexp(1.0f, -c->qs);
-    a.trace_sweeps = T;
-    a.rec_stride = 1;
+    a.trace_sweeps = outs ? n_total : T;
+    a.t0 = t0;
+    a.rec_stride = rec ? rec : 1;
     a.argmin = c->argmin.p;
+    if (outs) {
+        a.etrace = want_energy ? c->etrace.p : nullptr;
+        a.strace = rec ? c->strace.p : nullptr;
+        a.emin = want_min ? c->emin.p : nullptr;
+        a.best = (want_min && want_state) ? c->best.p : nullptr;
+    }
     a.lds_flags_off = L.flags_off; a.lds_u_off = L.u_off; a.lds_u_stride = L.u_bytes; a.lds_red_off = L.red_off;
+    a.lds_snap_off = L.snap_off;
 #ifdef NLMC_STAMPS
     HIP_TRY(c, c->dbg.reserve((size_t)R * 16 * 8 + 96));
     HIP_TRY(c, hipMemsetAsync(c->dbg.p, 0, ((size_t)R * 16 * 8 + 96) * sizeof(long long), c->stream));
@@ -371,10 +402,14 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
 #endif
     const int nt = fused_block(n);
     switch (variant) {
-    case 0: hipLaunchKernelGGL((k_sweep_fused<false, false>), dim3(R), dim3(nt), L.total, c->stream, a); break;
-    case 1: hipLaunchKernelGGL((k_sweep_fused<false, true>), dim3(R), dim3(nt), L.total, c->stream, a); break;
-    case 2: hipLaunchKernelGGL((k_sweep_fused<true, false>), dim3(R), dim3(nt), L.total, c->stream, a); break;
-    default: hipLaunchKernelGGL((k_sweep_fused<true, true>), dim3(R), dim3(nt), L.total, c->stream, a); break;
+    case 0: hipLaunchKernelGGL((k_sweep_fused<false, false, false>), dim3(R), dim3(nt), L.total, c->stream, a); break;
+    case 1: hipLaunchKernelGGL((k_sweep_fused<false, true, false>), dim3(R), dim3(nt), L.total, c->stream, a); break;
+    case 2: hipLaunchKernelGGL((k_sweep_fused<true, false, false>), dim3(R), dim3(nt), L.total, c->stream, a); break;
+    case 3: hipLaunchKernelGGL((k_sweep_fused<true, true, false>), dim3(R), dim3(nt), L.total, c->stream, a); break;
+    case 4: hipLaunchKernelGGL((k_sweep_fused<false, false, true>), dim3(R), dim3(nt), L.total, c->stream, a); break;
+    case 5: hipLaunchKernelGGL((k_sweep_fused<false, true, true>), dim3(R), dim3(nt), L.total, c->stream, a); break;
+    case 6: hipLaunchKernelGGL((k_sweep_fused<true, false, true>), dim3(R), dim3(nt), L.total, c->stream, a); break;
+    default: hipLaunchKernelGGL((k_sweep_fused<true, true, true>), dim3(R), dim3(nt), L.total, c->stream, a); break;
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(e2, c->stream));
@@ -384,14 +419,44 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
     return NLMC_OK;
 }
 
-struct SweepOut {
-    int record_stride;
-    int8_t *out_spins;
-    double *out_energy;
-    double *out_min_energy;
-    int32_t *out_argmin;
-    int8_t *out_argmin_state;
-};
+// device result buffers of a sweep call -> the caller's host arrays
+int read_sweep_outputs(nlmc_ctx *c, const SweepOut &o, int n_sweeps, int rec, int n_rec)
+{
+    const int R = c->n_chains, n = c->n;
+    bool need_sync = false;
+    std::vector<long long> h_ll;
+    if (o.out_energy) {
+        h_ll.resize((size_t)R * n_sweeps);
+        HIP_TRY(c, hipMemcpyAsync(h_ll.data(), c->etrace.p, sizeof(long long) * h_ll.size(), hipMemcpyDeviceToHost, c->stream));
+        need_sync = true;
+    }
+    std::vector<long long> h_min;
+    if (o.out_min_energy) {
+        h_min.resize(R);
+        HIP_TRY(c, hipMemcpyAsync(h_min.data(), c->emin.p, sizeof(long long) * R, hipMemcpyDeviceToHost, c->stream));
+        need_sync = true;
+    }
+    if (o.out_argmin) {
+        HIP_TRY(c, hipMemcpyAsync(o.out_argmin, c->argmin.p, sizeof(int32_t) * R, hipMemcpyDeviceToHost, c->stream));
+        need_sync = true;
+    }
+    if (o.out_argmin_state) {
+        int rc = rows_to_host_begin(c, c->best.p, R);
+        if (rc) return rc;
+        need_sync = true;
+    }
+    if (rec) {
+        HIP_TRY(c, hipMemcpyAsync(o.out_spins, c->strace.p, (size_t)R * n_rec * n, hipMemcpyDeviceToHost, c->stream));
+        need_sync = true;
+    }
+    if (need_sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (o.out_argmin_state) rows_to_host_finish(c, o.out_argmin_state, R);
+    const double inv = std::ldexp(1.0, -c->escale);
+    if (o.out_energy) for (size_t i = 0; i < h_ll.size(); ++i) o.out_energy[i] = (double)h_ll[i] * inv;
+    if (o.out_min_energy) for (int i = 0; i < R; ++i) o.out_min_energy[i] = (double)h_min[i] * inv;
+    return NLMC_OK;
+}
+
 
 // Shared driver: windows of sweeps -> (levelize) -> k_sweep.  `stream_mode` selects the kernel flavour.
 int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int n_sweeps, uint32_t sweep0,
@@ -408,16 +473,27 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
     if (R == 0 || n_sweeps == 0) return NLMC_OK;
     const bool want_min = o.out_min_energy || o.out_argmin || o.out_argmin_state;
     c->stat_fused_window = -1;
-    // Fused-window schedule: planned ahead (nlmc_plan_philox_fused), same results, no per-sweep outputs possible
-    if (!stream_mode && precision == NLMC_F32 && order_mode == NLMC_ORDER_SHARED && !o.out_spins && !o.out_energy &&
-        !want_min && tab_ss == 0 && c->fz_valid && c->fz_seed == seed && n_sweeps == c->fz_T && sweep0 >= c->fz_sweep0 &&
-        (sweep0 - c->fz_sweep0) % (uint32_t)c->fz_T == 0 && (sweep0 - c->fz_sweep0) / (uint32_t)c->fz_T < (uint32_t)c->fz_windows &&
-        !getenv("NLMC_NO_FUSED")) {
-        const int w = (int)((sweep0 - c->fz_sweep0) / (uint32_t)c->fz_T);
-        if (c->fz_nlev_host[w] > 0) return run_fused(c, w, sweep0, seed, tab_dev, tab_cs, use_slots);
-    }
     const int rec = o.out_spins ? std::max(1, o.record_stride) : 0;
     const int n_rec = rec ? (n_sweeps + rec - 1) / rec : 0;
+    const bool any_out = o.out_spins || o.out_energy || want_min;
+    // Fused-window schedule: planned ahead (nlmc_plan_philox_fused), same results.  Calls without per-sweep outputs
+    // and with one temperature per chain take the plain variant, one window per call; calls WITH outputs (energy trace,
+    // running minimum / argmin state, recorded configurations) or a temperature per sweep take the output variant, any
+    // whole number of planned windows per call, when its three snapshot slots fit in LDS next to the rest.
+    bool fused_out = false;
+    if (!stream_mode && precision == NLMC_F32 && order_mode == NLMC_ORDER_SHARED && c->fz_valid && c->fz_seed == seed &&
+        sweep0 >= c->fz_sweep0 && (sweep0 - c->fz_sweep0) % (uint32_t)c->fz_T == 0 && n_sweeps % c->fz_T == 0 &&
+        (uint64_t)(sweep0 - c->fz_sweep0) + (uint64_t)n_sweeps <= (uint64_t)c->fz_T * (uint64_t)c->fz_windows &&
+        !getenv("NLMC_NO_FUSED")) {
+        const int w0 = (int)((sweep0 - c->fz_sweep0) / (uint32_t)c->fz_T), nw = n_sweeps / c->fz_T;
+        bool all_ok = true;
+        for (int w = w0; w < w0 + nw; ++w) all_ok = all_ok && c->fz_nlev_host[w] > 0;
+        if (all_ok && !any_out && tab_ss == 0 && nw == 1)
+            return run_fused(c, w0, sweep0, seed, tab_dev, tab_cs, 0, use_slots, false, false, false, false, 0, 0, n_sweeps);
+        if (all_ok && (any_out || tab_ss != 0) && !getenv("NLMC_NO_FUSED_OUT") &&
+            fused_lds(c->n, c->n_pad, c->has_flags, true).total <= (size_t)150 * 1024)
+            fused_out = true;
+    }
     if (o.out_energy) HIP_TRY(c, c->etrace.reserve((size_t)R * n_sweeps));
     if (rec) HIP_TRY(c, c->strace.reserve((size_t)R * n_rec * n));
     if (want_min) {
@@ -425,6 +501,16 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         HIP_TRY(c, hipMemcpyAsync(c->emin.p, init.data(), sizeof(long long) * R, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->argmin.p, 0, sizeof(int32_t) * R, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));   // `init` is a stack-lifetime host buffer
+    }
+    if (fused_out) {
+        const int w0 = (int)((sweep0 - c->fz_sweep0) / (uint32_t)c->fz_T), nw = n_sweeps / c->fz_T;
+        for (int j = 0; j < nw; ++j) {
+            int rc = run_fused(c, w0 + j, sweep0 + (uint32_t)(j * c->fz_T), seed, tab_dev + (size_t)j * c->fz_T * tab_ss, tab_cs,
+                               tab_ss, use_slots, true, o.out_energy != nullptr, want_min, o.out_argmin_state != nullptr, rec,
+                               j * c->fz_T, n_sweeps);
+            if (rc) return rc;
+        }
+        return read_sweep_outputs(c, o, n_sweeps, rec, n_rec);
     }
 
     const int per_chain = (stream_mode || order_mode == NLMC_ORDER_PER_CHAIN) ? 1 : 0;
@@ -550,39 +636,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         c->launches_total++;
     }
 
-    // read-out
-    bool need_sync = false;
-    std::vector<long long> h_ll;
-    if (o.out_energy) {
-        h_ll.resize((size_t)R * n_sweeps);
-        HIP_TRY(c, hipMemcpyAsync(h_ll.data(), c->etrace.p, sizeof(long long) * h_ll.size(), hipMemcpyDeviceToHost, c->stream));
-        need_sync = true;
-    }
-    std::vector<long long> h_min;
-    if (o.out_min_energy) {
-        h_min.resize(R);
-        HIP_TRY(c, hipMemcpyAsync(h_min.data(), c->emin.p, sizeof(long long) * R, hipMemcpyDeviceToHost, c->stream));
-        need_sync = true;
-    }
-    if (o.out_argmin) {
-        HIP_TRY(c, hipMemcpyAsync(o.out_argmin, c->argmin.p, sizeof(int32_t) * R, hipMemcpyDeviceToHost, c->stream));
-        need_sync = true;
-    }
-    if (o.out_argmin_state) {
-        int rc = rows_to_host_begin(c, c->best.p, R);
-        if (rc) return rc;
-        need_sync = true;
-    }
-    if (rec) {
-        HIP_TRY(c, hipMemcpyAsync(o.out_spins, c->strace.p, (size_t)R * n_rec * n, hipMemcpyDeviceToHost, c->stream));
-        need_sync = true;
-    }
-    if (need_sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (o.out_argmin_state) rows_to_host_finish(c, o.out_argmin_state, R);
-    const double inv = std::ldexp(1.0, -c->escale);
-    if (o.out_energy) for (size_t i = 0; i < h_ll.size(); ++i) o.out_energy[i] = (double)h_ll[i] * inv;
-    if (o.out_min_energy) for (int i = 0; i < R; ++i) o.out_min_energy[i] = (double)h_min[i] * inv;
-    return NLMC_OK;
+    return read_sweep_outputs(c, o, n_sweeps, rec, n_rec);
 }
 
 }  // namespace
@@ -1069,7 +1123,7 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     c->fz_gen0 = fused_gen0(fused_block(c->n));
     a.level_cap = c->fz_workers * 64;
     a.pstride = c->fz_pstride;
-    a.tab_words = fused_lds(c->n, c->n_pad, true, T).u_bytes / 4;
+    a.tab_words = c->n_pad;
     a.k_dummy = c->n_pad;
     a.compact = c->compact16 ? 1 : 0;
     c->fz_compact = c->compact16;

@@ -430,7 +430,9 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
         const uint32_t it = perm[pos];
         const uint32_t dpack = (uint32_t)a.k_dummy << 16;
         if (it == 0xFFFFFFFFu) {
-            head[pos] = make_int2(a.k_dummy, 0);
+            // (threshold word 3 tab_words: behind the three tables / snapshot slots, so that a dummy's threshold read and
+            // snapshot write touch nothing that belongs to a spin)
+            head[pos] = make_int2(a.k_dummy | ((3 * a.tab_words) << 16), 0);
             if (a.compact) {
 #pragma unroll
                 for (int q = 0; q < NLMC_ELL_W32 / 4; ++q) ell[(size_t)q * PS + pos] = make_int4((int)dpack, (int)dpack, (int)dpack, (int)dpack);
@@ -549,6 +551,7 @@ struct SweepArgs {
     int fz_npos_next;         // positions the NEXT window actually uses (for the warm-up touches)
     int fz_compact;           // 4-byte schedule entries (col << 16 | Jq & 0xFFFF), see FusedItem
     int lds_send_off;
+    int lds_snap_off;         // k_sweep_fused<.., OUT>: three snapshot slots of n_pad bytes
     int dbg_flags;            // -DNLMC_DEBUG_KNOBS builds only (NLMC_DBG_FLAGS): 1 = no threshold production, 2 = no updates, 4 = no item loads
 };
 
@@ -1301,12 +1304,40 @@ struct FusedGenParams { uint32_t gc; int gtid, gnt, nblk, nj, Tn; };
         if ((l) == g_wend) { ++g_u; g_slot = g_slot == 2 ? 0 : g_slot + 1; NLMC_GEN_ARM(a, gp) }                        \
     }
 
-template <bool DIAG, bool FLAGS, bool TAIL, bool GEN, bool COMPACT>
+// OUT: per-sweep outputs (energy trace, running minimum + argmin state, recorded configurations) and a temperature per
+// sweep.  In a fused window at most two sweeps are live in a level, the OLDER one (index o_t) and the one after it; an
+// item belongs to the older one iff its threshold word lies in that sweep's table.  Every update also writes its new
+// spin to a snapshot slot of its sweep (three slots like the threshold tables: the snapshot of sweep t is complete at
+// level send[t] and not overwritten before sweep t+3 starts), energy deltas go to the accumulator of their sweep, and
+// when a sweep ends its sum is reduced over the workgroup (one LDS atomic per wave, read after the level's barrier):
+// that gives E after every sweep, the strict running minimum (first argmin, like np.argmin) and, from the snapshot,
+// the argmin / recorded states -- NMC/nmc.py:386-395 -- without giving up the overlap of consecutive sweeps.
+template <bool DIAG, bool FLAGS, bool TAIL, bool GEN, bool COMPACT, bool OUT = false>
 __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *lds_raw, int wv, int lane, int nl, float cq0,
                                              float cq1, long long &e_loc, const FusedGenParams gp)
 {
     NLMC_GEN_STATE
     NLMC_GEN_ARM(a, gp)
+    typedef const int32_t __attribute__((address_space(4))) *const_i32o;
+    typedef const double __attribute__((address_space(4))) *const_f64o;
+    const int o_npad = a.g.n_pad, o_c = blockIdx.x, o_tid = wv * 64 + lane;
+    int o_t = 0, o_end = 0;                                // older live sweep and its last level
+    unsigned o_lo = 0u;                                    // its threshold-word range is [o_lo, o_lo + n_pad)
+    long long e_new = 0, E_run = 0, E_min = 0;
+    int a_min = 0;
+    float cqo0 = cq0, cqo1 = cq1, cqn0 = cq0, cqn1 = cq1;  // coefficients of the older / the newer live sweep
+    const int o_row = a.slot_of_chain ? a.slot_of_chain[a.chain_base + o_c] : o_c;
+    auto o_cq = [&](int t, int j) __attribute__((always_inline)) {
+        const const_f64o tab = (const_f64o)(uintptr_t)a.tab;
+        return (float)tab[(size_t)o_row * a.tab_cs + (size_t)min(t, a.n_sweeps - 1) * a.tab_ss + j] * a.qinv;
+    };
+    if (OUT) {
+        o_end = ((const_i32o)(uintptr_t)a.fsend)[0];
+        E_run = a.efix[o_c];
+        E_min = a.emin ? a.emin[o_c] : 0x7FFFFFFFFFFFFFFFll;
+        a_min = a.emin ? a.argmin[o_c] : 0;
+        cqn0 = o_cq(1, 0); cqn1 = o_cq(1, 1);
+    }
     typedef FusedItem<COMPACT, TAIL> Item;
     constexpr int NP = Item::NP, NE = Item::NE;
     const int plane_bytes = a.fz_pstride * 16;
@@ -1371,11 +1402,61 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             }
         }
         const int X = X0 + X1;
-        const float z = ((FLAGS && f == 1u) ? cq1 : cq0) * (float)X;
-        int sn = (z < wk) ? 1 : -1;
-        if (FLAGS) sn = (f >= 2u) ? so : sn;                                        // frozen: unchanged
-        e_loc += (long long)(DIAG ? X - Xd : X) * (long long)((so - sn) << a.eshift);
-        *(lds_i8w)(uintptr_t)ka = (int8_t)sn;
+        if (!OUT) {
+            const float z = ((FLAGS && f == 1u) ? cq1 : cq0) * (float)X;
+            int sn = (z < wk) ? 1 : -1;
+            if (FLAGS) sn = (f >= 2u) ? so : sn;                                    // frozen: unchanged
+            e_loc += (long long)(DIAG ? X - Xd : X) * (long long)((so - sn) << a.eshift);
+            *(lds_i8w)(uintptr_t)ka = (int8_t)sn;
+        } else {
+            const unsigned tw = (unsigned)hx >> 16;                                 // threshold word = slot * n_pad + k
+            const bool is_old = tw - o_lo < (unsigned)o_npad;
+            const float cqa = is_old ? cqo0 : cqn0, cqb = is_old ? cqo1 : cqn1;
+            const float z = ((FLAGS && f == 1u) ? cqb : cqa) * (float)X;
+            int sn = (z < wk) ? 1 : -1;
+            if (FLAGS) sn = (f >= 2u) ? so : sn;
+            const int cv = (so - sn) << a.eshift, cvo = is_old ? cv : 0;
+            const long long Xt = (long long)(DIAG ? X - Xd : X);
+            e_loc += Xt * (long long)cvo;                                           // e_loc: the older sweep's deltas
+            e_new += Xt * (long long)(cv - cvo);
+            *(lds_i8w)(uintptr_t)ka = (int8_t)sn;
+            *(lds_i8w)(uintptr_t)(tw + (unsigned)a.lds_snap_off) = (int8_t)sn;      // snapshot slot of the update's sweep
+        }
+    };
+    // end of the older live sweep: before the level's barrier every wave adds its share to the sweep's LDS accumulator
+    auto out_pre = [&]() __attribute__((always_inline)) {
+        const long long w = wave_sum_i64(e_loc);
+        long long *red = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);
+        if (lane == 0 && w != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&red[o_t % 3]), (unsigned long long)w);
+    };
+    // ... after it every worker thread knows the energy after that sweep
+    auto out_post = [&]() __attribute__((always_inline)) {
+        long long *red = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);
+        const int slot = o_t % 3, tg = a.t0 + o_t;
+        E_run += red[slot];
+        const bool better = a.emin && E_run < E_min;            // strict <: first argmin (np.argmin, NMC/nmc.py:394)
+        if (better) { E_min = E_run; a_min = tg; }
+        if (o_tid == 0) {
+            red[(o_t + 2) % 3] = 0;                              // read a sweep ago, next used two sweeps from now
+            if (a.etrace) a.etrace[(size_t)o_c * a.trace_sweeps + tg] = E_run;
+        }
+        const unsigned char *snap = lds_raw + a.lds_snap_off + (size_t)slot * o_npad;
+        if (better && a.best) {
+            int4 *dst = reinterpret_cast<int4 *>(a.best + (size_t)o_c * o_npad);
+            const int4 *src = reinterpret_cast<const int4 *>(snap);
+            for (int i = o_tid; i < o_npad / 16; i += a.f_workers * 64) dst[i] = src[i];
+        }
+        if (a.strace && tg % a.rec_stride == 0) {               // M[:, ::M_skip]  (NMC/nmc.py:390)
+            const int n_rec = (a.trace_sweeps + a.rec_stride - 1) / a.rec_stride;
+            int8_t *dst = a.strace + ((size_t)o_c * n_rec + (size_t)(tg / a.rec_stride)) * a.g.n;
+            for (int i = o_tid; i < a.g.n; i += a.f_workers * 64) dst[i] = (int8_t)snap[i];
+        }
+        e_loc = e_new; e_new = 0;
+        ++o_t;
+        o_lo = (unsigned)((o_t % 3) * o_npad);
+        o_end = o_t < a.n_sweeps ? ((const_i32o)(uintptr_t)a.fsend)[o_t] : 0x7FFFFFFF;
+        cqo0 = cqn0; cqo1 = cqn1;
+        cqn0 = o_cq(o_t + 1, 0); cqn1 = o_cq(o_t + 1, 1);
     };
 
     // Order inside a level: update first, THEN loads.  The vector-memory path of the CU is the scarcest resource of
@@ -1400,18 +1481,24 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             if (GEN) NLMC_GEN(a, gp, l)
             if (hasA) { update(A); NLMC_FCALL }
             issue(B, q1 + wv, hasB NLMC_DBG_NOLOAD);
+            const bool end0 = OUT && l == o_end;
+            if (end0) out_pre();
             NLMC_FW1
             __syncthreads();
             NLMC_FW2
+            if (end0) out_post();
             if (l + 1 < nl) {
                 NLMC_FW0
                 hasA = (l + 2 < nl) && (q2 + wv < q3);
                 if (GEN) NLMC_GEN(a, gp, l + 1)
                 if (hasB) { update(B); NLMC_FCALL }
                 issue(A, q2 + wv, hasA NLMC_DBG_NOLOAD);
+                const bool end1 = OUT && l + 1 == o_end;
+                if (end1) out_pre();
                 NLMC_FW1
                 __syncthreads();
                 NLMC_FW2
+                if (end1) out_post();
             }
             q0 = q2; q1 = q3; q2 = q4; q3 = q5;
         }
@@ -1428,9 +1515,12 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             if (GEN) NLMC_GEN(a, gp, lv)                                                    \
             if (hcur) { update(cur); NLMC_FCALL }                                           \
             issue(nxt, (b2) + wv, hnxt NLMC_DBG_NOLOAD);                                    \
+            const bool end_ = OUT && (lv) == o_end;                                         \
+            if (end_) out_pre();                                                            \
             NLMC_FW1                                                                        \
             NLMC_DBG_BARRIER                                                                \
             NLMC_FW2                                                                        \
+            if (end_) out_post();                                                           \
         }
         for (int l = 0; l < nl; l += 3) {
             const int n3 = lo(l + 6), n4 = lo(l + 7), n5 = lo(l + 8);
@@ -1447,9 +1537,14 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
         d[4] = st_calls; d[5] = st_work; d[6] = st_bar;
     }
 #endif
+    if (OUT && o_tid == 0) {                       // every sweep has ended: E_run is the energy of the final state
+        a.efix[o_c] = E_run;
+        if (a.energy_sink) a.energy_sink[o_c] = (double)E_run * __longlong_as_double((long long)(1023 - a.escale) << 52);
+        if (a.emin) { a.emin[o_c] = E_min; a.argmin[o_c] = a_min; }
+    }
 }
 
-template <bool DIAG, bool FLAGS>
+template <bool DIAG, bool FLAGS, bool OUT = false>
 __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -1484,7 +1579,7 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
             for (int i = tid; i < n_pad / 16; i += nt) fdst[i] = fsrc[i];
             if (tid < 4) reinterpret_cast<int *>(lds_raw + a.lds_flags_off + n_pad)[tid] = 0;
         }
-        if (tid == 0) red[0] = 0;
+        if (tid < 4) red[tid] = 0;
     }
     // thresholds of the first two sweeps (the third table is produced inside the level loop like all later ones)
     for (int t = 0; t < min(2, Tn) NLMC_DBG_NOPROLOGUE; ++t)
@@ -1503,14 +1598,14 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
         const bool role_long = wv < a.hi_max[0];           // chunks that may hold rows longer than 8 entries come first
         const int variant = (role_long ? 4 : 0) + (is_gen ? 2 : 0) + (a.fz_compact ? 1 : 0);
         switch (variant) {
-        case 0: fused_levels<DIAG, FLAGS, false, false, false>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
-        case 1: fused_levels<DIAG, FLAGS, false, false, true>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
-        case 2: fused_levels<DIAG, FLAGS, false, true, false>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
-        case 3: fused_levels<DIAG, FLAGS, false, true, true>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
-        case 4: fused_levels<DIAG, FLAGS, true, false, false>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
-        case 5: fused_levels<DIAG, FLAGS, true, false, true>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
-        case 6: fused_levels<DIAG, FLAGS, true, true, false>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
-        default: fused_levels<DIAG, FLAGS, true, true, true>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
+        case 0: fused_levels<DIAG, FLAGS, false, false, false, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
+        case 1: fused_levels<DIAG, FLAGS, false, false, true, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
+        case 2: fused_levels<DIAG, FLAGS, false, true, false, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
+        case 3: fused_levels<DIAG, FLAGS, false, true, true, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
+        case 4: fused_levels<DIAG, FLAGS, true, false, false, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
+        case 5: fused_levels<DIAG, FLAGS, true, false, true, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
+        case 6: fused_levels<DIAG, FLAGS, true, true, false, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
+        default: fused_levels<DIAG, FLAGS, true, true, true, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
         }
     } else {
         // Waves without schedule items: their share of the thresholds, and they pull the NEXT window's schedule towards
@@ -1553,14 +1648,14 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
 
     // energy of the final state, spins back to HBM
     {
-        const long long w = wave_sum_i64(e_loc);
-        if (lane == 0 && w != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&red[0]), (unsigned long long)w);
+        const long long w = OUT ? 0ll : wave_sum_i64(e_loc);
+        if (lane == 0 && w != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&red[3]), (unsigned long long)w);
         __syncthreads();
         int4 *dst = reinterpret_cast<int4 *>(a.spins + (size_t)c * n_pad);
         const int4 *src = reinterpret_cast<const int4 *>(lds_raw);
         for (int i = tid; i < n_pad / 16; i += nt) dst[i] = src[i];
-        if (tid == 0) {
-            const long long E = a.efix[c] + red[0];
+        if (tid == 0 && !OUT) {                  // (OUT: the level loop has written the per-chain results)
+            const long long E = a.efix[c] + red[3];
             a.efix[c] = E;
             if (a.energy_sink) a.energy_sink[c] = (double)E * __longlong_as_double((long long)(1023 - a.escale) << 52);
         }

@@ -8,6 +8,7 @@ import numpy as np
 
 from . import hostlogic
 from .base import Common
+from .engine import fused_window
 
 
 class NMC(Common):
@@ -82,11 +83,19 @@ class NMC(Common):
             trail.append(o["min_energy"].copy())
             return o["argmin_state"].copy()
 
+        # Fused windows with per-sweep outputs (running minimum + argmin state, a temperature per sweep) for every
+        # launch: the anneal's windows, then ALL phases' windows in one planning call (they depend on the sweep index
+        # only).  Instances / lengths the fused kernels do not take fall back to the sweep-by-sweep schedule.
         if S0 > 0:
+            if fused_window(S0):
+                eng.plan_philox_fused(sweep0, S0 // fused_window(S0), fused_window(S0), self.seed)
             sched = hostlogic.beta_schedule(S0, global_beta, True, 1, 0)
             m = launch(m, S0, np.repeat(sched[None, :], R, axis=0), None)
         m_star = m.copy()
         flat = np.full((R, S), float(global_beta)) if S > 0 else None
+        n_phase_launches = sum(2 + (1 if cyc % full_update_frequency == 0 else 0) for cyc in range(num_NMC_cycles))
+        if S > 0 and fused_window(S):
+            eng.plan_philox_fused(sweep0, n_phase_launches * (S // fused_window(S)), fused_window(S), self.seed)
         for cycle in range(num_NMC_cycles):
             if S == 0:
                 break

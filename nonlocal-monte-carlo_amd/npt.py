@@ -328,6 +328,7 @@ class NPT(Common):
                 self.swap_pairs = p[:, 0].reshape(-1, 2) + 1
                 self.swap_accepted = a[:, 0].reshape(-1).astype(np.int8)
                 self.swap_acceptance_per_restart = a.reshape(rounds, n_restarts, -1).mean(axis=(0, 2))
+                self.swap_log_all = (p, a)               # slots (0-based) / decisions of every restart
             else:
                 self.swap_pairs, self.swap_accepted = np.zeros((0, 2), np.int32), np.zeros(0, np.int8)
             self.final_slots = lt.slots()

@@ -21,10 +21,13 @@ def c2():
     eng = P.Engine(J, h, R)
     m = init_spins(R, N)
     cl = np.arange(N // 20)
+    T = P.engine.fused_window(S_phase)
     eng.set_spins(m); eng.sweep_philox(10, 1, beta=3.0)     # warm-up
     def run():
         nonlocal m
         sw = 10
+        if T and not os.environ.get("C2_PLAIN"):       # fused windows with running minimum + argmin state, planned at once
+            eng.plan_philox_fused(sw, 3 * cycles * (S_phase // T), T, 7)
         for c in range(cycles):
             for kind in ("C", "NC", "ALL"):
                 fl = None if kind == "ALL" else np.stack([P.hostlogic.phase_flags(N, m[r], cl, kind) for r in range(R)])

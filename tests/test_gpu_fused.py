@@ -100,9 +100,9 @@ def test_fused_with_swaps_and_sharded_contexts(product):
     assert np.array_equal(one_f[0], np.concatenate([lo[0], hi[0]]))
 
 
-def test_fused_plan_declines_what_it_cannot_run(product):
-    """Tiny instance (n < 256), window of 2: nothing planned, calls take the plain path;
-    calls with per-sweep outputs ignore a fused plan."""
+def test_fused_plan_declines_what_it_cannot_run(product, monkeypatch):
+    """Tiny instance (n < 256), window of 2: nothing planned, calls take the plain path; per-chain orders and f64
+    ignore a fused plan; calls with per-sweep outputs run on it unless the three snapshot slots do not fit in LDS."""
     J, h = make_instance(200, seed=3)
     with product.Engine(J, h, 2) as eng:
         assert eng.plan_philox_fused(0, 4, 10, SEED) == 0
@@ -112,14 +112,32 @@ def test_fused_plan_declines_what_it_cannot_run(product):
         assert eng.plan_philox_fused(0, 2, 2, SEED) == 0
         assert eng.plan_philox_fused(0, 2, T, SEED) == 2
         eng.set_spins(init_spins(2, N))
-        o = eng.sweep_philox(T, SEED, sweep0=0, beta=1.0, want_energy=True, want_min=True)     # per-sweep outputs
+        monkeypatch.setenv("NLMC_NO_FUSED_OUT", "1")
+        o = eng.sweep_philox(T, SEED, sweep0=0, beta=1.0, want_energy=True, want_min=True)     # sweep by sweep
         st = eng.last_schedule_stats()
         assert o["energy"].shape == (2, T) and st["orders"] == T and st["levels"] / T > 15
         e_plain = eng.energy()
+        monkeypatch.delenv("NLMC_NO_FUSED_OUT")
         eng.set_spins(init_spins(2, N))
-        eng.sweep_philox(T, SEED, sweep0=0, beta=1.0)                                           # fused
+        o2 = eng.sweep_philox(T, SEED, sweep0=0, beta=1.0, want_energy=True, want_min=True)    # fused, with outputs
+        assert eng.last_schedule_stats()["levels"] / T < st["levels"] / T
+        assert np.array_equal(o2["energy"], o["energy"]) and np.array_equal(o2["min_energy"], o["min_energy"])
+        eng.set_spins(init_spins(2, N))
+        eng.sweep_philox(T, SEED, sweep0=0, beta=1.0)                                           # fused, no outputs
         assert eng.last_schedule_stats()["levels"] / T < st["levels"] / T
         assert np.array_equal(eng.energy(), e_plain)
+        eng.set_spins(init_spins(2, N))
+        eng.sweep_philox(T, SEED, sweep0=0, beta=1.0, order="per_chain")                        # not what was planned
+        assert eng.last_schedule_stats()["orders"] == 2 * T
+    N = 10000                                                                                   # snapshots do not fit
+    J, h = make_instance(N, seed=32)
+    with product.Engine(J, h, 2) as eng:
+        assert eng.plan_philox_fused(0, 1, T, SEED) == 1
+        eng.set_spins(init_spins(2, N))
+        eng.sweep_philox(T, SEED, sweep0=0, beta=1.0, want_min=True)
+        lv_out = eng.last_schedule_stats()["levels"]
+        eng.sweep_philox(T, SEED, sweep0=0, beta=1.0)
+        assert eng.last_schedule_stats()["levels"] < lv_out
 
 
 @pytest.mark.parametrize("N", [300, 1000, 1600, 3000, 5000])
@@ -141,3 +159,49 @@ def test_fused_small_workgroups(product, N):
     e0 = int(np.rint(oracle.energy(csr, h, m0[c]) * 2.0 ** f[5]))
     _, s_fin, tr = oracle.sweeps_philox(csr, h, m0[c], cb, SEED, c, escale=f[5], efix0=e0, want_M=False)
     assert np.array_equal(f[0][c], s_fin) and f[1][c] == tr[-1] * 2.0 ** -f[5]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["pmj", "gauss_flags", "anneal"])
+def test_fused_windows_with_per_sweep_outputs_equal_the_sweep_by_sweep_kernel(product, case, monkeypatch):
+    """Calls that want the energy trace, the running minimum + argmin state (NMC/nmc.py:386-395) or recorded
+    configurations, or that anneal (one temperature per sweep, NMC/nmc.py:56-69), run on the fused windows too
+    (k_sweep_fused<.., OUT>): every output must equal the sweep-by-sweep kernel's bit for bit, over several windows per
+    call, with phase flags, and the tracked state must carry on correctly into the next call."""
+    from helpers import make_instance, init_spins
+    N, R, T, W = 700, 5, 6, 4
+    gauss = case == "gauss_flags"
+    J, h = make_instance(N, seed=41, with_h=gauss, gaussian=gauss)
+    m0 = init_spins(R, N)
+    S = T * W
+    if case == "anneal":
+        beta = np.stack([np.linspace(0.1, 2.5 + 0.1 * c, S) for c in range(R)])
+    else:
+        beta = np.repeat(np.geomspace(0.3, 2.5, R)[:, None], S, axis=1)
+    flags = None
+    if gauss:
+        rng = np.random.default_rng(3)
+        flags = rng.choice([0, 0, 0, 1, 2, 3], size=(R, N)).astype(np.uint8)
+
+    def go(fused_out):
+        if fused_out:
+            monkeypatch.delenv("NLMC_NO_FUSED_OUT", raising=False)
+        else:
+            monkeypatch.setenv("NLMC_NO_FUSED_OUT", "1")
+        with product.Engine(J, h, R) as eng:
+            eng.set_spins(m0)
+            if flags is not None:
+                eng.set_flags(flags, 7.0)
+            assert eng.plan_philox_fused(0, 2 * W, T, SEED) == 2 * W
+            o1 = eng.sweep_philox(S, SEED, sweep0=0, beta=beta, record_stride=2, want_energy=True, want_min=True, want_state=True)
+            lv = eng.last_schedule_stats()
+            o2 = eng.sweep_philox(S, SEED, sweep0=S, beta=beta[:, ::-1].copy(), want_min=True, want_state=True)
+            return o1, o2, eng.get_spins(), eng.energy_tracked(), lv
+    a1, a2, sa, ea, lva = go(True)
+    b1, b2, sb, eb, lvb = go(False)
+    assert lva["orders"] == T and lvb["orders"] != T                      # the first really ran on fused windows
+    for k in ("spins", "energy", "min_energy", "argmin", "argmin_state"):
+        assert np.array_equal(a1[k], b1[k]), k
+    for k in ("min_energy", "argmin", "argmin_state"):
+        assert np.array_equal(a2[k], b2[k]), k
+    assert np.array_equal(sa, sb) and np.array_equal(ea, eb)

@@ -1,0 +1,110 @@
+"""Law of the device-RNG mode against STATISTICS of the reference itself (tests/golden/stats_*.npz, written by
+tools/make_golden.py `stats` from runs of the reference's MCMC / NPT.run in the build container).
+
+The device-RNG ("philox") mode is not stream-matched with the reference, so it is compared with it the way two Monte
+Carlo codes are compared: time-averaged energies at four inverse temperatures (incl. the cold beta = 4 rung) on a +-J
+and on a Gaussian-coupling instance, and swap acceptance per rung of a small ladder.  Error bars: the spread over the
+reference's 12 independent chains (fixture) and over ours; a difference beyond 4.5 combined standard errors fails.
+The CPU test runs the oracle's sequential restatement of the spec (both precisions); the GPU tests run the HIP engine.
+Stated tolerance of the "f32" mode: couplings quantised to 24-bit fixed point, |dJ| <= 2^-(qs+1);
+acceptance probabilities within 2e-7 relative of the reference's, down to 2^-33.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import golden
+
+SIGMAS = 4.5
+CHAINS = 48
+
+
+def _fixture(name):
+    g = golden(name)
+    csr = oracle.Csr.from_parts(int(g["N"]), g["indptr"], g["indices"], g["data"])
+    return g, csr
+
+
+def _check(name, ours_mean, ours_se, g):
+    for bi, beta in enumerate(g["betas"]):
+        se = np.hypot(float(g["stderr"][bi]), float(ours_se[bi]))
+        # chains frozen into different local minima at beta = 4 make both error bars honest but wide; a floor on the
+        # standard error keeps a lucky tiny spread from turning noise into a failure
+        se = max(se, 2e-3 * max(1.0, abs(float(g["mean"][bi]))))
+        z = (float(ours_mean[bi]) - float(g["mean"][bi])) / se
+        assert abs(z) < SIGMAS, f"{name}: beta={beta}: ours {ours_mean[bi]:.4f} +- {ours_se[bi]:.4f} vs reference " \
+                                f"{g['mean'][bi]:.4f} +- {g['stderr'][bi]:.4f} ({z:.1f} sigma)"
+
+
+@pytest.mark.parametrize("name", ["pmj48", "gsparse48"])
+@pytest.mark.parametrize("use_f64", [False, True])
+def test_spec_mean_energies_match_the_reference(name, use_f64):
+    g, csr = _fixture("stats_energy_" + name)
+    S, burn, n = int(g["num_sweeps"]), int(g["burn_in"]), csr.n
+    qs, esc = oracle.field_scale(csr, g["h"])
+    means, ses = [], []
+    for bi, beta in enumerate(g["betas"]):
+        cb = np.tile(np.array(oracle.cb_pair(float(beta), 1.0, use_f64)), (S, 1))
+        cm = []
+        for c in range(CHAINS):
+            s0 = np.where(np.random.default_rng(5000 + 100 * bi + c).random(n) < 0.5, -1, 1).astype(np.int8)
+            e0 = int(np.rint(oracle.energy(csr, g["h"], s0) * 2.0 ** esc))
+            _, _, tr = oracle.sweeps_philox(csr, g["h"], s0, cb, 0xBEEF + bi, c, escale=esc, use_f64=use_f64, efix0=e0,
+                                            want_M=False)
+            cm.append(float(np.mean(tr[burn:])) * 2.0 ** -esc)
+        means.append(np.mean(cm))
+        ses.append(np.std(cm, ddof=1) / np.sqrt(CHAINS))
+    _check(name, means, ses, g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["pmj48", "gsparse48"])
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_engine_mean_energies_match_the_reference(product, name, precision):
+    g, csr = _fixture("stats_energy_" + name)
+    S, burn, n, R = int(g["num_sweeps"]), int(g["burn_in"]), csr.n, 256
+    J = csr.toarray()
+    means, ses = [], []
+    for bi, beta in enumerate(g["betas"]):
+        with product.Engine(J, g["h"], R) as eng:
+            m0 = np.stack([np.where(np.random.default_rng(9000 + 1000 * bi + c).random(n) < 0.5, -1, 1) for c in range(R)])
+            eng.set_spins(m0.astype(np.int8))
+            o = eng.sweep_philox(S, 0xF00D + bi, beta=float(beta), precision=precision, order="per_chain", want_energy=True)
+            cm = o["energy"][:, burn:].mean(axis=1)
+        means.append(cm.mean())
+        ses.append(cm.std(ddof=1) / np.sqrt(R))
+    _check(name, means, ses, g)
+
+
+@pytest.mark.gpu
+def test_engine_swap_acceptance_matches_the_reference(product):
+    """Per-rung acceptance of NPT.run (NPT/npt.py:649-680) on the fixture's ladder: 64 restarts of the device-resident
+    philox path vs the reference's two runs (binomial error bars of both sides)."""
+    import contextlib
+    import io
+    g, csr = _fixture("stats_swaps_pmj32")
+    R, rounds, pairs = int(g["num_replicas"]), int(g["num_swap_attempts"]), int(g["num_swapping_pairs"])
+    obj = product.NPT(csr.toarray(), g["h"], rng="philox", seed=314)
+    with contextlib.redirect_stdout(io.StringIO()):
+        obj.run(g["beta_list"], R, [False] * R, num_sweeps_MCMC=int(g["num_sweeps_MCMC"]),
+                num_sweeps_read=int(g["num_sweeps_MCMC"]), num_swap_attempts=rounds, num_swapping_pairs=pairs,
+                num_restarts=64, return_trace=None)
+    assert obj.swap_log_all[0].shape == (rounds, 64, pairs, 2)
+    p_all, a_all = obj.swap_log_all
+    att = np.zeros(R - 1)
+    acc = np.zeros(R - 1)
+    for i in range(R - 1):
+        m = p_all[..., 0] == i
+        att[i] = m.sum()
+        acc[i] = a_all[m].sum()
+    for i in range(R - 1):
+        n_ref, k_ref = float(g["attempted"][i]), float(g["accepted"][i])
+        p_ref, p_us = k_ref / n_ref, acc[i] / att[i]
+        p = (k_ref + acc[i]) / (n_ref + att[i])
+        se = np.sqrt(max(p * (1 - p), 1e-4) * (1 / n_ref + 1 / att[i]))
+        assert abs(p_us - p_ref) < SIGMAS * se, f"rung {i}: ours {p_us:.3f} ({int(att[i])} attempts) vs reference {p_ref:.3f} ({int(n_ref)})"
+    # pair selection law: every adjacent pair is attempted equally often up to the greedy selection's edge effect --
+    # the reference's own attempt counts are the yardstick
+    f_ref = g["attempted"] / g["attempted"].sum()
+    f_us = att / att.sum()
+    assert np.max(np.abs(f_us - f_ref)) < SIGMAS * np.sqrt(0.25 / g["attempted"].sum())

@@ -385,10 +385,58 @@ def gen_known_answers():
     print("[golden] copied known-answer data files:", sorted(os.listdir(dst)), file=sys.__stdout__)
 
 
+# ----------------------------------------------------------------------------------------------
+# G8: STATISTICS of the reference's Markov kernel, for the device-RNG mode whose stream is not matched
+#     ("mean energy vs beta, swap acceptance rate")
+# ----------------------------------------------------------------------------------------------
+def gen_stats():
+    """Equilibrium-ish time averages of the energy under the reference's MCMC (NMC/nmc.py:28-91) at four inverse
+    temperatures, several independent chains each (the spread over chains is the error bar), on a +-J and on a
+    Gaussian-coupling instance (normalised by max|J| like run() does, NMC/nmc.py:474-476: non-integer couplings);
+    and per-rung swap acceptance counts of two small NPT.run calls (NPT/npt.py:649-680)."""
+    S, BURN, CHAINS = 1200, 200, 12
+    for name, (J, h) in (("pmj48", inst_pmj_sparse(48, 4242)), ("gsparse48", inst_gauss_sparse(48, 77))):
+        nf = np.max(np.abs(J))
+        Jn, hn = J / nf, h / nf
+        obj = ref_nmc.NMC(Jn, hn)
+        betas = np.array([0.05, 0.8, 2.0, 4.0])
+        chain_means = np.zeros((len(betas), CHAINS))
+        chain_min = np.zeros((len(betas), CHAINS))
+        for bi, beta in enumerate(betas):
+            for c in range(CHAINS):
+                np.random.seed(100000 + 1000 * bi + c)
+                m0 = np.sign(2 * np.random.rand(Jn.shape[0]) - 1)
+                M = obj.MCMC(S, m0.copy(), float(beta), Jn, hn)
+                E = energies_of(M[:, BURN:], Jn, hn)
+                chain_means[bi, c] = E.mean()
+                chain_min[bi, c] = E.min()
+        save(f"stats_energy_{name}", **csr_parts(Jn), h=hn, betas=betas, num_sweeps=S, burn_in=BURN,
+             chain_means=chain_means, chain_min=chain_min, mean=chain_means.mean(axis=1),
+             stderr=chain_means.std(axis=1, ddof=1) / np.sqrt(CHAINS))
+    J, h = inst_pmj_sparse(32, 21, with_h=True)
+    R, nsw, nswap, npairs = 6, 2400, 240, 2
+    beta_list = np.linspace(0.3, 2.0, R)
+    att = np.zeros(R - 1, dtype=np.int64)
+    acc = np.zeros(R - 1, dtype=np.int64)
+    for seed in (901, 902):
+        obj = ref_npt.NPT(J.copy(), h.copy())
+        np.random.seed(seed)
+        random.seed(seed)
+        with quiet() as buf:
+            obj.run(beta_list=beta_list, num_replicas=R, doNMC=[False] * R, num_sweeps_MCMC=nsw, num_sweeps_read=nsw,
+                    num_swap_attempts=nswap, num_swapping_pairs=npairs, num_cycles=2, use_hash_table=False, num_cores=1)
+        pairs, a = parse_swap_log(buf.getvalue())
+        for (i, _), ok in zip(pairs, a):
+            att[i - 1] += 1
+            acc[i - 1] += int(ok)
+    save("stats_swaps_pmj32", **csr_parts(J), h=np.asarray(h).reshape(-1), beta_list=beta_list, num_replicas=R,
+         num_sweeps_MCMC=nsw, num_swap_attempts=nswap, num_swapping_pairs=npairs, attempted=att, accepted=acc)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["mcmc", "nmcsub", "lbp", "npt", "icm", "pre", "known"]
+    which = sys.argv[1:] or ["mcmc", "nmcsub", "lbp", "npt", "icm", "pre", "known", "stats"]
     table = dict(mcmc=gen_mcmc, nmcsub=gen_nmc_subroutine, lbp=gen_lbp_and_run, npt=gen_npt, icm=gen_icm,
-                 pre=gen_preprocessor, known=gen_known_answers)
+                 pre=gen_preprocessor, known=gen_known_answers, stats=gen_stats)
     for w in which:
         table[w]()
