@@ -263,7 +263,7 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
     uint32_t *hist = reinterpret_cast<uint32_t *>(queue + n4);
     uint32_t *histL = hist + NLMC_LCAP + 2;
     __shared__ int sh_lmax[NLMC_FUSED_TMAX];
-    __shared__ int sh_max, sh_fail, sh_nlev, sh_qn, sh_npos;
+    __shared__ int sh_max, sh_fail, sh_nlev, sh_qn, sh_npos, sh_himax;
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int k = tid; k < n; k += nt) g[k] = 0;
     for (int l = tid; l < 2 * (NLMC_LCAP + 2); l += nt) hist[l] = 0u;      // hist and histL are adjacent
@@ -383,20 +383,31 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
                 hist[lv] = (uint32_t)run;
                 himax = max(himax, ((int)histL[lv] + 63) >> 6);
                 histL[lv] = (uint32_t)(run + cnt);
-                for (int p = 0; p < cnt; p += a.level_cap) { if (m < NLMC_LCAP) off[m] = (run + p) >> 6; ++m; }
+                for (int p = 0; p < cnt; p += a.level_cap) { if (m < NLMC_LCAP) { off[m] = (run + p) >> 6; mx[m] = (uint32_t)((run + p) >> 6); } ++m; }
                 run += (cnt + 63) & ~63;
                 while (t_next < T && sh_lmax[t_next] == lv) a.send[(size_t)w * T + t_next++] = m - 1;
             }
-            if (m >= NLMC_LCAP || run > a.pstride) sh_fail = 1; else off[m] = run >> 6;
+            if (m >= NLMC_LCAP || run > a.pstride) sh_fail = 1; else { off[m] = run >> 6; mx[m] = (uint32_t)(run >> 6); }
         }
         sh_nlev = sh_fail ? 0 : m;
         sh_npos = run;
         a.nlev[w] = sh_nlev;
         a.npos[w] = run;
         a.hi_max[w] = min(himax, a.level_cap >> 6);
+        sh_himax = min(himax, a.level_cap >> 6);
     }
     __syncthreads();
     if (sh_nlev == 0) return;
+    // Which chunks are read with the second half of the row window: the first hi_max chunks of every (sub-)level -- the
+    // waves that take them (k_sweep_fused, role_long) load the upper planes in EVERY level.  Everywhere else those planes
+    // are never read and therefore never written (the placement is bound by its HBM writes).  mx[] (dead by now) holds
+    // the published chunk offsets, the queue's memory the per-chunk flags.
+    uint8_t *lmap = reinterpret_cast<uint8_t *>(queue);
+    for (int i = tid; i < (sh_npos >> 6); i += nt) lmap[i] = 0;
+    __syncthreads();
+    for (int m = tid; m < sh_nlev; m += nt)
+        for (int c = (int)mx[m]; c < min((int)mx[m] + sh_himax, (int)mx[m + 1]); ++c) lmap[c] = 1;
+    __syncthreads();
 
     // placement: rows longer than 8 entries from the front of their level, the others from the back of its real items.
     // Two steps so that the 136 B per update are written with coalesced stores: (1) scatter the 4-byte item ids to
@@ -429,16 +440,19 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
     for (int pos = tid; pos < npos; pos += nt) {
         const uint32_t it = perm[pos];
         const uint32_t dpack = (uint32_t)a.k_dummy << 16;
+        const bool hi = lmap[pos >> 6] != 0;                       // this chunk is read with its upper planes
         if (it == 0xFFFFFFFFu) {
             // (threshold word 3 tab_words: behind the three tables / snapshot slots, so that a dummy's threshold read and
             // snapshot write touch nothing that belongs to a spin)
             head[pos] = make_int2(a.k_dummy | ((3 * a.tab_words) << 16), 0);
             if (a.compact) {
 #pragma unroll
-                for (int q = 0; q < NLMC_ELL_W32 / 4; ++q) ell[(size_t)q * PS + pos] = make_int4((int)dpack, (int)dpack, (int)dpack, (int)dpack);
+                for (int q = 0; q < NLMC_ELL_W32 / 4; ++q)
+                    if (q < 2 || hi) ell[(size_t)q * PS + pos] = make_int4((int)dpack, (int)dpack, (int)dpack, (int)dpack);
             } else {
 #pragma unroll
-                for (int q = 0; q < NLMC_ELL_W32; q += 2) ell[(size_t)(q / 2) * PS + pos] = make_int4(a.k_dummy, 0, a.k_dummy, 0);
+                for (int q = 0; q < NLMC_ELL_W32; q += 2)
+                    if (q < 8 || hi) ell[(size_t)(q / 2) * PS + pos] = make_int4(a.k_dummy, 0, a.k_dummy, 0);
             }
             continue;
         }
@@ -447,20 +461,24 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
         head[pos] = make_int2(k | (deg > NLMC_ELL_W32 ? 0x4000 : 0) | (((t % 3) * a.tab_words + k) << 16), a.g.hq[k]);
         EdgeQ ed[NLMC_ELL_W32];
 #pragma unroll
-        for (int q = 0; q < NLMC_ELL_W32; ++q) ed[q] = a.g.edge32[rs + q];     // unconditional (the array is padded by
-        if (a.compact) {                                                        // a full window): independent loads
+        for (int q = 0; q < 8; ++q) ed[q] = a.g.edge32[rs + q];                // unconditional (the array is padded by
+        if (deg > 8) {                                                          // a full window): independent loads
+#pragma unroll
+            for (int q = 8; q < NLMC_ELL_W32; ++q) ed[q] = a.g.edge32[rs + q];
+        }
+        if (a.compact) {
             uint32_t pk[NLMC_ELL_W32];
 #pragma unroll
             for (int q = 0; q < NLMC_ELL_W32; ++q) pk[q] = q < deg ? ((uint32_t)ed[q].col << 16) | ((uint32_t)ed[q].q & 0xFFFFu) : dpack;
 #pragma unroll
             for (int q = 0; q < NLMC_ELL_W32; q += 4)
-                ell[(size_t)(q / 4) * PS + pos] = make_int4((int)pk[q], (int)pk[q + 1], (int)pk[q + 2], (int)pk[q + 3]);
+                if (q < 8 || hi) ell[(size_t)(q / 4) * PS + pos] = make_int4((int)pk[q], (int)pk[q + 1], (int)pk[q + 2], (int)pk[q + 3]);
         } else {
 #pragma unroll
             for (int q = 0; q < NLMC_ELL_W32; q += 2) {
                 const EdgeQ z{a.k_dummy, 0};
                 const EdgeQ e0 = q < deg ? ed[q] : z, e1 = q + 1 < deg ? ed[q + 1] : z;
-                ell[(size_t)(q / 2) * PS + pos] = make_int4(e0.col, e0.q, e1.col, e1.q);
+                if (q < 8 || hi) ell[(size_t)(q / 2) * PS + pos] = make_int4(e0.col, e0.q, e1.col, e1.q);
             }
         }
     }
@@ -1327,16 +1345,13 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
     int a_min = 0;
     float cqo0 = cq0, cqo1 = cq1, cqn0 = cq0, cqn1 = cq1;  // coefficients of the older / the newer live sweep
     const int o_row = a.slot_of_chain ? a.slot_of_chain[a.chain_base + o_c] : o_c;
-    auto o_cq = [&](int t, int j) __attribute__((always_inline)) {
-        const const_f64o tab = (const_f64o)(uintptr_t)a.tab;
-        return (float)tab[(size_t)o_row * a.tab_cs + (size_t)min(t, a.n_sweeps - 1) * a.tab_ss + j] * a.qinv;
-    };
+#define NLMC_OCQ(t, j) ((float)((const_f64o)(uintptr_t)a.tab)[(size_t)o_row * a.tab_cs + (size_t)min((t), a.n_sweeps - 1) * a.tab_ss + (j)] * a.qinv)
     if (OUT) {
         o_end = ((const_i32o)(uintptr_t)a.fsend)[0];
         E_run = a.efix[o_c];
         E_min = a.emin ? a.emin[o_c] : 0x7FFFFFFFFFFFFFFFll;
         a_min = a.emin ? a.argmin[o_c] : 0;
-        cqn0 = o_cq(1, 0); cqn1 = o_cq(1, 1);
+        cqn0 = NLMC_OCQ(1, 0); cqn1 = NLMC_OCQ(1, 1);
     }
     typedef FusedItem<COMPACT, TAIL> Item;
     constexpr int NP = Item::NP, NE = Item::NE;
@@ -1423,41 +1438,44 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             *(lds_i8w)(uintptr_t)(tw + (unsigned)a.lds_snap_off) = (int8_t)sn;      // snapshot slot of the update's sweep
         }
     };
-    // end of the older live sweep: before the level's barrier every wave adds its share to the sweep's LDS accumulator
-    auto out_pre = [&]() __attribute__((always_inline)) {
-        const long long w = wave_sum_i64(e_loc);
-        long long *red = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);
-        if (lane == 0 && w != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&red[o_t % 3]), (unsigned long long)w);
-    };
-    // ... after it every worker thread knows the energy after that sweep
-    auto out_post = [&]() __attribute__((always_inline)) {
-        long long *red = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);
-        const int slot = o_t % 3, tg = a.t0 + o_t;
-        E_run += red[slot];
-        const bool better = a.emin && E_run < E_min;            // strict <: first argmin (np.argmin, NMC/nmc.py:394)
-        if (better) { E_min = E_run; a_min = tg; }
-        if (o_tid == 0) {
-            red[(o_t + 2) % 3] = 0;                              // read a sweep ago, next used two sweeps from now
-            if (a.etrace) a.etrace[(size_t)o_c * a.trace_sweeps + tg] = E_run;
-        }
-        const unsigned char *snap = lds_raw + a.lds_snap_off + (size_t)slot * o_npad;
-        if (better && a.best) {
-            int4 *dst = reinterpret_cast<int4 *>(a.best + (size_t)o_c * o_npad);
-            const int4 *src = reinterpret_cast<const int4 *>(snap);
-            for (int i = o_tid; i < o_npad / 16; i += a.f_workers * 64) dst[i] = src[i];
-        }
-        if (a.strace && tg % a.rec_stride == 0) {               // M[:, ::M_skip]  (NMC/nmc.py:390)
-            const int n_rec = (a.trace_sweeps + a.rec_stride - 1) / a.rec_stride;
-            int8_t *dst = a.strace + ((size_t)o_c * n_rec + (size_t)(tg / a.rec_stride)) * a.g.n;
-            for (int i = o_tid; i < a.g.n; i += a.f_workers * 64) dst[i] = (int8_t)snap[i];
-        }
-        e_loc = e_new; e_new = 0;
-        ++o_t;
-        o_lo = (unsigned)((o_t % 3) * o_npad);
-        o_end = o_t < a.n_sweeps ? ((const_i32o)(uintptr_t)a.fsend)[o_t] : 0x7FFFFFFF;
-        cqo0 = cqn0; cqo1 = cqn1;
-        cqn0 = o_cq(o_t + 1, 0); cqn1 = o_cq(o_t + 1, 1);
-    };
+    // End of the older live sweep: before the level's barrier every wave adds its share to the sweep's LDS accumulator
+    // (NLMC_OUT_PRE); after it every worker thread knows the energy after that sweep (NLMC_OUT_POST).  Plain macros over
+    // local variables: lambdas that capture this much state end up in scratch memory.
+#define NLMC_OUT_PRE                                                                                                    \
+    {                                                                                                                   \
+        const long long w_ = wave_sum_i64(e_loc);                                                                       \
+        long long *red_ = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);                                       \
+        if (lane == 0 && w_ != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&red_[o_t % 3]), (unsigned long long)w_); \
+    }
+#define NLMC_OUT_POST                                                                                                   \
+    {                                                                                                                   \
+        long long *red_ = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);                                       \
+        const int slot_ = o_t % 3, tg_ = a.t0 + o_t;                                                                    \
+        E_run += red_[slot_];                                                                                           \
+        const bool better_ = a.emin && E_run < E_min;        /* strict <: first argmin (np.argmin, NMC/nmc.py:394) */    \
+        if (better_) { E_min = E_run; a_min = tg_; }                                                                    \
+        if (o_tid == 0) {                                                                                               \
+            red_[(o_t + 2) % 3] = 0;                          /* read a sweep ago, next used two sweeps from now */      \
+            if (a.etrace) a.etrace[(size_t)o_c * a.trace_sweeps + tg_] = E_run;                                         \
+        }                                                                                                               \
+        const unsigned char *snap_ = lds_raw + a.lds_snap_off + (size_t)slot_ * o_npad;                                 \
+        if (better_ && a.best) {                                                                                        \
+            int4 *dst_ = reinterpret_cast<int4 *>(a.best + (size_t)o_c * o_npad);                                       \
+            const int4 *src_ = reinterpret_cast<const int4 *>(snap_);                                                   \
+            for (int i_ = o_tid; i_ < o_npad / 16; i_ += a.f_workers * 64) dst_[i_] = src_[i_];                         \
+        }                                                                                                               \
+        if (a.strace && tg_ % a.rec_stride == 0) {            /* M[:, ::M_skip]  (NMC/nmc.py:390) */                     \
+            const int n_rec_ = (a.trace_sweeps + a.rec_stride - 1) / a.rec_stride;                                      \
+            int8_t *dst_ = a.strace + ((size_t)o_c * n_rec_ + (size_t)(tg_ / a.rec_stride)) * a.g.n;                   \
+            for (int i_ = o_tid; i_ < a.g.n; i_ += a.f_workers * 64) dst_[i_] = (int8_t)snap_[i_];                      \
+        }                                                                                                               \
+        e_loc = e_new; e_new = 0;                                                                                       \
+        ++o_t;                                                                                                          \
+        o_lo = (unsigned)((o_t % 3) * o_npad);                                                                          \
+        o_end = o_t < a.n_sweeps ? ((const_i32o)(uintptr_t)a.fsend)[o_t] : 0x7FFFFFFF;                                   \
+        cqo0 = cqn0; cqo1 = cqn1;                                                                                       \
+        cqn0 = NLMC_OCQ(o_t + 1, 0); cqn1 = NLMC_OCQ(o_t + 1, 1);                                                       \
+    }
 
     // Order inside a level: update first, THEN loads.  The vector-memory path of the CU is the scarcest resource of
     // this loop (a 1 KB wave load occupies it ~16 cycles): a wave that issues its loads first blocks on the full queue
@@ -1482,11 +1500,11 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             if (hasA) { update(A); NLMC_FCALL }
             issue(B, q1 + wv, hasB NLMC_DBG_NOLOAD);
             const bool end0 = OUT && l == o_end;
-            if (end0) out_pre();
+            if (end0) NLMC_OUT_PRE
             NLMC_FW1
             __syncthreads();
             NLMC_FW2
-            if (end0) out_post();
+            if (end0) NLMC_OUT_POST
             if (l + 1 < nl) {
                 NLMC_FW0
                 hasA = (l + 2 < nl) && (q2 + wv < q3);
@@ -1494,11 +1512,11 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
                 if (hasB) { update(B); NLMC_FCALL }
                 issue(A, q2 + wv, hasA NLMC_DBG_NOLOAD);
                 const bool end1 = OUT && l + 1 == o_end;
-                if (end1) out_pre();
+                if (end1) NLMC_OUT_PRE
                 NLMC_FW1
                 __syncthreads();
                 NLMC_FW2
-                if (end1) out_post();
+                if (end1) NLMC_OUT_POST
             }
             q0 = q2; q1 = q3; q2 = q4; q3 = q5;
         }
@@ -1516,11 +1534,11 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             if (hcur) { update(cur); NLMC_FCALL }                                           \
             issue(nxt, (b2) + wv, hnxt NLMC_DBG_NOLOAD);                                    \
             const bool end_ = OUT && (lv) == o_end;                                         \
-            if (end_) out_pre();                                                            \
+            if (end_) NLMC_OUT_PRE                                                          \
             NLMC_FW1                                                                        \
             NLMC_DBG_BARRIER                                                                \
             NLMC_FW2                                                                        \
-            if (end_) out_post();                                                           \
+            if (end_) NLMC_OUT_POST                                                         \
         }
         for (int l = 0; l < nl; l += 3) {
             const int n3 = lo(l + 6), n4 = lo(l + 7), n5 = lo(l + 8);
