@@ -53,7 +53,7 @@ L2_PEAK_GBS = 34500.0        # MI355X_MICROARCH.md, L2 (per XCD): ~34.5 TB/s agg
 VALU_LANES_PER_CU_CLK = 128  # 4 SIMD-32 per CU, one wave64 instruction per 2 cycles per SIMD (MI355X_MICROARCH.md)
 CLOCK_GHZ = 2.4
 N_CUS = 256
-SCHEDULE_BYTES_PER_UPDATE = 72   # what the sweep kernel reads per update from L2: item head 8 B + row window 64 B
+SCHEDULE_BYTES_PER_UPDATE = 40   # what the sweep kernel streams per update from L2: item head 8 B + 8 x 4 B row entries
 
 
 def load_pmc():
@@ -189,7 +189,8 @@ def main():
         chunk = PLAN_CHUNK_ROUNDS if precision == "f32" else 8
         wr = warmup * ROUNDS_PER_STEP
         if wr:
-            st.plan(wr * S_SWAP, wr, chunk_rounds=chunk, lazy=True)
+            # (buffers for a full chunk are allocated here: memory allocation is not part of a round's work)
+            st.plan(wr * S_SWAP, wr, chunk_rounds=chunk, lazy=True, reserve_rounds=chunk)
             for _ in range(wr):
                 st.round(S_SWAP)
         tr = steps * ROUNDS_PER_STEP
@@ -255,7 +256,7 @@ def main():
                          "traffic": pmc.get("hbm_bytes_per_launch"),
                          "traffic_source": pmc.get("source"),
                          "algorithmic_bytes_per_launch": upd_launch * BYTES_PER_UPDATE,
-                         "kernel": "k_sweep_fused<false>", "us_per_launch": ms_launch * 1e3,
+                         "kernel": "k_sweep_fused<false,false,false>", "us_per_launch": ms_launch * 1e3,
                          "bytes_per_update": BYTES_PER_UPDATE, "updates_per_launch": upd_launch,
                          "note": "SURVEY 8d algorithmic bytes (63 B per update, no discount for rows shared by chains). "
                                  "This design keeps spins in LDS and shares one level schedule between all chains of a "

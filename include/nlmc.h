@@ -124,6 +124,9 @@ int nlmc_plan_philox(nlmc_ctx *ctx, int precision, int order_mode, uint32_t swee
  * fused schedule (0 when the instance does not qualify: n < 256 or n > 11264,
  * window < 3 or > 64, or the three threshold tables do not fit in LDS next to the spins). */
 int nlmc_plan_philox_fused(nlmc_ctx *ctx, uint32_t sweep0, int n_windows, int window, uint64_t seed, int32_t *out_planned);
+/* Only allocates the plan buffers for up to n_windows windows of `window` sweeps (a later nlmc_plan_philox_fused of at
+ * most that size then allocates nothing).  Drops the current fused plan. */
+int nlmc_plan_reserve_fused(nlmc_ctx *ctx, int n_windows, int window);
 
 /* Replica exchange (NPT/npt.py:602-683).  Chains are grouped into ladders of ladder_len consecutive global
  * chain ids; slot r of a ladder runs at beta_list[r].  Accepted swaps exchange the beta slots of two chains

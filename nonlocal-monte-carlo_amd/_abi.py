@@ -22,7 +22,7 @@ MAX_N = 24576
 EXPORTS = [
     "nlmc_abi_version", "nlmc_device_count", "nlmc_create", "nlmc_destroy", "nlmc_last_error", "nlmc_set_spins",
     "nlmc_get_spins", "nlmc_set_flags", "nlmc_energy", "nlmc_energy_tracked", "nlmc_energy_dev", "nlmc_set_energy_sink", "nlmc_energy_scale", "nlmc_field_scale", "nlmc_energy_of", "nlmc_sweep_stream",
-    "nlmc_sweep_philox", "nlmc_plan_philox", "nlmc_plan_philox_fused", "nlmc_pt_init", "nlmc_pt_get_slots", "nlmc_pt_set_slots",
+    "nlmc_sweep_philox", "nlmc_plan_philox", "nlmc_plan_philox_fused", "nlmc_plan_reserve_fused", "nlmc_pt_init", "nlmc_pt_get_slots", "nlmc_pt_set_slots",
     "nlmc_pt_apply_swap", "nlmc_pt_swap_philox", "nlmc_pt_plan", "nlmc_pt_check", "nlmc_pt_swap_philox_host", "nlmc_pt_log_begin", "nlmc_pt_log_read", "nlmc_icm_components", "nlmc_icm_move", "nlmc_icm_get_labels", "nlmc_icm_round_philox", "nlmc_icm_round_ladders",
     "nlmc_lbp_convexified", "nlmc_find_clusters",
     "nlmc_last_timing", "nlmc_timing_reset", "nlmc_timing_total", "nlmc_last_schedule_stats",
@@ -91,6 +91,8 @@ def lib():
     L.nlmc_plan_philox.argtypes = [_vp, _i, _i, _u32, _i, _u64]
     L.nlmc_plan_philox_fused.restype = _i
     L.nlmc_plan_philox_fused.argtypes = [_vp, _u32, _i, _i, _u64, _vp]
+    L.nlmc_plan_reserve_fused.restype = _i
+    L.nlmc_plan_reserve_fused.argtypes = [_vp, _i, _i]
     L.nlmc_pt_init.restype = _i
     L.nlmc_pt_init.argtypes = [_vp, _i, _vp]
     L.nlmc_pt_apply_swap.restype = _i

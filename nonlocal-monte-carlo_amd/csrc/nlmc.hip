@@ -135,6 +135,8 @@ struct nlmc_ctx {
     // loopy BP (edge graph built on first use)
     bool lbp_graph_ready = false;
     DevBuf<int32_t> lbp_src, lbp_rev, lbp_flag, lbp_out_i;
+    DevBuf<unsigned int> lbp_bar;
+    DevBuf<double> lbp_part;
     DevBuf<double> lbp_tJ, lbp_eps, lbp_ms, lbp_lams, lbp_w0, lbp_w1, lbp_hm, lbp_tot, lbp_mag, lbp_mag_all;
     // timing / stats
     std::vector<hipEvent_t> events;
@@ -850,6 +852,7 @@ void nlmc_destroy(nlmc_ctx *c)
     c->fz_himax.release(); c->fz_send.release(); c->fz_npos.release();
     c->lbp_src.release(); c->lbp_rev.release(); c->lbp_flag.release(); c->lbp_out_i.release(); c->lbp_tJ.release();
     c->lbp_eps.release(); c->lbp_ms.release(); c->lbp_lams.release(); c->lbp_w0.release(); c->lbp_w1.release();
+    c->lbp_bar.release(); c->lbp_part.release();
     c->lbp_hm.release(); c->lbp_tot.release(); c->lbp_mag.release(); c->lbp_mag_all.release();
     c->pt_tab.release(); c->pt_beta.release(); c->pt_energies_all.release();
     c->slot_of_chain.release(); c->chain_of_slot.release(); c->pt_pairs.release(); c->pt_status.release();
@@ -1093,6 +1096,31 @@ int nlmc_plan_philox(nlmc_ctx *c, int precision, int order_mode, uint32_t sweep0
     return NLMC_OK;
 }
 
+static int reserve_fused_plan(nlmc_ctx *c, int n_windows, int T)
+{
+    const size_t W = (size_t)n_windows, TN = (size_t)T * c->n, PS = (size_t)fused_pstride(c->n, T);
+    HIP_TRY(c, c->fz_glv.reserve(W * TN));
+    HIP_TRY(c, c->fz_perm.reserve(W * PS));
+    HIP_TRY(c, c->fz_head.reserve(W * PS));
+    HIP_TRY(c, c->fz_ell.reserve(W * PS * NLMC_ELL_W32));
+    HIP_TRY(c, c->fz_loff.reserve(W * (NLMC_LCAP + 1)));
+    HIP_TRY(c, c->fz_nlev.reserve(W));
+    HIP_TRY(c, c->fz_npos.reserve(W));
+    HIP_TRY(c, c->fz_himax.reserve(W));
+    HIP_TRY(c, c->fz_send.reserve(W * T));
+    return NLMC_OK;
+}
+
+int nlmc_plan_reserve_fused(nlmc_ctx *c, int n_windows, int window)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (n_windows < 0 || window < 1) return fail(c, NLMC_ERR_ARG, "nlmc_plan_reserve_fused: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n_windows == 0 || !fused_supported(c, window)) return NLMC_OK;
+    c->fz_valid = false;                          // (growing a buffer drops its contents)
+    return reserve_fused_plan(c, n_windows, window);
+}
+
 int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int window, uint64_t seed, int32_t *out_planned)
 {
     if (!c) return NLMC_ERR_ARG;
@@ -1102,19 +1130,10 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     if (out_planned) *out_planned = 0;
     if (n_windows == 0 || !fused_supported(c, window)) return NLMC_OK;
     const int n = c->n, T = window;
-    const size_t W = (size_t)n_windows, TN = (size_t)T * n;
+    const size_t W = (size_t)n_windows;
     c->fz_pstride = fused_pstride(n, T);
-    const size_t PS = (size_t)c->fz_pstride;
-    HIP_TRY(c, c->fz_glv.reserve(W * TN));
-    HIP_TRY(c, c->fz_perm.reserve(W * PS));
+    { int rc = reserve_fused_plan(c, n_windows, T); if (rc) return rc; }
     { int rc = ensure_adjacency(c); if (rc) return rc; }
-    HIP_TRY(c, c->fz_head.reserve(W * PS));
-    HIP_TRY(c, c->fz_ell.reserve(W * PS * NLMC_ELL_W32));
-    HIP_TRY(c, c->fz_loff.reserve(W * (NLMC_LCAP + 1)));
-    HIP_TRY(c, c->fz_nlev.reserve(W));
-    HIP_TRY(c, c->fz_npos.reserve(W));
-    HIP_TRY(c, c->fz_himax.reserve(W));
-    HIP_TRY(c, c->fz_send.reserve(W * T));
     FusedLevelizeArgs a{};
     a.g = c->g;
     a.T = T;
@@ -1668,7 +1687,22 @@ int nlmc_lbp_convexified(nlmc_ctx *c, int n_problems, const double *m_star, cons
     a.w0 = c->lbp_w0.p; a.w1 = c->lbp_w1.p; a.hm = c->lbp_hm.p; a.tot = c->lbp_tot.p; a.mag = c->lbp_mag.p;
     a.mag_all = out_mag_all ? c->lbp_mag_all.p : nullptr;
     a.out_nlam = c->lbp_out_i.p; a.out_status = c->lbp_out_i.p + P; a.out_iters = c->lbp_out_i.p + 2 * P;
-    hipLaunchKernelGGL(k_lbp, dim3(n_problems), dim3(NLMC_LBP_THREADS), 0, c->stream, a);
+    // Workgroups per problem (a problem is bound by the fp64 VALU of the CUs it runs on): up to 8 when FEW problems
+    // are in flight and each has work for them.  The group barrier costs two agent-scope fences per iteration, and L2
+    // write-backs from many workgroups at once are expensive -- measured: 1 problem of 10^4 spins 23 -> 6.6 ms with 8
+    // workgroups, 4 problems 23 -> 8.9 ms, but 64 problems 41 -> 67 ms with 4 each (and 8x slower at 10^3 spins): so
+    // at most 32 workgroups take part in barriers, every launch stays resident (<= one workgroup per CU) in any case.
+    int cus = 0;
+    HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    int group = 1;
+    while (group < 8 && (long long)n_problems * group * 2 <= std::min(32, cus) && n / (group * 2) >= 1024) group *= 2;
+    if (const char *e = getenv("NLMC_LBP_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 8 && (long long)n_problems * v <= cus) group = v; }
+    a.group = group;
+    HIP_TRY(c, c->lbp_bar.reserve(P));
+    HIP_TRY(c, c->lbp_part.reserve(P * 2 * (size_t)group * 4));
+    HIP_TRY(c, hipMemsetAsync(c->lbp_bar.p, 0, sizeof(unsigned int) * P, c->stream));
+    a.bar = c->lbp_bar.p; a.part = c->lbp_part.p;
+    hipLaunchKernelGGL(k_lbp, dim3(n_problems * group), dim3(NLMC_LBP_THREADS), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     std::vector<int32_t> oi(P * (2 + (size_t)n_lambdas));
     HIP_TRY(c, hipMemcpyAsync(oi.data(), c->lbp_out_i.p, sizeof(int32_t) * oi.size(), hipMemcpyDeviceToHost, c->stream));
@@ -1676,6 +1710,8 @@ int nlmc_lbp_convexified(nlmc_ctx *c, int n_problems, const double *m_star, cons
     if (out_mag_all)
         HIP_TRY(c, hipMemcpyAsync(out_mag_all, c->lbp_mag_all.p, sizeof(double) * P * (size_t)n_lambdas * n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t q = 0; q < P; ++q)
+        if (oi[P + q] == 2) return fail(c, NLMC_ERR_HIP, "nlmc_lbp_convexified: the workgroups of a problem lost each other (group barrier timed out)");
     std::memcpy(out_n_lambdas, oi.data(), sizeof(int32_t) * P);
     std::memcpy(out_status, oi.data() + P, sizeof(int32_t) * P);
     std::memcpy(out_iters, oi.data() + 2 * P, sizeof(int32_t) * P * (size_t)n_lambdas);

@@ -4,7 +4,7 @@
 // stored CSR entry e = (i -> j) of row i carries
 //     w[e]  = u_msgs[j, i]   the message INCOMING to i from j (so a node's total is a contiguous row sum)
 //     hm[e] = h_msgs[i, j]   the cavity field of i without j
-// One 1024-thread workgroup per problem (one m_star); all lambdas of LBP_convexified run inside one launch; Jacobi
+// 1-8 workgroups of 1024 threads per problem (one m_star), see k_lbp; all lambdas of LBP_convexified run inside one launch; Jacobi
 // iteration with ping-pong message buffers in global memory (L2 resident: 2 * nnz doubles per problem).
 // Arithmetic: fp64 in the reference's operation order, row sums sequential in ascending neighbour index (the
 // reference's `total` uses NumPy's pairwise association and NumPy's own tanh/arctanh, so results agree to rounding,
@@ -31,7 +31,11 @@ struct LbpArgs {
     double *mag_all;            // [P][n_lams][n] or nullptr
     int32_t *out_nlam;          // [P] number of lambdas processed (entries of the reference's marginals dict)
     int32_t *out_iters;         // [P][n_lams] last iteration index per lambda
-    int32_t *out_status;        // [P] 0 ok, 1 = "LBP diverged at initial lambda"
+    int32_t *out_status;        // [P] 0 ok, 1 = "LBP diverged at initial lambda", 2 = group barrier timed out
+    // a problem may be spread over `group` workgroups (k_lbp: blockIdx = p * group + g), see lbp_group_barrier
+    int group;
+    unsigned int *bar;          // [P] arrival counters (zeroed before the launch)
+    double *part;               // [P][2][group][4] partial maxima of the convergence test, double-buffered
 };
 
 __global__ void k_lbp_src(int n, const int32_t *rowptr, int32_t *src)
@@ -141,37 +145,71 @@ __device__ __forceinline__ double lbp_wave_max(double v)
     return v;
 }
 
+// Barrier between the `group` workgroups that share one problem (they run on different CUs, possibly on different
+// XCDs whose L2s are not coherent): every thread releases its stores at agent scope, one lane arrives on a monotonic
+// counter and polls it with relaxed agent-scope loads, then every thread acquires (invalidates its CU's L1).  The
+// launch keeps problems * group <= number of CUs, so all workgroups are resident; the poll is BOUNDED all the same --
+// on a timeout the problem is flagged (status 2) and its workgroups leave.  Returns false on timeout.
+__device__ __forceinline__ bool lbp_group_barrier(unsigned int *counter, unsigned int target, int tid)
+{
+    __shared__ int ok;
+    __threadfence();                                            // release (agent): write back this thread's stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int budget = 1 << 22;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && --budget > 0)
+            __builtin_amdgcn_s_sleep(2);
+        ok = budget > 0;
+    }
+    __syncthreads();
+    __threadfence();                                            // acquire (agent): drop stale L1 lines
+    return ok != 0;
+}
+
+// blockIdx.x = p * group + g: workgroup g of problem p owns the nodes [i0, i1) and their CSR rows [e0, e1).  Per
+// iteration: node totals of the own nodes (they read messages other workgroups scattered into the own rows during the
+// previous iteration), messages of the own edges (scattered into the neighbours' rows of the other buffer), ONE group
+// barrier that also carries the four partial maxima of the convergence test.  Row sums are sequential and maxima are
+// order-independent, so the result does not depend on `group`.
 __global__ __launch_bounds__(NLMC_LBP_THREADS) void k_lbp(LbpArgs a)
 {
     __shared__ double red[4][NLMC_LBP_THREADS / 64];
     __shared__ double res[4];
-    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int G = a.group, p = blockIdx.x / G, g = blockIdx.x % G;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = a.n, nnz = a.nnz;
+    const int i0 = (int)((long long)n * g / G), i1 = (int)((long long)n * (g + 1) / G);
+    const int e0 = a.rowptr[i0], e1 = a.rowptr[i1];
     double *wc = a.w0 + (size_t)p * nnz, *wn = a.w1 + (size_t)p * nnz;
     double *hm = a.hm + (size_t)p * nnz, *tot = a.tot + (size_t)p * n, *mag = a.mag + (size_t)p * n;
     const double *ms = a.m_star + (size_t)p * n;
+    unsigned int seq = 0;                                   // group barriers passed so far
+    bool dead = false;
 
     // h_msgs = 0, u_msgs = J * m_star.reshape(1, -1)  (NMC/nmc.py:128-129): u_msgs[j, i] = J[j, i] * m_star[i]
-    for (int e = tid; e < nnz; e += NLMC_LBP_THREADS) {
+    for (int e = e0 + tid; e < e1; e += NLMC_LBP_THREADS) {
         wc[e] = a.val[a.rev[e]] * ms[a.src[e]];
         hm[e] = 0.0;
     }
-    for (int i = tid; i < n; i += NLMC_LBP_THREADS) tot[i] = 0.0;
-    __syncthreads();
+    for (int i = i0 + tid; i < i1; i += NLMC_LBP_THREADS) tot[i] = 0.0;
+    if (G > 1) dead = !lbp_group_barrier(a.bar + p, ++seq * (unsigned)G, tid);
+    else __syncthreads();
 
     int n_done = 0, status = 0;
-    for (int l = 0; l < a.n_lams; ++l) {
+    for (int l = 0; l < a.n_lams && !dead; ++l) {
         const double lam = a.lams[l];
         int it = 0;
         for (int iter = 0; iter < a.max_iter; ++iter) {
             it = iter;
             double dh_n = 0.0, dh_d = 0.0, du_n = 0.0, du_d = 0.0;
             // ---- node totals: total_i = h_lam[i] + sum_k u_msgs[k, i]   (NMC/nmc.py:199-201)
-            for (int i = tid; i < n; i += NLMC_LBP_THREADS) {
-                const int e0 = a.rowptr[i], e1 = a.rowptr[i + 1];
+            for (int i = i0 + tid; i < i1; i += NLMC_LBP_THREADS) {
+                const int r0 = a.rowptr[i], r1 = a.rowptr[i + 1];
                 double s = 0.0;
                 int offdiag = 0;
-                for (int e = e0; e < e1; ++e) { s += wc[e]; offdiag += a.col[e] != i; }
+                for (int e = r0; e < r1; ++e) { s += wc[e]; offdiag += a.col[e] != i; }
                 const double hl = a.h[i] + lam * ms[i] * a.eps[i];
                 const double t_new = hl + s, t_old = tot[i];
                 tot[i] = t_new;
@@ -183,7 +221,7 @@ __global__ __launch_bounds__(NLMC_LBP_THREADS) void k_lbp(LbpArgs a)
             __syncthreads();
             // ---- messages: h_msgs[i, j] = total_i - u_msgs[j, i];  u_msgs[i, j] = atanh_sat(tanh(bJ) tanh(b h_msgs)) / b
             // (VALU-bound: ~220 fp64 instructions per message; batching the gathers four messages deep changed nothing)
-            for (int e = tid; e < nnz; e += NLMC_LBP_THREADS) {
+            for (int e = e0 + tid; e < e1; e += NLMC_LBP_THREADS) {
                 const int i = a.src[e], r = a.rev[e];
                 const double h_old = hm[e];
                 const double h_new = (a.col[e] != i) ? tot[i] - wc[e] : 0.0;
@@ -203,19 +241,31 @@ __global__ __launch_bounds__(NLMC_LBP_THREADS) void k_lbp(LbpArgs a)
                 double m = red[tid][0];
                 for (int k = 1; k < NLMC_LBP_THREADS / 64; ++k) m = fmax(m, red[tid][k]);
                 res[tid] = m;
+                if (G > 1) a.part[(((size_t)p * 2 + (seq & 1u)) * G + g) * 4 + tid] = m;
+            }
+            if (G > 1) {
+                const unsigned int slot = seq & 1u;
+                if (!lbp_group_barrier(a.bar + p, ++seq * (unsigned)G, tid)) { dead = true; break; }
+                if (tid < 4) {
+                    double m = 0.0;
+                    for (int k = 0; k < G; ++k) m = fmax(m, a.part[(((size_t)p * 2 + slot) * G + k) * 4 + tid]);
+                    res[tid] = m;
+                }
             }
             __syncthreads();
             { double *t = wc; wc = wn; wn = t; }
             // 0/0 = NaN compares false, like the reference's `du < tolerance and dh < tolerance` (NMC/nmc.py:212-213)
             const double dh = res[0] / res[1], du = res[2] / res[3];
+            __syncthreads();                   // res is rewritten in the next iteration
             if (du < a.tol && dh < a.tol) break;
         }
-        if (tid == 0) a.out_iters[(size_t)p * a.n_lams + l] = it;
+        if (dead) break;
+        if (tid == 0 && g == 0) a.out_iters[(size_t)p * a.n_lams + l] = it;
         const bool exhausted = (it == a.max_iter - 1);
         if (exhausted && l == 0) { status = 1; break; }          // NMC/nmc.py:142-144
         if (!exhausted) {
             // magnetizations = tanh(beta (h_lam + sum_k u_msgs[k, :]))  (NMC/nmc.py:216-217), rows added in ascending k
-            for (int i = tid; i < n; i += NLMC_LBP_THREADS) {
+            for (int i = i0 + tid; i < i1; i += NLMC_LBP_THREADS) {
                 double s = 0.0;
                 for (int e = a.rowptr[i]; e < a.rowptr[i + 1]; ++e) s += wc[e];
                 mag[i] = tanh(a.beta * ((a.h[i] + lam * ms[i] * a.eps[i]) + s));
@@ -225,11 +275,11 @@ __global__ __launch_bounds__(NLMC_LBP_THREADS) void k_lbp(LbpArgs a)
         if (a.mag_all) {
             double *dst = a.mag_all + ((size_t)p * a.n_lams + l) * n;
             __syncthreads();
-            for (int i = tid; i < n; i += NLMC_LBP_THREADS) dst[i] = mag[i];
+            for (int i = i0 + tid; i < i1; i += NLMC_LBP_THREADS) dst[i] = mag[i];
         }
         n_done = l + 1;
         if (exhausted) break;
         __syncthreads();
     }
-    if (tid == 0) { a.out_nlam[p] = n_done; a.out_status[p] = status; }
+    if (tid == 0 && (g == 0 || dead)) { a.out_nlam[p] = dead ? 0 : n_done; a.out_status[p] = dead ? 2 : status; }
 }

@@ -53,12 +53,13 @@ class ShardedTempering:
     def set_spins(self, spins_global):
         self.eng.set_spins(np.asarray(spins_global)[self.base:self.base + self.count])
 
-    def plan(self, n_sweeps, n_rounds=0, chunk_rounds=None, lazy=False):
+    def plan(self, n_sweeps, n_rounds=0, chunk_rounds=None, lazy=False, reserve_rounds=0):
         """Level schedules of the next n_sweeps sweeps and pair selections of the next n_rounds swap rounds (both depend
         on the RNG only).  They are built a bounded chunk of rounds at a time (`chunk_rounds`, and a memory budget);
         with `lazy` nothing is built here: every chunk, the first one included, is planned by the round() that first
         needs it, so that the planning work lies inside whatever the caller times (the reference draws its permutation
-        inside the sweep loop, NMC/nmc.py:62-71)."""
+        inside the sweep loop, NMC/nmc.py:62-71).  `reserve_rounds`: allocate (only allocate) plan buffers for chunks of
+        that many rounds now."""
         self._planner = None
         if n_rounds > 0 and n_sweeps % n_rounds == 0 and hasattr(self.eng, "plan_philox_fused"):
             # rounds of equal length: fused-window level lists where the instance qualifies (same bits, fuller levels)
@@ -66,6 +67,8 @@ class ShardedTempering:
                                          precision=self.precision, budget_bytes=16 << 30, chunk_rounds=chunk_rounds,
                                          pt_pairs=self.n_pairs, pt_round0=self.rounds_done)
             self._planner_round0 = self.rounds_done
+            if reserve_rounds and self._planner.window and hasattr(self.eng, "plan_reserve_fused"):
+                self.eng.plan_reserve_fused(int(reserve_rounds) * (self._planner.S // self._planner.window), self._planner.window)
             if not lazy:
                 self._planner._plan(0, True)
             return

@@ -218,6 +218,10 @@ class Engine:
                                                 ctypes.byref(k)))
         return int(k.value)
 
+    def plan_reserve_fused(self, n_windows, window):
+        """Allocate the fused-window plan buffers for up to n_windows windows (no schedule is built)."""
+        self._ck(self._L.nlmc_plan_reserve_fused(self._ctx, int(n_windows), int(window)))
+
     # -- replica exchange -------------------------------------------------------------------------------
     def pt_init(self, beta_list):
         b = _abi.as_c(beta_list, np.float64).reshape(-1)

@@ -129,3 +129,24 @@ def test_device_lbp_bench_size(product):
         for l in lam_d[:m if len(lam_h) == len(lam_d) else m - 1]:
             assert np.max(np.abs(margs[p][l] - hm[l])) < 1e-9
             assert np.all(np.abs(margs[p][l]) <= 1.0)
+
+
+def test_device_lbp_does_not_depend_on_workgroups_per_problem(product, monkeypatch):
+    """A problem may be spread over 1, 2, 4 or 8 workgroups (one group barrier per BP iteration): row sums stay
+    sequential and maxima are order-independent, so marginals, iteration counts and the stopping lambda are the same
+    bits for every grouping."""
+    J, h = make_instance(3000, seed=19, with_h=True, gaussian=True)
+    inst = product.Instance(J, h)
+    graph = product.lbp.EdgeGraph(inst)
+    eps = graph.epsilon(inst.h)
+    ms = low_energy_states(J, h, 3, seed=2, sweeps=60)
+    lams = product.lbp.lambda_list(0.5, 0.01, 0.9)
+    res = {}
+    for grp in (1, 2, 4, 8):
+        monkeypatch.setenv("NLMC_LBP_GROUP", str(grp))
+        with product.Engine(inst, None, 1) as eng:
+            res[grp] = eng.lbp_convexified(ms, eps, lams, 2.5, EPS, 60, float(np.tanh(19.06)) - EPS, want_all=True)
+    for grp in (2, 4, 8):
+        for k in ("mag", "n_lambdas", "iters", "status", "mag_all"):
+            assert np.array_equal(res[grp][k], res[1][k]), (grp, k)
+    assert res[1]["n_lambdas"].min() >= 2
