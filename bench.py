@@ -157,7 +157,20 @@ def main():
     if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout carries the one JSON line,
+        # so fd 1 points at stderr until the communicator exists (forced by one small collective)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            t = torch.zeros(1, device="cuda")
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     J, h = make_instance(N_SPINS, seed=INSTANCE_SEED)
     inst = P.Instance(J, h)

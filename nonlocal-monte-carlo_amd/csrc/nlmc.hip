@@ -141,6 +141,8 @@ struct nlmc_ctx {
     // timing / stats
     std::vector<hipEvent_t> events;
     size_t ev_used = 0, ev_call_start = 0;
+    std::vector<uint8_t> ev_kind;      // per event triple: 0 = {start, after levelize, after sweep}, 1 = {start, -, end} of a sweep
+                                       // launch, 2 = {start, -, end} of a planning kernel (the middle event is not recorded)
     bool ev_accumulate = false;
     long long launches_total = 0;
     int launches_sweep = 0;
@@ -174,6 +176,16 @@ int rows_to_device(nlmc_ctx *c, void *dst_dev, const void *src_host, int rows);
 int rows_to_host_begin(nlmc_ctx *c, const void *src_dev, int rows);               // async copy into c->stage
 void rows_to_host_finish(nlmc_ctx *c, void *dst_host, int rows);                  // after the stream was synchronised
 
+void tag_triple(nlmc_ctx *c, uint8_t kind)     // call right after taking the three events of a triple
+{
+    const size_t t = c->ev_used / 3 - 1;
+    if (c->ev_kind.size() <= t) c->ev_kind.resize(t + 1, 0);
+    c->ev_kind[t] = kind;
+}
+
+// elapsed (levelize, sweep) milliseconds of triple t
+int triple_ms(nlmc_ctx *c, size_t t, float &lev, float &sw);
+
 hipEvent_t next_event(nlmc_ctx *c)
 {
     if (c->ev_used == c->events.size()) {
@@ -182,6 +194,23 @@ hipEvent_t next_event(nlmc_ctx *c)
         c->events.push_back(e);
     }
     return c->events[c->ev_used++];
+}
+
+int triple_ms(nlmc_ctx *c, size_t t, float &lev, float &sw)
+{
+    const size_t i = 3 * t;
+    const uint8_t kind = t < c->ev_kind.size() ? c->ev_kind[t] : 0;
+    lev = sw = 0.f;
+    HIP_TRY(c, hipEventSynchronize(c->events[i + 2]));
+    if (kind == 0) {
+        HIP_TRY(c, hipEventElapsedTime(&lev, c->events[i], c->events[i + 1]));
+        HIP_TRY(c, hipEventElapsedTime(&sw, c->events[i + 1], c->events[i + 2]));
+    } else if (kind == 1) {
+        HIP_TRY(c, hipEventElapsedTime(&sw, c->events[i], c->events[i + 2]));
+    } else {
+        HIP_TRY(c, hipEventElapsedTime(&lev, c->events[i], c->events[i + 2]));
+    }
+    return NLMC_OK;
 }
 
 int sweep_block(int n)
@@ -348,8 +377,9 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
     { int rc = ensure_lds(c, 8 + variant, kfun, L.total); if (rc) return rc; }
     hipEvent_t e0 = next_event(c), e1 = next_event(c), e2 = next_event(c);
     if (!e0 || !e1 || !e2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
+    (void)e1;
+    tag_triple(c, 1);                              // two stream commands per launch instead of three
     HIP_TRY(c, hipEventRecord(e0, c->stream));
-    HIP_TRY(c, hipEventRecord(e1, c->stream));
     SweepArgs a{};
     a.g = c->g;
     a.chain_base = c->chain_base;
@@ -564,6 +594,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         size_t o0 = 0;
         hipEvent_t e0 = next_event(c), e1 = next_event(c), e2 = next_event(c);
         if (!e0 || !e1 || !e2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
+        tag_triple(c, 0);
         HIP_TRY(c, hipEventRecord(e0, c->stream));
         if (cached) {
             o0 = (size_t)(sweep0 - c->plan_sweep0) + t0;
@@ -1082,11 +1113,12 @@ int nlmc_plan_philox(nlmc_ctx *c, int precision, int order_mode, uint32_t sweep0
     if (c->ev_accumulate) {
         pe0 = next_event(c); pe1 = next_event(c); pe2 = next_event(c);
         if (!pe0 || !pe1 || !pe2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
+        tag_triple(c, 2);
         HIP_TRY(c, hipEventRecord(pe0, c->stream));
     }
     int rc = run_levelize(c, n_sweeps, nullptr, 0, n_sweeps, sweep0, seed, c->plan, ell_mode);
     if (rc) return rc;
-    if (pe0) { HIP_TRY(c, hipEventRecord(pe1, c->stream)); HIP_TRY(c, hipEventRecord(pe2, c->stream)); }
+    if (pe0) HIP_TRY(c, hipEventRecord(pe2, c->stream));
     c->plan_valid = true;
     c->plan_mode = order_mode;
     c->plan_precision = precision;
@@ -1159,11 +1191,12 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     if (c->ev_accumulate) {
         pe0 = next_event(c); pe1 = next_event(c); pe2 = next_event(c);
         if (!pe0 || !pe1 || !pe2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
+        tag_triple(c, 2);
         HIP_TRY(c, hipEventRecord(pe0, c->stream));
     }
     hipLaunchKernelGGL(k_levelize_fused, dim3(n_windows), dim3(1024), lds, c->stream, a);
     HIP_TRY(c, hipGetLastError());
-    if (pe0) { HIP_TRY(c, hipEventRecord(pe1, c->stream)); HIP_TRY(c, hipEventRecord(pe2, c->stream)); }
+    if (pe0) HIP_TRY(c, hipEventRecord(pe2, c->stream));
     c->fz_nlev_host.assign(W, 0);
     c->fz_npos_host.assign(W, 0);
     HIP_TRY(c, hipMemcpyAsync(c->fz_nlev_host.data(), c->fz_nlev.p, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
@@ -1188,10 +1221,9 @@ int nlmc_last_timing(nlmc_ctx *c, float *ms_levelize, float *ms_sweep, int32_t *
     HIP_TRY(c, hipSetDevice(c->device));
     float lev = 0.f, sw = 0.f;
     for (size_t i = c->ev_call_start; i + 3 <= c->ev_used; i += 3) {
-        HIP_TRY(c, hipEventSynchronize(c->events[i + 2]));
         float a = 0.f, b = 0.f;
-        HIP_TRY(c, hipEventElapsedTime(&a, c->events[i], c->events[i + 1]));
-        HIP_TRY(c, hipEventElapsedTime(&b, c->events[i + 1], c->events[i + 2]));
+        int rc = triple_ms(c, i / 3, a, b);
+        if (rc) return rc;
         lev += a; sw += b;
     }
     if (ms_levelize) *ms_levelize = lev;
@@ -1216,10 +1248,9 @@ int nlmc_timing_total(nlmc_ctx *c, double *ms_levelize, double *ms_sweep, int64_
     HIP_TRY(c, hipSetDevice(c->device));
     double lev = 0.0, sw = 0.0;
     for (size_t i = 0; i + 3 <= c->ev_used; i += 3) {
-        HIP_TRY(c, hipEventSynchronize(c->events[i + 2]));
         float a = 0.f, b = 0.f;
-        HIP_TRY(c, hipEventElapsedTime(&a, c->events[i], c->events[i + 1]));
-        HIP_TRY(c, hipEventElapsedTime(&b, c->events[i + 1], c->events[i + 2]));
+        int rc = triple_ms(c, i / 3, a, b);
+        if (rc) return rc;
         lev += a; sw += b;
     }
     if (ms_levelize) *ms_levelize = lev;
