@@ -29,6 +29,24 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     return u32x4{c0, c1, c2, c3};
 }
 
+// rounds [r0, r0 + nr) of philox4x32-10 on a state (the key schedule is a function of the round index): lets a caller
+// cut one call into pieces
+__device__ __forceinline__ u32x4 philox4x32_rounds(u32x4 c, uint32_t k0, uint32_t k1, int r0, int nr)
+{
+    k0 += (uint32_t)r0 * 0x9E3779B9u;
+    k1 += (uint32_t)r0 * 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < nr; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x, p1 = (unsigned long long)0xCD9E8D57u * c.z;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        c = u32x4{n0, (uint32_t)p1, n2, (uint32_t)p0};
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
 // two independent calls side by side: their dependent multiply chains interleave in one wave's instruction stream
 // (a lone producing wave gets no latency hiding from its SIMD neighbours, which sit in barriers most of the time)
 __device__ __forceinline__ void philox4x32_10_x2(uint32_t a0, uint32_t b0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,

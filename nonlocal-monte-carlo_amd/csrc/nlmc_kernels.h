@@ -1289,25 +1289,29 @@ struct FusedGenParams { uint32_t gc; int gtid, gnt, nblk, nj, Tn; };
 #define NLMC_GEN_DBG_LOGIT
 #endif
 // (plain macros over local variables: with lambdas the captured state was kept in scratch memory)
-#define NLMC_GEN_STATE int g_u = 2, g_slot = 2, g_w0 = 0, g_wend = 0, g_per = 1, g_sidx = 0; u32x4 g_r{0u, 0u, 0u, 0u};
+#define NLMC_GEN_STATE int g_u = 2, g_slot = 2, g_w0 = 0, g_wend = 0, g_wlen = 1, g_acc = 0, g_sidx = 0; u32x4 g_r{0u, 0u, 0u, 0u};
+#define NLMC_GEN_NSTEP 3                    /* steps per call: Philox rounds 0-4 | rounds 5-9 | four logits + store */
 #define NLMC_GEN_ARM(a, gp)                                                                                             \
     {                                                                                                                   \
         typedef const int32_t __attribute__((address_space(4))) *const_i32_;                                            \
-        g_sidx = 0;                                                                                                     \
+        g_sidx = 0; g_acc = 0;                                                                                          \
         if (g_u < gp.Tn) {                                                                                              \
             const const_i32_ send_ = (const_i32_)(uintptr_t)a.fsend;                                                    \
-            g_w0 = g_u >= 3 ? __builtin_amdgcn_readfirstlane(send_[g_u - 3]) : -1;                                     \
+            g_w0 = g_u >= 3 ? __builtin_amdgcn_readfirstlane(send_[g_u - 3]) : -1;                                      \
             g_wend = __builtin_amdgcn_readfirstlane(send_[g_u - 2]);                                                    \
-            const int wlen_ = max(1, g_wend - g_w0);     /* levels (w0, wend] are the production window of sweep u */   \
-            g_per = (2 * gp.nj + wlen_ - 1) / wlen_;                                                                    \
+            g_wlen = max(1, g_wend - g_w0);              /* levels (w0, wend] are the production window of sweep u */   \
         } else g_w0 = 0x7FFFFFFF;                                                                                       \
     }
 #define NLMC_GEN_STEP(a, gp)                                                                                            \
     {                                                                                                                   \
-        const int b = gp.gtid + (g_sidx >> 1) * gp.gnt;                                                                 \
-        if ((g_sidx & 1) == 0) {                                                                                        \
+        const int call_ = g_sidx / NLMC_GEN_NSTEP, ph_ = g_sidx - call_ * NLMC_GEN_NSTEP;                               \
+        const int b = gp.gtid + call_ * gp.gnt;                                                                         \
+        if (ph_ == 0) {                                                                                                 \
             NLMC_GEN_DBG_PHILOX                                                                                         \
-            g_r = philox4x32_10((uint32_t)b, a.sweep0 + (uint32_t)g_u, gp.gc, NLMC_TAG_UNIFORM, a.seed_lo, a.seed_hi);  \
+            g_r = philox4x32_rounds(u32x4{(uint32_t)b, a.sweep0 + (uint32_t)g_u, gp.gc, NLMC_TAG_UNIFORM}, a.seed_lo, a.seed_hi, 0, 5); \
+        } else if (ph_ == 1) {                                                                                          \
+            NLMC_GEN_DBG_PHILOX                                                                                         \
+            g_r = philox4x32_rounds(g_r, a.seed_lo, a.seed_hi, 5, 5);                                                   \
         } else if (b < gp.nblk) {                                                                                       \
             typedef nlmc_f4 __attribute__((address_space(3))) *lds_f4_;    /* LDS offsets, no generic pointers */         \
             const lds_f4_ dst = (lds_f4_)(uintptr_t)(unsigned)(a.lds_u_off + g_slot * a.lds_u_stride);                  \
@@ -1316,10 +1320,16 @@ struct FusedGenParams { uint32_t gc; int gtid, gnt, nblk, nj, Tn; };
         }                                                                                                               \
         ++g_sidx;                                                                                                       \
     }
+/* the NLMC_GEN_NSTEP * nj steps of a lane are spread EVENLY over the levels of the production window (an accumulator in
+   the manner of a line-drawing algorithm): a level lasts as long as its slowest wave */
 #define NLMC_GEN(a, gp, l)                                                                                              \
     if (!(NLMC_GEN_DBG_OFF_COND) && (l) > g_w0) {                                                                       \
-        for (int i_ = 0; i_ < g_per && g_sidx < 2 * gp.nj; ++i_) NLMC_GEN_STEP(a, gp)                                   \
-        if ((l) == g_wend) { ++g_u; g_slot = g_slot == 2 ? 0 : g_slot + 1; NLMC_GEN_ARM(a, gp) }                        \
+        g_acc += NLMC_GEN_NSTEP * gp.nj;                                                                                \
+        while (g_acc >= g_wlen) { g_acc -= g_wlen; if (g_sidx < NLMC_GEN_NSTEP * gp.nj) NLMC_GEN_STEP(a, gp) }          \
+        if ((l) == g_wend) {                                                                                            \
+            while (g_sidx < NLMC_GEN_NSTEP * gp.nj) NLMC_GEN_STEP(a, gp)                                                \
+            ++g_u; g_slot = g_slot == 2 ? 0 : g_slot + 1; NLMC_GEN_ARM(a, gp)                                           \
+        }                                                                                                               \
     }
 
 // OUT: per-sweep outputs (energy trace, running minimum + argmin state, recorded configurations) and a temperature per
@@ -1641,27 +1651,46 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
         const unsigned warm_total = warm_lines + (a.fz_compact ? 2u : 4u) * warm_used_p;
         unsigned warm_at = (unsigned)c * (unsigned)hcnt + (unsigned)hid;
         const unsigned warm_step = gridDim.x * (unsigned)hcnt;
-        unsigned wvv = 0u;
-        auto warm_next = [&]() {
-            asm volatile("" :: "v"(wvv) : "memory");          // retire the previous one before reusing its register
-            if (warm_at < warm_total) {
-                const char *p;
-                if (warm_at < warm_lines) p = reinterpret_cast<const char *>(a.warm_head) + (size_t)warm_at * 128;
-                else {
-                    const unsigned r = warm_at - warm_lines, q = r / warm_used_p, i = r - q * warm_used_p;
-                    p = reinterpret_cast<const char *>(a.warm_ell) + ((size_t)q * warm_lines_p + i) * 128;
-                }
-                wvv = *reinterpret_cast<const unsigned *>(p);
-                warm_at += warm_step;
+        // four touches in flight (a touch of a cold line takes longer than a level: waiting for the previous one every
+        // level made these waves the last to reach the barrier)
+        unsigned wv0 = 0u, wv1 = 0u, wv2 = 0u, wv3 = 0u;
+        auto warm_addr = [&]() __attribute__((always_inline)) -> const unsigned * {
+            // (always a load, so that the number of loads in flight is static: past the end, or with nothing to warm, the
+            // lane re-reads a line of this window's own level offsets)
+            const char *p = reinterpret_cast<const char *>(a.lvl_off);
+            if (warm_at < warm_lines) p = reinterpret_cast<const char *>(a.warm_head) + (size_t)warm_at * 128;
+            else if (warm_at < warm_total) {
+                const unsigned r = warm_at - warm_lines, q = r / warm_used_p, i = r - q * warm_used_p;
+                p = reinterpret_cast<const char *>(a.warm_ell) + ((size_t)q * warm_lines_p + i) * 128;
             }
+            warm_at = warm_at < warm_total ? warm_at + warm_step : warm_at;
+            return reinterpret_cast<const unsigned *>(p);
         };
-        for (int l = 0; l < nl; ++l) {
-            warm_next();
+#define NLMC_WARM(reg) { asm volatile("" :: "v"(reg) : "memory"); reg = *warm_addr(); }
+#ifdef NLMC_STAMPS
+        long long sw0, sw1, sw2, st_work = 0, st_bar = 0;
+#endif
+        for (int l = 0; l < nl; l += 4) {
+            NLMC_FW0
+            NLMC_WARM(wv0)
             if (is_gen) NLMC_GEN(a, gp, l)
+            NLMC_FW1
             __syncthreads();
+            NLMC_FW2
+            if (l + 1 < nl) { NLMC_FW0 NLMC_WARM(wv1) if (is_gen) NLMC_GEN(a, gp, l + 1) NLMC_FW1 __syncthreads(); NLMC_FW2 }
+            if (l + 2 < nl) { NLMC_FW0 NLMC_WARM(wv2) if (is_gen) NLMC_GEN(a, gp, l + 2) NLMC_FW1 __syncthreads(); NLMC_FW2 }
+            if (l + 3 < nl) { NLMC_FW0 NLMC_WARM(wv3) if (is_gen) NLMC_GEN(a, gp, l + 3) NLMC_FW1 __syncthreads(); NLMC_FW2 }
         }
+#ifdef NLMC_STAMPS
+        if (a.dbg && lane == 0) {
+            long long *d = a.dbg + ((size_t)blockIdx.x * 16 + wv) * 8;
+            d[5] = st_work; d[6] = st_bar;
+        }
+#endif
+        auto warm_next = [&]() __attribute__((always_inline)) { NLMC_WARM(wv0) };
         while (warm_at < warm_total) warm_next();     // few chains: the rest of this chain's share
-        asm volatile("" :: "v"(wvv) : "memory");
+        asm volatile("" :: "v"(wv0), "v"(wv1), "v"(wv2), "v"(wv3) : "memory");
+#undef NLMC_WARM
     }
 
     // energy of the final state, spins back to HBM
