@@ -84,6 +84,11 @@ int nlmc_field_scale(const nlmc_ctx *ctx);
 
 /* Energies of an arbitrary batch of configurations (trace read-out, NPT/npt.py:685-692). */
 int nlmc_energy_of(nlmc_ctx *ctx, const int8_t *spins /*[count][n]*/, int64_t count, double *out /*[count]*/);
+/* fp64 energies of the configurations the most recent sweep call recorded (out_spins), computed where they still lie on
+ * the device: configurations first .. first+count-1 of every chain -> out [n_chains][count].  Replaces the per-replica
+ * `replica_energy(M[...], k)` loop of NPT/npt.py:685-692 without sending the trace back.  NLMC_ERR_STATE when the last
+ * call recorded fewer. */
+int nlmc_energy_of_recorded(nlmc_ctx *ctx, int first, int count, double *out);
 
 /* Outputs shared by both sweep entry points (every pointer nullable):
  *   out_spins  [n_chains][ceil(n_sweeps/record_stride)][n]  state after sweeps 0, record_stride, 2*record_stride, ...
@@ -209,6 +214,13 @@ int nlmc_lbp_convexified(nlmc_ctx *ctx, int n_problems, const double *m_star, co
 int nlmc_find_clusters(int n, const int32_t *rowptr, const int32_t *colidx, const double *vals, const double *mag,
                        double threshold_initial, double threshold_cutoff, double threshold_step, int32_t *out_members,
                        int64_t members_capacity, int32_t *out_sizes, int32_t *out_n_clusters);
+
+/* Host routine (no device work): lays a recorded trace out as the reference's M blocks.  src [n_blocks][n_sweeps][n]
+ * int8 (out_spins of the sweep calls) -> dst [n_dst_blocks][n][n_sweeps], block b written to block dst_block[b] (NULL:
+ * identity), as int8 (elem_bytes 1) or float64 (elem_bytes 8) -- `M[r*N:(r+1)*N, :] = MCMC(...)` of NPT/npt.py:641 for
+ * every replica at once, filled by n_threads host threads (<= 0: one per core, at most 32). */
+int nlmc_trace_layout(const int8_t *src, int64_t n_blocks, int64_t n_sweeps, int64_t n, const int32_t *dst_block,
+                      int64_t n_dst_blocks, void *dst, int elem_bytes, int n_threads);
 
 /* Timing of the most recent sweep call, measured with HIP events on the context's stream. */
 int nlmc_last_timing(nlmc_ctx *ctx, float *ms_levelize, float *ms_sweep, int32_t *launches_sweep);

@@ -24,7 +24,7 @@ EXPORTS = [
     "nlmc_get_spins", "nlmc_set_flags", "nlmc_energy", "nlmc_energy_tracked", "nlmc_energy_dev", "nlmc_set_energy_sink", "nlmc_energy_scale", "nlmc_field_scale", "nlmc_energy_of", "nlmc_sweep_stream",
     "nlmc_sweep_philox", "nlmc_plan_philox", "nlmc_plan_philox_fused", "nlmc_plan_reserve_fused", "nlmc_pt_init", "nlmc_pt_get_slots", "nlmc_pt_set_slots",
     "nlmc_pt_apply_swap", "nlmc_pt_swap_philox", "nlmc_pt_plan", "nlmc_pt_check", "nlmc_pt_swap_philox_host", "nlmc_pt_log_begin", "nlmc_pt_log_read", "nlmc_icm_components", "nlmc_icm_move", "nlmc_icm_get_labels", "nlmc_icm_round_philox", "nlmc_icm_round_ladders",
-    "nlmc_lbp_convexified", "nlmc_find_clusters",
+    "nlmc_lbp_convexified", "nlmc_find_clusters", "nlmc_trace_layout", "nlmc_energy_of_recorded",
     "nlmc_last_timing", "nlmc_timing_reset", "nlmc_timing_total", "nlmc_last_schedule_stats",
 ]
 
@@ -123,6 +123,10 @@ def lib():
     L.nlmc_lbp_convexified.argtypes = [_vp, _i, _vp, _vp, _vp, _i, _dbl, _dbl, _i, _dbl, _vp, _vp, _vp, _vp, _vp]
     L.nlmc_find_clusters.restype = _i
     L.nlmc_find_clusters.argtypes = [_i, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _vp, _i64, _vp, _vp]
+    L.nlmc_energy_of_recorded.restype = _i
+    L.nlmc_energy_of_recorded.argtypes = [_vp, _i, _i, _vp]
+    L.nlmc_trace_layout.restype = _i
+    L.nlmc_trace_layout.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i, _i]
     L.nlmc_last_timing.restype = _i
     L.nlmc_last_timing.argtypes = [_vp, _vp, _vp, _vp]
     L.nlmc_timing_reset.restype = _i

@@ -62,6 +62,7 @@ struct nlmc_ctx {
     DevBuf<double> energy, tab, ustream, etrace_d;
     DevBuf<uint32_t> keys;
     DevBuf<int8_t> strace, cfg;
+    int strace_nrec = 0;          // recorded configurations per chain held in strace by the last sweep call (0: none)
     // schedule scratch (per call) and plan cache (persistent)
     struct Sched {            // one set of level-schedule buffers (per-call scratch, or the persistent plan)
         DevBuf<int2> order, head32;
@@ -502,6 +503,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
     c->stat_orders = 0;
     c->stat_levels = 0;
     c->stats_pending = false;
+    c->strace_nrec = 0;
     if (R == 0 || n_sweeps == 0) return NLMC_OK;
     const bool want_min = o.out_min_energy || o.out_argmin || o.out_argmin_state;
     c->stat_fused_window = -1;
@@ -528,6 +530,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
     }
     if (o.out_energy) HIP_TRY(c, c->etrace.reserve((size_t)R * n_sweeps));
     if (rec) HIP_TRY(c, c->strace.reserve((size_t)R * n_rec * n));
+    c->strace_nrec = n_rec;
     if (want_min) {
         std::vector<long long> init((size_t)R, LLONG_MAX);
         HIP_TRY(c, hipMemcpyAsync(c->emin.p, init.data(), sizeof(long long) * R, hipMemcpyHostToDevice, c->stream));
@@ -998,6 +1001,25 @@ int nlmc_energy_of(nlmc_ctx *c, const int8_t *spins, int64_t count, double *out)
         HIP_TRY(c, hipMemcpyAsync(out + b, c->etrace_d.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    return NLMC_OK;
+}
+
+int nlmc_energy_of_recorded(nlmc_ctx *c, int first, int count, double *out)
+{
+    if (!c || !out || first < 0 || count < 0) return fail(c, NLMC_ERR_ARG, "nlmc_energy_of_recorded: bad argument");
+    if (first + count > c->strace_nrec)
+        return fail(c, NLMC_ERR_STATE, "nlmc_energy_of_recorded: the last sweep call recorded fewer configurations per chain");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int64_t m = (int64_t)c->n_chains * count;
+    if (m == 0) return NLMC_OK;
+    HIP_TRY(c, c->etrace_d.reserve((size_t)m));
+    EnergyArgs a{};
+    a.g = c->g; a.spins = c->strace.p + (size_t)first * c->n; a.stride = c->n; a.stride_outer = (int64_t)c->strace_nrec * c->n;
+    a.inner = count; a.out = c->etrace_d.p; a.efix = nullptr; a.escale = c->escale;
+    hipLaunchKernelGGL(k_energy, dim3((unsigned)m), dim3(c->n >= 4096 ? 1024 : 256), (size_t)c->n_pad, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, c->etrace_d.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return NLMC_OK;
 }
 
@@ -1759,6 +1781,26 @@ int nlmc_find_clusters(int n, const int32_t *rowptr, const int32_t *colidx, cons
     if (host_find_clusters(n, rowptr, colidx, vals, mag, threshold_initial, threshold_cutoff, threshold_step, out_members,
                            members_capacity, out_sizes, out_n_clusters) != 0)
         return fail(nullptr, NLMC_ERR_ARG, "nlmc_find_clusters: out_members too small");
+    return NLMC_OK;
+}
+
+int nlmc_trace_layout(const int8_t *src, int64_t n_blocks, int64_t n_sweeps, int64_t n, const int32_t *dst_block,
+                      int64_t n_dst_blocks, void *dst, int elem_bytes, int n_threads)
+{
+    if (n_blocks < 0 || n_sweeps < 0 || n < 1 || (n_blocks * n_sweeps > 0 && (!src || !dst)) || n_dst_blocks < n_blocks)
+        return fail(nullptr, NLMC_ERR_ARG, "nlmc_trace_layout: bad sizes or NULL arrays");
+    if (elem_bytes != 1 && elem_bytes != 8) return fail(nullptr, NLMC_ERR_ARG, "nlmc_trace_layout: elem_bytes must be 1 or 8");
+    if (dst_block) {                                 // destination blocks: distinct and in range (threads write disjointly)
+        std::vector<uint8_t> seen((size_t)n_dst_blocks, 0);
+        for (int64_t b = 0; b < n_blocks; ++b) {
+            if (dst_block[b] < 0 || dst_block[b] >= n_dst_blocks || seen[dst_block[b]])
+                return fail(nullptr, NLMC_ERR_ARG, "nlmc_trace_layout: dst_block must hold distinct indices < n_dst_blocks");
+            seen[dst_block[b]] = 1;
+        }
+    }
+    if (n_threads <= 0) n_threads = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    if (elem_bytes == 8) host_trace_layout<double>(src, n_blocks, n_sweeps, n, dst_block, (double *)dst, n_threads);
+    else host_trace_layout<int8_t>(src, n_blocks, n_sweeps, n, dst_block, (int8_t *)dst, n_threads);
     return NLMC_OK;
 }
 

@@ -1717,8 +1717,10 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
 // ------------------------------------------------------------------------------------------------------
 struct EnergyArgs {
     CsrDev g;
-    const int8_t *spins;   // [count][stride]
+    const int8_t *spins;   // [count][stride], or [count / inner][stride_outer] of [inner][stride] when inner > 0
     int64_t stride;
+    int64_t stride_outer;
+    int inner;
     double *out;           // [count] or nullptr
     long long *efix;       // [count] or nullptr
     int escale;
@@ -1731,7 +1733,8 @@ __global__ void k_energy(EnergyArgs a)
     const int n = a.g.n;
     int8_t *s = reinterpret_cast<int8_t *>(lds_raw);
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int8_t *src = a.spins + (size_t)blockIdx.x * a.stride;
+    const int8_t *src = a.inner > 0 ? a.spins + (size_t)(blockIdx.x / a.inner) * a.stride_outer + (size_t)(blockIdx.x % a.inner) * a.stride
+                                    : a.spins + (size_t)blockIdx.x * a.stride;
     for (int i = tid; i < n; i += nt) s[i] = src[i];
     __syncthreads();
     // Four rows per thread at a time, the first 8 entries of each fetched unconditionally (padded arrays): 64

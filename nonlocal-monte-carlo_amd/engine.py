@@ -134,6 +134,13 @@ class Engine:
         self._ck(self._L.nlmc_energy_of(self._ctx, _abi.ptr(c), c.shape[0], _abi.ptr(out)))
         return out
 
+    def energy_of_recorded(self, count, first=0):
+        """fp64 energies of recorded configurations first .. first+count-1 of every chain, taken from the device copy of
+        the trace of the most recent sweep call (`record_stride` > 0) -> [n_chains, count]."""
+        out = np.empty((self.n_chains, int(count)), dtype=np.float64)
+        self._ck(self._L.nlmc_energy_of_recorded(self._ctx, int(first), int(count), _abi.ptr(out)))
+        return out
+
     # -- sweeps -----------------------------------------------------------------------------------------
     def _outputs(self, S, record_stride, want_energy, want_min, want_state):
         R, n = self.n_chains, self.n
@@ -348,6 +355,27 @@ class Engine:
         a, b = ctypes.c_int64(0), ctypes.c_int64(0)
         self._ck(self._L.nlmc_last_schedule_stats(self._ctx, ctypes.byref(a), ctypes.byref(b)))
         return {"orders": a.value, "levels": b.value}
+
+
+def trace_layout(spins, dst_block=None, n_dst_blocks=None, dtype=np.float64, n_threads=0):
+    """Recorded traces [blocks, S, N] int8 -> the reference's M layout [n_dst_blocks * N, S] (`M[r*N:(r+1)*N, :] =
+    MCMC(...)`, NPT/npt.py:641), block b going to rows of block dst_block[b]; int8 or float64; compiled host routine
+    (nlmc_trace_layout), one thread per core."""
+    spins = np.ascontiguousarray(spins, dtype=np.int8)
+    B, S, N = spins.shape
+    nd = B if n_dst_blocks is None else int(n_dst_blocks)
+    dt = np.dtype(dtype)
+    if dt not in (np.dtype(np.int8), np.dtype(np.float64)):
+        raise ValueError("trace_layout: dtype must be int8 or float64")
+    full = dst_block is None and nd == B
+    M = np.empty((nd * N, S), dtype=dt) if full else np.zeros((nd * N, S), dtype=dt)
+    db = None if dst_block is None else np.ascontiguousarray(dst_block, dtype=np.int32)
+    if db is not None and db.shape != (B,):
+        raise ValueError("trace_layout: dst_block must have one entry per block")
+    L = _abi.lib()
+    _abi.check(L.nlmc_trace_layout(_abi.ptr(spins), B, S, N, _abi.ptr(db) if db is not None else None, nd, _abi.ptr(M),
+                                   dt.itemsize, int(n_threads)), None)
+    return M
 
 
 def device_count():

@@ -19,7 +19,7 @@ import numpy as np
 
 from . import hostlogic
 from .base import Common
-from .engine import Engine, RoundPlanner
+from .engine import Engine, RoundPlanner, trace_layout
 
 
 class NPT(Common):
@@ -272,13 +272,14 @@ class NPT(Common):
             raise ValueError("num_replicas * num_restarts must be a multiple of len(device_ids)")
         lt = LocalTempering(inst, beta_list, G, self.seed, self.num_swapping_pairs, devs)
         try:
-            m0 = np.sign(np.random.default_rng(self.seed).random((G, N)) - 0.5).astype(np.int8)   # == sign(2 u - 1)
+            m0 = (2 * np.random.default_rng(self.seed).integers(0, 2, size=(G, N), dtype=np.int8) - 1).astype(np.int8)
             lt.set_spins(m0)
             lt.sweeps_done = self._sweep_counter
             lt.plan(rounds * S, rounds)
             if self.num_swapping_pairs > 0:
                 lt.log_begin(rounds)
-            last, e_last, slots_last = None, None, np.arange(G, dtype=np.int32) % R
+            k = self.num_sweeps_read_per_swap
+            last, e_last, E_cols, slots_last = None, None, None, np.arange(G, dtype=np.int32) % R
             for ii in range(rounds):
                 is_last = ii == rounds - 1
                 if is_last:
@@ -286,22 +287,20 @@ class NPT(Common):
                 if not is_last:
                     lt.round(S)
                 elif return_trace is not None:
-                    last = np.concatenate([o["spins"] for o in lt.round(S, record_stride=1)])       # [G, S, N] int8
+                    outs = lt.round(S, record_stride=1)
+                    last = outs[0]["spins"] if len(outs) == 1 else np.concatenate([o["spins"] for o in outs])  # [G, S, N] int8
+                    if 0 < k and S > 0:
+                        # replica_energy (NPT/npt.py:31-45, :685-692) of every replica: fp64 energies of the FIRST R_swap
+                        # recorded columns, computed on the device copy of the trace (one launch per context)
+                        E_cols = np.concatenate([e.energy_of_recorded(min(k, S)) for e in lt.engs])
                 else:
                     e_last = np.concatenate([o["energy"] for o in lt.round(S, want_energy=True)])   # [G, S] tracked
             self._sweep_counter += rounds * S
             Energy = np.zeros(R)
             E_all = np.zeros((n_restarts, R))
-            k = self.num_sweeps_read_per_swap
             if last is not None and S > 0:
-                # replica_energy (NPT/npt.py:31-45, :685-692) of every replica: min over the FIRST R_swap columns -- one
-                # batched energy call per context instead of one per replica
                 if k > 0:
-                    E_cols = np.concatenate([e.energy_of(np.ascontiguousarray(last[b:b + c, :k]).reshape(c * k, N)).reshape(c, k)
-                                             for e, (b, c) in zip(lt.engs, lt.parts)])
-                    E_min = E_cols.min(axis=1)
-                    for g in range(G):
-                        E_all[g // R, int(slots_last[g])] = E_min[g]
+                    E_all[np.arange(G) // R, slots_last] = E_cols.min(axis=1)
                     Energy = E_all[0].copy()
                 else:
                     Energy[0] = np.min(np.zeros(0))                              # np.min of nothing: ValueError (NPT/npt.py:43)
@@ -310,17 +309,13 @@ class NPT(Common):
                 # fixed-point couplings, within 2^-(qs+1) per coupling of the fp64 ones)
                 if k <= 0:
                     Energy[0] = np.min(np.zeros(0))
-                E_min = e_last[:, :k].min(axis=1)
-                for g in range(G):
-                    E_all[g // R, int(slots_last[g])] = E_min[g]
+                E_all[np.arange(G) // R, slots_last] = e_last[:, :k].min(axis=1)
                 Energy = E_all[0].copy()
             M = None
             if return_trace is not None:
                 dt = np.float64 if return_trace == "float64" else np.int8
-                if last is not None:                     # restart 0 is the one returned in the reference's shape
-                    M3 = np.empty((R, N, S), dtype=dt)   # block r = the replica at temperature slot r
-                    M3[slots_last[:R]] = last[:R].transpose(0, 2, 1)
-                    M = M3.reshape(R * N, S)
+                if last is not None:                     # restart 0 is the one returned in the reference's shape:
+                    M = trace_layout(last[:R], slots_last[:R], R, dt)    # block r = the replica at temperature slot r
                 else:
                     M = np.zeros((R * N, S), dtype=dt)
             if self.num_swapping_pairs > 0 and rounds > 0:

@@ -59,3 +59,29 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
                 assert "oracle/" not in src or f.endswith((".h", ".hip", ".py")) and "import" not in src.split("oracle/")[0][-20:]
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.float64])
+@pytest.mark.parametrize("shape", [(3, 5, 7), (6, 10, 3000), (40, 4, 2100)])
+def test_trace_layout_host_routine(product, dtype, shape):
+    """include/nlmc.h: nlmc_trace_layout (compiled host routine, threads) == `M[r*N:(r+1)*N, :] = trace_r.T`
+    (NPT/npt.py:641) for every block, with and without a block permutation, small (one thread) and large (threads)."""
+    P = product
+    B, S, N = shape
+    rng = np.random.default_rng(B * 1000 + S)
+    spins = (2 * rng.integers(0, 2, size=shape, dtype=np.int8) - 1).astype(np.int8)
+    M = P.engine.trace_layout(spins, dtype=dtype)
+    assert M.dtype == dtype and M.shape == (B * N, S)
+    for b in range(B):
+        assert np.array_equal(M[b * N:(b + 1) * N], spins[b].T)
+    perm = rng.permutation(B + 2)[:B].astype(np.int32)
+    M = P.engine.trace_layout(spins, perm, B + 2, dtype=dtype, n_threads=5)
+    for b in range(B):
+        assert np.array_equal(M[perm[b] * N:(perm[b] + 1) * N], spins[b].T)
+    untouched = sorted(set(range(B + 2)) - set(perm.tolist()))
+    for r in untouched:
+        assert not M[r * N:(r + 1) * N].any()
+    with pytest.raises(ValueError):
+        P.engine.trace_layout(spins, np.zeros(B, np.int32), B, dtype=dtype)        # repeated destination block
+    with pytest.raises(ValueError):
+        P.engine.trace_layout(spins, dtype=np.float32)

@@ -151,3 +151,28 @@ def test_new_entry_points_degenerate_inputs(product):
                                                np.finfo(float).eps, 20, 0.999999, 0.99999, 2.5)
     assert product.lbp.find_clusters(graph, np.zeros(n), 0.999999, 0.99999, 0.01) == []
     assert product.lbp.find_clusters(graph, np.zeros(n), 0.999999, 0.99999, 0.01, flat=True).size == 0
+
+
+@pytest.mark.parametrize("n,fused", [(300, False), (1500, True)])
+def test_energies_of_the_recorded_trace_on_the_device(product, n, fused):
+    """nlmc_energy_of_recorded (replica_energy over the first k columns, NPT/npt.py:31-45,685-692, without sending the
+    trace back) == nlmc_energy_of of the same configurations == the oracle's energy; refused when nothing was recorded."""
+    J, h = make_instance(n, seed=7, with_h=True, gaussian=True)
+    csr = oracle.Csr(J)
+    R, S = 5, 6
+    m0 = init_spins(R, n)
+    with product.Engine(J, h, R) as eng:
+        eng.set_spins(m0)
+        if fused:
+            assert eng.plan_philox_fused(0, 1, S, 99) == 1
+        o = eng.sweep_philox(S, 99, beta=np.linspace(0.3, 2.0, R), record_stride=1)
+        for first, k in ((0, S), (0, 2), (3, 3)):
+            E = eng.energy_of_recorded(k, first)
+            assert E.shape == (R, k)
+            assert np.array_equal(E, eng.energy_of(o["spins"][:, first:first + k]).reshape(R, k))
+        assert abs(E[2, 1] - oracle.energy(csr, h, o["spins"][2, 4])) <= 1e-9 * max(1.0, abs(E[2, 1]))
+        with pytest.raises(RuntimeError):
+            eng.energy_of_recorded(S + 1)
+        eng.sweep_philox(2, 99, sweep0=S, beta=1.0)              # records nothing
+        with pytest.raises(RuntimeError):
+            eng.energy_of_recorded(1)
