@@ -216,11 +216,13 @@ int nlmc_find_clusters(int n, const int32_t *rowptr, const int32_t *colidx, cons
                        int64_t members_capacity, int32_t *out_sizes, int32_t *out_n_clusters);
 
 /* Host routine (no device work): lays a recorded trace out as the reference's M blocks.  src [n_blocks][n_sweeps][n]
- * int8 (out_spins of the sweep calls) -> dst [n_dst_blocks][n][n_sweeps], block b written to block dst_block[b] (NULL:
- * identity), as int8 (elem_bytes 1) or float64 (elem_bytes 8) -- `M[r*N:(r+1)*N, :] = MCMC(...)` of NPT/npt.py:641 for
- * every replica at once, filled by n_threads host threads (<= 0: one per core, at most 32). */
+ * int8 (out_spins of the sweep calls) -> dst [n_dst_blocks][n][row_len]; block b goes to block dst_block[b] (NULL:
+ * identity), columns dst_col[b] .. dst_col[b]+n_sweeps-1 (NULL: 0; a multiple of n_sweeps), as int8 (elem_bytes 1) or
+ * float64 (elem_bytes 8) -- `M[r*N:(r+1)*N, :] = MCMC(...)` of NPT/npt.py:641 and the sub-replica column groups of
+ * NPT/apt_ICM.py:207 for every chain at once, filled by n_threads host threads (<= 0: one per core, at most 32).
+ * Elements of dst that no block maps to are left untouched. */
 int nlmc_trace_layout(const int8_t *src, int64_t n_blocks, int64_t n_sweeps, int64_t n, const int32_t *dst_block,
-                      int64_t n_dst_blocks, void *dst, int elem_bytes, int n_threads);
+                      const int32_t *dst_col, int64_t n_dst_blocks, int64_t row_len, void *dst, int elem_bytes, int n_threads);
 
 /* Timing of the most recent sweep call, measured with HIP events on the context's stream. */
 int nlmc_last_timing(nlmc_ctx *ctx, float *ms_levelize, float *ms_sweep, int32_t *launches_sweep);

@@ -126,7 +126,7 @@ def lib():
     L.nlmc_energy_of_recorded.restype = _i
     L.nlmc_energy_of_recorded.argtypes = [_vp, _i, _i, _vp]
     L.nlmc_trace_layout.restype = _i
-    L.nlmc_trace_layout.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i, _i]
+    L.nlmc_trace_layout.argtypes = [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i, _i]
     L.nlmc_last_timing.restype = _i
     L.nlmc_last_timing.argtypes = [_vp, _vp, _vp, _vp]
     L.nlmc_timing_reset.restype = _i

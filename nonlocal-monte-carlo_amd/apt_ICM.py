@@ -19,7 +19,7 @@ import numpy as np
 
 from . import hostlogic
 from .base import SweepMixin
-from .engine import Engine, RoundPlanner
+from .engine import Engine, RoundPlanner, trace_layout
 
 
 class APT_ICM(SweepMixin):
@@ -83,8 +83,11 @@ class APT_ICM(SweepMixin):
 
     # ------------------------------------------------------------------------------------------------
     def run(self, beta_list, num_replicas, num_sweeps_MCMC=1000, num_sweeps_read=1000, num_swap_attempts=100,
-            num_swapping_pairs=1, use_hash_table=0, num_cores=8, plot=False, icm_feedback=False):
-        """NPT/apt_ICM.py:145-305.  Returns (M [R*N, S_swap*10], Energy [R])."""
+            num_swapping_pairs=1, use_hash_table=0, num_cores=8, plot=False, icm_feedback=False, return_trace="float64"):
+        """NPT/apt_ICM.py:145-305.  Returns (M [R*N, S_swap*10], Energy [R]).  `return_trace` (device-resident path only):
+        "float64" (the reference's M), "int8" (same layout, 1 byte per entry) or None (M is not materialised)."""
+        if return_trace not in ("float64", "int8", None):
+            raise ValueError("return_trace must be 'float64', 'int8' or None")
         self.num_replicas = num_replicas
         self.num_sweeps_MCMC = num_sweeps_MCMC
         self.num_sweeps_read = num_sweeps_read
@@ -99,7 +102,7 @@ class APT_ICM(SweepMixin):
         S = self.num_sweeps_MCMC_per_swap
         beta_list = np.asarray(beta_list, dtype=np.float64)
         if self.rng == "philox" and icm_feedback:
-            return self._run_device_resident(inst, beta_list, plot)
+            return self._run_device_resident(inst, beta_list, plot, return_trace)
         numpy_mode = self.rng == "numpy"
         host_rng = None if numpy_mode else np.random.default_rng(self.seed)
         all_pairs = [(i, i + 1) for i in range(1, R)]
@@ -186,7 +189,7 @@ class APT_ICM(SweepMixin):
                                 for r in range(R)], beta_list)
         return M, Energy
 
-    def _run_device_resident(self, inst, beta_list, plot):
+    def _run_device_resident(self, inst, beta_list, plot, return_trace="float64"):
         """Throughput path (rng="philox", icm_feedback=True): every (sub-replica, replica) chain lives in ONE context,
         laid out sub-replica-major so that each sub-replica's beta ladder is a block of consecutive chains.  Per round:
         batched sweeps at the ladder temperatures -> iso-cluster moves between randomly paired sub-replicas of every
@@ -199,42 +202,49 @@ class APT_ICM(SweepMixin):
         host_rng = np.random.default_rng(self.seed)      # initial states only
         eng = Engine(inst, None, G, device=self._cache.device)
         try:
-            eng.set_spins(np.sign(2 * host_rng.random((G, N)) - 1).astype(np.int8))
+            eng.set_spins((2 * host_rng.integers(0, 2, size=(G, N), dtype=np.int8) - 1).astype(np.int8))
             eng.pt_init(beta_list)
             planner = RoundPlanner(eng, self._sweep_counter, rounds, S, self.seed)
             if self.num_swapping_pairs > 0 and rounds > 0:
                 eng.pt_plan(0, rounds, self.seed, self.num_swapping_pairs)
-            last, slots_last = None, np.arange(G, dtype=np.int32) % R
-            acc_log, icm_sizes = [], []
-            log_every = max(1, rounds // 64)
+            last, E_rec, slots_last = None, None, np.arange(G, dtype=np.int32) % R
+            icm_sizes = []
+            log_every = max(1, rounds // 16)
+            swaps = self.num_swapping_pairs > 0 and rounds > 0
+            if swaps:
+                eng.pt_log_begin(0, rounds, self.num_swapping_pairs)      # swap log stays on the device, read once
             for ii in range(rounds):
                 is_last = ii == rounds - 1
                 if is_last:
                     slots_last = eng.pt_slots()
                 o = planner.sweep(ii, record_stride=1 if is_last else 0)
-                if is_last:
-                    last = o["spins"]
+                if is_last and S > 0:
+                    last = o["spins"]                                  # [G, S, N] int8
+                    E_rec = eng.energy_of_recorded(S)                  # fp64 energies of the trace, from its device copy
                 # Houdayer: for every temperature slot the K sub-replicas that currently hold it are shuffled and paired
-                # on the device (nlmc_icm_round_ladders); logs are read back on a sample of the rounds only (a read-back
-                # synchronises the stream)
-                logged = rounds <= 256 or is_last or ii % log_every == 0
+                # on the device (nlmc_icm_round_ladders); cluster sizes are read back on a sample of the rounds only (a
+                # read-back synchronises the stream; it also reports a component search that did not converge)
+                logged = rounds <= 16 or is_last or ii % log_every == 0
                 info = eng.icm_round_ladders(ii, self.seed, self.useKatzgraber, want_info=logged)
                 if logged:
                     icm_sizes.append(info[:, 1].copy())
-                if self.num_swapping_pairs > 0:
-                    _, a = eng.pt_swap_philox(ii, self.seed, self.num_swapping_pairs, want_log=logged)
-                    if logged:
-                        acc_log.append(a)
+                if swaps:
+                    eng.pt_swap_philox(ii, self.seed, self.num_swapping_pairs, want_log=False)
+            acc_log = [eng.pt_log_read()[1]] if swaps else []
             self._sweep_counter += rounds * S
-            M = np.zeros((N * R, S * K))
+            # M block of replica r = [N, K S]: sub-replica j in columns j S .. (NPT/apt_ICM.py:188,207); Energy[r] = min
+            # over the FIRST num_sweeps_read_per_swap columns of the block (NPT/apt_ICM.py:36-50, :290-297)
+            dt = np.float64 if return_trace != "int8" else np.int8
+            M = None if return_trace is None else np.zeros((N * R, S * K), dtype=dt)
             Energy = np.zeros(R)
-            if last is not None and S > 0:
-                for j in range(K):
-                    for c in range(R):
-                        r = int(slots_last[j * R + c])
-                        M[r * N:(r + 1) * N, j * S:(j + 1) * S] = last[j * R + c].T
-                for r in range(R):
-                    Energy[r] = self.replica_energy(M[r * N:(r + 1) * N, :], self.num_sweeps_read_per_swap)[0]
+            if last is not None:
+                cols = (np.arange(G, dtype=np.int32) // R) * S
+                if return_trace is not None:
+                    M = trace_layout(last, slots_last, R, dt, dst_col=cols, row_len=S * K)
+                E_blk = np.empty((R, K * S))
+                E_blk[slots_last[:, None], cols[:, None] + np.arange(S)[None, :]] = E_rec
+                k = self.num_sweeps_read_per_swap
+                Energy = np.min(E_blk[:, :k], axis=1) if k > 0 else np.min(np.zeros(0))    # np.min of nothing: ValueError
             self.final_energies = eng.energy()
             self.final_slots = eng.pt_slots()
             self.swap_accepted = np.concatenate([a.reshape(-1) for a in acc_log]).astype(np.int8) if acc_log else np.zeros(0, np.int8)
@@ -242,7 +252,7 @@ class APT_ICM(SweepMixin):
         finally:
             eng.close()
         print(f"\nLatest energy from each replica = {Energy}")
-        if plot:
+        if plot and M is not None:
             self.plot_energies([self.replica_energy(M[r * N:(r + 1) * N, :], self.num_sweeps_read_per_swap)[1]
                                 for r in range(R)], beta_list)
         return M, Energy

@@ -24,7 +24,7 @@ import os
 import numpy as np
 
 from . import hostlogic
-from .engine import Engine, Instance
+from .engine import Engine, Instance, trace_layout
 from .lbp import (EdgeGraph, lbp_convexified, lbp_convexified_device, loopy_bp, atanh_saturated as _atanh_saturated,
                   find_clusters as _find_clusters)
 
@@ -96,20 +96,22 @@ class SweepMixin:
         if use_hash_table and hash_table is None:
             raise ValueError("hash_table must be an instance of cachetools.LRUCache")
 
-    def _mcmc_on(self, eng, num_sweeps, m_start, beta_run, record=True, flags=None, temp_x=1.0):
-        """Run `num_sweeps` sweeps of ONE chain on `eng` (n_chains == 1).  Returns the engine's output dict."""
+    def _mcmc_on(self, eng, num_sweeps, m_start, beta_run, record=True, flags=None, temp_x=1.0, record_stride=1):
+        """Run `num_sweeps` sweeps of ONE chain on `eng` (n_chains == 1).  Returns the engine's output dict (configurations
+        after sweeps 0, record_stride, 2 record_stride, ... when `record`)."""
+        rs = int(record_stride) if record else 0
         n = eng.n
         s0 = np.asarray(m_start, dtype=np.float64).reshape(-1)
         eng.set_spins(s0.astype(np.int8)[None, :])
         eng.set_flags(None if flags is None else flags[None, :], temp_x)
         if self.rng == "numpy":
             perm, u = hostlogic.draw_legacy_stream(num_sweeps, n)
-            return eng.sweep_stream(perm[None], u[None], np.asarray(beta_run)[None, :], record_stride=1 if record else 0,
+            return eng.sweep_stream(perm[None], u[None], np.asarray(beta_run)[None, :], record_stride=rs,
                                     want_energy=True, want_min=True, want_state=True)
         # single-chain API calls return energy traces: fp64 fields keep them exact to rounding (the fp32 path is the
         # batched throughput path); very large instances only fit the fp32 layout in LDS
         o = eng.sweep_philox(num_sweeps, self.seed, sweep0=self._sweep_counter, beta=np.asarray(beta_run)[None, :],
-                             precision="f64" if n <= 12000 else "f32", record_stride=1 if record else 0,
+                             precision="f64" if n <= 12000 else "f32", record_stride=rs,
                              want_energy=True, want_min=True, want_state=True)
         self._sweep_counter += num_sweeps
         return o
@@ -156,8 +158,7 @@ class Common(SweepMixin):
         run = hostlogic.beta_schedule(num_sweeps, beta, anneal, sweeps_per_beta, initial_beta)
         eng = self._phase_cache.engine(J, np.asarray(h).reshape(-1), 1)
         o = self._mcmc_on(eng, num_sweeps, m_start, run)
-        M[:, :] = o["spins"][0].T
-        return M
+        return trace_layout(o["spins"], out=M)        # M[:, jj] = state after sweep jj
 
     # ------------------------------------------------------------------------------------------------
     def atanh_saturated(self, x):
@@ -245,11 +246,16 @@ class Common(SweepMixin):
         def phase(kind, m_from):
             nonlocal at, m_init
             fl = hostlogic.phase_flags(N, m_from, all_clusters, kind)
-            o = self._mcmc_on(eng, S, m_from, run, flags=None if kind == "ALL" else fl, temp_x=temp_x)
-            M = o["spins"][0].T.astype(np.float64)
-            en = o["energy"][0]
             w = S // M_skip
-            M_overall[:, at:at + w] = M[:, ::M_skip]       # shape mismatch raises like the reference when S % M_skip
+            strided = M_skip > 0 and S % M_skip == 0 and M_overall.flags["C_CONTIGUOUS"]
+            o = self._mcmc_on(eng, S, m_from, run, flags=None if kind == "ALL" else fl, temp_x=temp_x,
+                              record_stride=M_skip if strided else 1)
+            en = o["energy"][0]
+            if strided:                                    # M[:, ::M_skip] is what the engine recorded: laid out in place
+                trace_layout(o["spins"], dst_col=[at], row_len=M_overall.shape[1], out=M_overall)
+            else:
+                M = o["spins"][0].T.astype(np.float64)
+                M_overall[:, at:at + w] = M[:, ::M_skip]   # shape mismatch raises like the reference when S % M_skip
             energy_overall[at:at + w] = en[::M_skip]
             at += w
             m_init = o["argmin_state"][0].astype(np.float64)

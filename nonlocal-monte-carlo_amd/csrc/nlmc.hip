@@ -1785,22 +1785,25 @@ int nlmc_find_clusters(int n, const int32_t *rowptr, const int32_t *colidx, cons
 }
 
 int nlmc_trace_layout(const int8_t *src, int64_t n_blocks, int64_t n_sweeps, int64_t n, const int32_t *dst_block,
-                      int64_t n_dst_blocks, void *dst, int elem_bytes, int n_threads)
+                      const int32_t *dst_col, int64_t n_dst_blocks, int64_t row_len, void *dst, int elem_bytes, int n_threads)
 {
-    if (n_blocks < 0 || n_sweeps < 0 || n < 1 || (n_blocks * n_sweeps > 0 && (!src || !dst)) || n_dst_blocks < n_blocks)
+    if (n_blocks < 0 || n_sweeps < 0 || n < 1 || (n_blocks * n_sweeps > 0 && (!src || !dst)) || row_len < n_sweeps ||
+        (!dst_block && n_dst_blocks < n_blocks))
         return fail(nullptr, NLMC_ERR_ARG, "nlmc_trace_layout: bad sizes or NULL arrays");
     if (elem_bytes != 1 && elem_bytes != 8) return fail(nullptr, NLMC_ERR_ARG, "nlmc_trace_layout: elem_bytes must be 1 or 8");
-    if (dst_block) {                                 // destination blocks: distinct and in range (threads write disjointly)
-        std::vector<uint8_t> seen((size_t)n_dst_blocks, 0);
+    if ((dst_block || dst_col) && n_sweeps > 0) {    // destinations: in range, whole column groups, distinct (threads write disjointly)
+        const int64_t groups = row_len / n_sweeps;
+        std::vector<uint8_t> seen((size_t)(n_dst_blocks * groups), 0);
         for (int64_t b = 0; b < n_blocks; ++b) {
-            if (dst_block[b] < 0 || dst_block[b] >= n_dst_blocks || seen[dst_block[b]])
-                return fail(nullptr, NLMC_ERR_ARG, "nlmc_trace_layout: dst_block must hold distinct indices < n_dst_blocks");
-            seen[dst_block[b]] = 1;
+            const int64_t r = dst_block ? dst_block[b] : b, c = dst_col ? dst_col[b] : 0;
+            if (r < 0 || r >= n_dst_blocks || c < 0 || c % n_sweeps || c + n_sweeps > row_len || seen[r * groups + c / n_sweeps])
+                return fail(nullptr, NLMC_ERR_ARG, "nlmc_trace_layout: destinations must be distinct (block, column group) pairs in range");
+            seen[r * groups + c / n_sweeps] = 1;
         }
     }
     if (n_threads <= 0) n_threads = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    if (elem_bytes == 8) host_trace_layout<double>(src, n_blocks, n_sweeps, n, dst_block, (double *)dst, n_threads);
-    else host_trace_layout<int8_t>(src, n_blocks, n_sweeps, n, dst_block, (int8_t *)dst, n_threads);
+    if (elem_bytes == 8) host_trace_layout<double>(src, n_blocks, n_sweeps, n, dst_block, dst_col, row_len, (double *)dst, n_threads);
+    else host_trace_layout<int8_t>(src, n_blocks, n_sweeps, n, dst_block, dst_col, row_len, (int8_t *)dst, n_threads);
     return NLMC_OK;
 }
 

@@ -59,39 +59,40 @@ static int host_find_clusters(int n, const int32_t *rowptr, const int32_t *col, 
 }
 
 // Read-out layout of a recorded trace: src [n_blocks][S][N] int8 (what the sweep kernels record, one block per chain)
-// -> dst [dst_block[b]][N][S] (the reference's M block of a replica: rows = spins, columns = sweeps, NPT/npt.py:641),
-// as int8 or as float64.  Split over host threads by (block, spin range): first-touch page faults of a large float64
-// M are the dominant cost of a single-threaded fill.
+// -> dst [n_dst_blocks][N][row_len], block b written to rows of block dst_block[b], columns dst_col[b] .. dst_col[b]+S-1
+// (the reference's M block of a replica: rows = spins, columns = sweeps, NPT/npt.py:641; sub-replica j of APT_ICM in
+// columns j S .., NPT/apt_ICM.py:188,207), as int8 or as float64.  Split over host threads by (block, spin range):
+// first-touch page faults of a large float64 M are the dominant cost of a single-threaded fill.
 #include <thread>
 template <typename T>
-static void host_trace_layout_part(const int8_t *src, int64_t S, int64_t N, const int32_t *dst_block, T *dst, int64_t job0,
-                                   int64_t job1, int64_t tiles_per_block, int64_t tile)
+static void host_trace_layout_part(const int8_t *src, int64_t S, int64_t N, const int32_t *dst_block, const int32_t *dst_col,
+                                   int64_t row_len, T *dst, int64_t job0, int64_t job1, int64_t tiles_per_block, int64_t tile)
 {
     for (int64_t j = job0; j < job1; ++j) {
         const int64_t b = j / tiles_per_block, k0 = (j % tiles_per_block) * tile, k1 = std::min(N, k0 + tile);
         const int8_t *sb = src + b * S * N;
-        T *db = dst + (int64_t)(dst_block ? dst_block[b] : b) * N * S;
+        T *db = dst + (int64_t)(dst_block ? dst_block[b] : b) * N * row_len + (dst_col ? dst_col[b] : 0);
         for (int64_t k = k0; k < k1; ++k) {
-            T *row = db + k * S;
+            T *row = db + k * row_len;
             for (int64_t t = 0; t < S; ++t) row[t] = (T)sb[t * N + k];
         }
     }
 }
 
 template <typename T>
-static void host_trace_layout(const int8_t *src, int64_t n_blocks, int64_t S, int64_t N, const int32_t *dst_block, T *dst,
-                              int n_threads)
+static void host_trace_layout(const int8_t *src, int64_t n_blocks, int64_t S, int64_t N, const int32_t *dst_block,
+                              const int32_t *dst_col, int64_t row_len, T *dst, int n_threads)
 {
     const int64_t tile = 1024, tiles_per_block = (N + tile - 1) / tile, jobs = n_blocks * tiles_per_block;
     int64_t nt = std::max<int64_t>(1, std::min<int64_t>(n_threads, jobs));
     if (n_blocks * S * N < (int64_t)1 << 18) nt = 1;
     if (nt == 1) {
-        host_trace_layout_part<T>(src, S, N, dst_block, dst, 0, jobs, tiles_per_block, tile);
+        host_trace_layout_part<T>(src, S, N, dst_block, dst_col, row_len, dst, 0, jobs, tiles_per_block, tile);
         return;
     }
     std::vector<std::thread> th;
     for (int64_t i = 0; i < nt; ++i)
-        th.emplace_back(host_trace_layout_part<T>, src, S, N, dst_block, dst, jobs * i / nt, jobs * (i + 1) / nt,
-                        tiles_per_block, tile);
+        th.emplace_back(host_trace_layout_part<T>, src, S, N, dst_block, dst_col, row_len, dst, jobs * i / nt,
+                        jobs * (i + 1) / nt, tiles_per_block, tile);
     for (auto &t : th) t.join();
 }

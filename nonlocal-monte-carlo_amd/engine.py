@@ -357,24 +357,33 @@ class Engine:
         return {"orders": a.value, "levels": b.value}
 
 
-def trace_layout(spins, dst_block=None, n_dst_blocks=None, dtype=np.float64, n_threads=0):
-    """Recorded traces [blocks, S, N] int8 -> the reference's M layout [n_dst_blocks * N, S] (`M[r*N:(r+1)*N, :] =
-    MCMC(...)`, NPT/npt.py:641), block b going to rows of block dst_block[b]; int8 or float64; compiled host routine
-    (nlmc_trace_layout), one thread per core."""
+def trace_layout(spins, dst_block=None, n_dst_blocks=None, dtype=np.float64, n_threads=0, dst_col=None, row_len=None,
+                 out=None):
+    """Recorded traces [blocks, S, N] int8 -> the reference's M layout [n_dst_blocks * N, row_len] (`M[r*N:(r+1)*N, :] =
+    MCMC(...)`, NPT/npt.py:641; NPT/apt_ICM.py:207 with a column group per sub-replica): block b goes to the rows of block
+    dst_block[b], columns dst_col[b] .. dst_col[b]+S-1; int8 or float64; compiled host routine (nlmc_trace_layout), one
+    thread per core.  `out`: write into this C-contiguous [n_dst_blocks * N, row_len] array instead of a new one."""
     spins = np.ascontiguousarray(spins, dtype=np.int8)
     B, S, N = spins.shape
     nd = B if n_dst_blocks is None else int(n_dst_blocks)
-    dt = np.dtype(dtype)
+    rl = S if row_len is None else int(row_len)
+    dt = np.dtype(dtype) if out is None else out.dtype
     if dt not in (np.dtype(np.int8), np.dtype(np.float64)):
         raise ValueError("trace_layout: dtype must be int8 or float64")
-    full = dst_block is None and nd == B
-    M = np.empty((nd * N, S), dtype=dt) if full else np.zeros((nd * N, S), dtype=dt)
     db = None if dst_block is None else np.ascontiguousarray(dst_block, dtype=np.int32)
-    if db is not None and db.shape != (B,):
-        raise ValueError("trace_layout: dst_block must have one entry per block")
-    L = _abi.lib()
-    _abi.check(L.nlmc_trace_layout(_abi.ptr(spins), B, S, N, _abi.ptr(db) if db is not None else None, nd, _abi.ptr(M),
-                                   dt.itemsize, int(n_threads)), None)
+    dc = None if dst_col is None else np.ascontiguousarray(dst_col, dtype=np.int32)
+    for x in (db, dc):
+        if x is not None and x.shape != (B,):
+            raise ValueError("trace_layout: dst_block / dst_col must have one entry per block")
+    if out is not None:
+        if out.shape != (nd * N, rl) or not out.flags["C_CONTIGUOUS"] or not out.flags["WRITEABLE"]:
+            raise ValueError("trace_layout: out must be a writeable C-contiguous [n_dst_blocks * N, row_len] array")
+        M = out
+    else:
+        full = B * S == nd * rl                  # distinct destinations (checked by the routine) then cover all of M
+        M = np.empty((nd * N, rl), dtype=dt) if full else np.zeros((nd * N, rl), dtype=dt)
+    _abi.check(_abi.lib().nlmc_trace_layout(_abi.ptr(spins), B, S, N, _abi.ptr(db), _abi.ptr(dc), nd, rl, _abi.ptr(M),
+                                            dt.itemsize, int(n_threads)), None)
     return M
 
 

@@ -85,3 +85,15 @@ def test_trace_layout_host_routine(product, dtype, shape):
         P.engine.trace_layout(spins, np.zeros(B, np.int32), B, dtype=dtype)        # repeated destination block
     with pytest.raises(ValueError):
         P.engine.trace_layout(spins, dtype=np.float32)
+    # column groups (sub-replica j of APT_ICM in columns j S ..): blocks (r, j) from a shuffled source order
+    Rr, Kk = 2, (B + 1) // 2
+    pairs = [(r, j) for j in range(Kk) for r in range(Rr)][:B]
+    order = rng.permutation(B)
+    blk = np.array([pairs[i][0] for i in order], np.int32)
+    col = np.array([pairs[i][1] * S for i in order], np.int32)
+    M = P.engine.trace_layout(spins, blk, Rr, dtype=dtype, dst_col=col, row_len=Kk * S, n_threads=3)
+    assert M.shape == (Rr * N, Kk * S)
+    for b in range(B):
+        assert np.array_equal(M[blk[b] * N:(blk[b] + 1) * N, col[b]:col[b] + S], spins[b].T)
+    with pytest.raises(ValueError):
+        P.engine.trace_layout(spins, blk, Rr, dtype=dtype, dst_col=col + 1, row_len=Kk * S + 1)   # not a whole column group

@@ -401,3 +401,32 @@ def test_npt_philox_restarts_devices_and_trace_kwargs(product):
         go(rng="numpy", num_restarts=2)
     with pytest.raises(ValueError):
         go(num_restarts=3, device_ids=[0, 0, 0, 0, 0])                 # 24 chains do not split over 5 contexts
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k_read", [30, 120, 600])
+def test_apt_icm_device_resident_read_out(product, k_read):
+    """Device-resident APT_ICM (rng="philox", icm_feedback=True): Energy[r] is replica_energy over the first
+    num_sweeps_read_per_swap columns of replica r's block of the returned M (NPT/apt_ICM.py:36-50,290-297), whatever
+    part of the sub-replica column groups that prefix covers; int8 / no-trace variants return the same numbers."""
+    from helpers import make_instance
+    N, R = 200, 4
+    J, h = make_instance(N, seed=31, with_h=True, gaussian=True)
+    betas = np.geomspace(0.3, 2.0, R)
+
+    def go(trace):
+        obj = product.APT_ICM(J.toarray(), h, rng="philox", seed=9)
+        with quiet():
+            M, E = obj.run(betas, R, num_sweeps_MCMC=30, num_sweeps_read=k_read, num_swap_attempts=6, num_swapping_pairs=1,
+                           icm_feedback=True, return_trace=trace)
+        return obj, M, E
+    obj, M, E = go("float64")
+    S, K = 5, obj.num_subreplicas
+    assert M.shape == (R * N, S * K) and M.dtype == np.float64 and set(np.unique(M)) <= {-1.0, 1.0}
+    k = k_read // 6
+    for r in range(R):
+        assert E[r] == obj.replica_energy(M[r * N:(r + 1) * N, :], min(k, S * K))[0]
+    _, M8, E8 = go("int8")
+    assert M8.dtype == np.int8 and np.array_equal(M8, M) and np.array_equal(E8, E)
+    _, Mn, En = go(None)
+    assert Mn is None and np.array_equal(En, E)

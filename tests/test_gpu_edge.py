@@ -165,7 +165,7 @@ def test_energies_of_the_recorded_trace_on_the_device(product, n, fused):
         eng.set_spins(m0)
         if fused:
             assert eng.plan_philox_fused(0, 1, S, 99) == 1
-        o = eng.sweep_philox(S, 99, beta=np.linspace(0.3, 2.0, R), record_stride=1)
+        o = eng.sweep_philox(S, 99, beta=np.repeat(np.linspace(0.3, 2.0, R)[:, None], S, axis=1), record_stride=1)
         for first, k in ((0, S), (0, 2), (3, 3)):
             E = eng.energy_of_recorded(k, first)
             assert E.shape == (R, k)
