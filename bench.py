@@ -7,7 +7,7 @@ With N > 1 and no torch.distributed environment this script starts `python -m to
 bench.py ...` itself as a CHILD process (before anything touches the GPU) and exits with the child's code; launched by
 torch.distributed.run it is one rank per GPU over RCCL.
 
-A "step" is ROUNDS_PER_STEP = 16 replica-exchange rounds of NPT; a round is S_SWAP = 10 heat-bath sweeps of every
+A "step" is ROUNDS_PER_STEP = 64 replica-exchange rounds of NPT; a round is S_SWAP = 10 heat-bath sweeps of every
 replica at its ladder temperature followed by one swap-attempt round.  Workload (SURVEY.md section 8d, config C4 on
 one GPU): synthetic +-J spin glass, N = 10^4 spins, exactly 3N edges (mean degree 6), h = 0; 256 replicas PER GPU on a
 geometric beta ladder 0.05 -> 4 that spans all GPUs (256*N_gpus slots; --strong: 256 replicas in total, 256/N per
@@ -41,7 +41,8 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 N_SPINS = 10_000
 REPLICAS_PER_GPU = 256
 S_SWAP = 10
-ROUNDS_PER_STEP = 16
+ROUNDS_PER_STEP = 64
+EVENT_EVERY = int(os.environ.get("NLMC_BENCH_EVENT_EVERY", "8"))   # HIP events around every 8th sweep-kernel launch of the timed region
 PLAN_CHUNK_ROUNDS = 256      # rounds whose schedules are built together (one workgroup per window: fills the chip)
 BETA_MIN, BETA_MAX = 0.05, 4.0
 INSTANCE_SEED = 20250225
@@ -208,7 +209,7 @@ def main():
                 st.round(S_SWAP)
         tr = steps * ROUNDS_PER_STEP
         st.plan(tr * S_SWAP, tr, chunk_rounds=chunk, lazy=True)     # a fresh, EMPTY planner: nothing is built yet
-        st.eng.timing_reset(True)
+        st.eng.timing_reset(True, every=EVENT_EVERY if precision == "f32" else 1)
         sync()
         t0 = time.perf_counter()
         for _ in range(tr):
@@ -234,7 +235,7 @@ def main():
         dt, tm, tr, count = r["dt"], r["tm"], r["rounds"], r["count"]
         updates = float(G) * N_SPINS * S_SWAP * tr
         upd_launch = float(count) * N_SPINS * S_SWAP
-        ms_launch = tm["ms_sweep"] / max(1, tm["launches_sweep"])
+        ms_launch = tm["ms_sweep"] / max(1, tm["launches_timed"])       # average over the launches that had events
         sec_launch = ms_launch * 1e-3
         achieved = upd_launch * BYTES_PER_UPDATE / sec_launch / 1e9 if ms_launch > 0 else 0.0
         pmc = load_pmc() if (world == 1 and count == REPLICAS_PER_GPU) else {}
@@ -260,10 +261,11 @@ def main():
             "plan_chunks_in_timed_region": r["chunks"],
             "rounds_timed": tr,
             "ms_per_round": dt / tr * 1e3,
-            "value_kernel_loop": (upd_launch * tm["launches_sweep"] / (tm["ms_sweep"] * 1e-3)) * world if tm["ms_sweep"] > 0 else None,
+            "value_kernel_loop": (upd_launch / (ms_launch * 1e-3)) * world if ms_launch > 0 else None,
             "ms_levelize": tm["ms_levelize"],
-            "ms_sweep_kernels": tm["ms_sweep"],
+            "ms_sweep_kernels": ms_launch * tm["launches_sweep"],
             "sweep_launches": tm["launches_sweep"],
+            "sweep_launches_with_events": tm["launches_timed"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc.get("hbm_bytes_per_launch"),
@@ -294,7 +296,7 @@ def main():
                                      "wait_any_frac": pmc.get("wait_any_frac"), "source": pmc.get("source")}
         if world == 1 and not a.no_f64_leg:
             f = run_leg("f64", 1, 0)
-            ms64 = f["tm"]["ms_sweep"] / max(1, f["tm"]["launches_sweep"])
+            ms64 = f["tm"]["ms_sweep"] / max(1, f["tm"]["launches_timed"])
             upd64 = float(f["count"]) * N_SPINS * S_SWAP * f["rounds"]
             out["f64_field"] = {"value": upd64 / f["dt"], "unit": "spin-updates/s", "rounds_timed": f["rounds"],
                                 "dtype": "f64", "bytes_per_update": BYTES_PER_UPDATE_F64,

@@ -224,12 +224,17 @@ int nlmc_find_clusters(int n, const int32_t *rowptr, const int32_t *colidx, cons
 int nlmc_trace_layout(const int8_t *src, int64_t n_blocks, int64_t n_sweeps, int64_t n, const int32_t *dst_block,
                       const int32_t *dst_col, int64_t n_dst_blocks, int64_t row_len, void *dst, int elem_bytes, int n_threads);
 
-/* Timing of the most recent sweep call, measured with HIP events on the context's stream. */
+/* Timing of the most recent sweep call, measured with HIP events on the context's stream -- zero unless event timing
+ * was switched on with nlmc_timing_reset (the plain product path records no events). */
 int nlmc_last_timing(nlmc_ctx *ctx, float *ms_levelize, float *ms_sweep, int32_t *launches_sweep);
-/* Accumulated HIP-event timing of every sweep call since nlmc_timing_reset (one synchronisation, at read time).
- * While accumulation is on, sweep calls do not recycle their events. */
+/* Accumulated HIP-event timing of the sweep calls since nlmc_timing_reset (one synchronisation, at read time).
+ * enable = 0: off; 1: events around every kernel launch; k > 1: around every k-th fused-window launch only (an event
+ * record is a stream command of its own: at one launch per 130 us the two records of a launch are a measurable part of
+ * the gap between launches).  While accumulation is on, sweep calls do not recycle their events.
+ * nlmc_timing_total: ms_sweep = summed duration of the `launches_timed` launches that had events (of `launches_sweep`
+ * launches in all); ms_levelize = summed duration of every schedule construction. */
 int nlmc_timing_reset(nlmc_ctx *ctx, int enable);
-int nlmc_timing_total(nlmc_ctx *ctx, double *ms_levelize, double *ms_sweep, int64_t *launches_sweep);
+int nlmc_timing_total(nlmc_ctx *ctx, double *ms_levelize, double *ms_sweep, int64_t *launches_sweep, int64_t *launches_timed);
 /* Level-schedule statistics of the most recent sweep call: total levels and total spins over its orders. */
 int nlmc_last_schedule_stats(nlmc_ctx *ctx, int64_t *n_orders, int64_t *n_levels);
 

@@ -132,7 +132,7 @@ def lib():
     L.nlmc_timing_reset.restype = _i
     L.nlmc_timing_reset.argtypes = [_vp, _i]
     L.nlmc_timing_total.restype = _i
-    L.nlmc_timing_total.argtypes = [_vp, _vp, _vp, _vp]
+    L.nlmc_timing_total.argtypes = [_vp, _vp, _vp, _vp, _vp]
     L.nlmc_last_schedule_stats.restype = _i
     L.nlmc_last_schedule_stats.argtypes = [_vp, _vp, _vp]
     _lib = L

@@ -43,6 +43,12 @@ struct nlmc_ctx {
     int n_chains = 0, chain_base = 0, n_chains_global = 0;
     int escale = 32;
     bool compact16 = false;            // every Jq fits 16 bits: fused-window schedules use 4-byte entries
+    // diagnostic switches read ONCE, at nlmc_create (NLMC_NO_WARM, NLMC_FUSED_NOPRIO, NLMC_NO_DBUF, NLMC_DBG_FLAGS): not
+    // looked up again on the launch path
+    bool knob_no_warm = false, knob_no_prio = false, knob_no_dbuf = false;
+    int knob_dbg_flags = 0;
+    int ev_every = 1;                  // fused-window launches: events around every ev_every-th one (nlmc_timing_reset)
+    long long launches_timed = 0;      // launches that contributed to the event sums since nlmc_timing_reset
     int qs = 0;                        // field scale of the fixed-point ("f32") path: Jq = rint(J 2^qs)
     double *energy_sink = nullptr;     // device buffer the sweep kernels also write the tracked energies to
     double temp_x = 1.0;
@@ -376,11 +382,18 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
     default: kfun = reinterpret_cast<const void *>(k_sweep_fused<true, true, true>); break;
     }
     { int rc = ensure_lds(c, 8 + variant, kfun, L.total); if (rc) return rc; }
-    hipEvent_t e0 = next_event(c), e1 = next_event(c), e2 = next_event(c);
-    if (!e0 || !e1 || !e2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
-    (void)e1;
-    tag_triple(c, 1);                              // two stream commands per launch instead of three
-    HIP_TRY(c, hipEventRecord(e0, c->stream));
+    // events around the launch (two stream commands) only while timings accumulate (nlmc_timing_reset): every launch or
+    // every ev_every-th one.  An event record costs ~2.5 us of stream time: none on the plain product path.
+    const bool timed = c->ev_accumulate && (c->ev_every <= 1 || c->launches_total % c->ev_every == 0);
+    hipEvent_t e0 = nullptr, e2 = nullptr;
+    if (timed) {
+        e0 = next_event(c);
+        hipEvent_t e1 = next_event(c);
+        e2 = next_event(c);
+        if (!e0 || !e1 || !e2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
+        tag_triple(c, 1);
+        HIP_TRY(c, hipEventRecord(e0, c->stream));
+    }
     SweepArgs a{};
     a.g = c->g;
     a.chain_base = c->chain_base;
@@ -395,16 +408,16 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
     a.fsend = c->fz_send.p + (size_t)w * T;
     a.fz_pstride = c->fz_pstride;
     a.fz_compact = c->fz_compact ? 1 : 0;
-    if (w + 1 < c->fz_windows && c->fz_nlev_host[(size_t)w + 1] > 0 && !getenv("NLMC_NO_WARM")) {
+    if (w + 1 < c->fz_windows && c->fz_nlev_host[(size_t)w + 1] > 0 && !c->knob_no_warm) {
         a.warm_head = c->fz_head.p + (size_t)(w + 1) * PS;
         a.warm_ell = c->fz_ell.p + (size_t)(w + 1) * PS * NLMC_ELL_W32;
         a.fz_npos_next = c->fz_npos_host[(size_t)w + 1];
     }
     a.f_workers = c->fz_workers;
     a.f_gen0 = c->fz_gen0;
-    a.f_gen_prio = getenv("NLMC_FUSED_NOPRIO") ? 0 : 1;
+    a.f_gen_prio = c->knob_no_prio ? 0 : 1;
 #ifdef NLMC_DEBUG_KNOBS
-    if (const char *e = getenv("NLMC_DBG_FLAGS")) a.dbg_flags = atoi(e);
+    a.dbg_flags = c->knob_dbg_flags;
 #endif
     a.n_sweeps = T;
     a.sweep0 = sweep0;
@@ -445,7 +458,7 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
     default: hipLaunchKernelGGL((k_sweep_fused<true, true, true>), dim3(R), dim3(nt), L.total, c->stream, a); break;
     }
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(e2, c->stream));
+    if (timed) { HIP_TRY(c, hipEventRecord(e2, c->stream)); c->launches_timed++; }
     c->launches_sweep++;
     c->launches_total++;
     c->stat_fused_window = w;
@@ -577,7 +590,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
     // second copy of the per-sweep uniforms / level offsets when it fits: lets the idle waves prepare sweep t+1 while
     // wave 0 runs the narrow tail of sweep t
     const bool dbuf = !stream_mode && (size_t)cur + 2 * (size_t)u_bytes + 2 * NLMC_LCAP * 4 + 32 <= (size_t)150 * 1024 &&
-                      !getenv("NLMC_NO_DBUF");
+                      !c->knob_no_dbuf;
     cur += u_bytes * (dbuf ? 2 : 1);
     const int lds_loff_off = cur;
     if (!stream_mode) cur += NLMC_LCAP * 4 * (dbuf ? 2 : 1);
@@ -595,10 +608,13 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         const int w = std::min(W, n_sweeps - t0);
         const nlmc_ctx::Sched &sc = cached ? c->plan : c->scratch;
         size_t o0 = 0;
-        hipEvent_t e0 = next_event(c), e1 = next_event(c), e2 = next_event(c);
-        if (!e0 || !e1 || !e2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
-        tag_triple(c, 0);
-        HIP_TRY(c, hipEventRecord(e0, c->stream));
+        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+        if (c->ev_accumulate) {
+            e0 = next_event(c); e1 = next_event(c); e2 = next_event(c);
+            if (!e0 || !e1 || !e2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
+            tag_triple(c, 0);
+            HIP_TRY(c, hipEventRecord(e0, c->stream));
+        }
         if (cached) {
             o0 = (size_t)(sweep0 - c->plan_sweep0) + t0;
         } else {
@@ -609,7 +625,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
             c->stats_nlev_count = n_orders;
             c->stats_pending = true;
         }
-        HIP_TRY(c, hipEventRecord(e1, c->stream));
+        if (e1) HIP_TRY(c, hipEventRecord(e1, c->stream));
 
         SweepArgs a{};
         a.g = c->g;
@@ -667,7 +683,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         else
             hipLaunchKernelGGL((k_sweep_philox<float, false>), dim3(R), dim3(nt), lds, c->stream, a);
         HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipEventRecord(e2, c->stream));
+        if (e2) { HIP_TRY(c, hipEventRecord(e2, c->stream)); c->launches_timed++; }
         c->launches_sweep++;
         c->launches_total++;
     }
@@ -818,6 +834,10 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
         if (e32[e].q > 32767 || e32[e].q < -32768) fits16 = false;
     }
     c->compact16 = fits16 && !getenv("NLMC_NO_COMPACT");
+    c->knob_no_warm = getenv("NLMC_NO_WARM") != nullptr;
+    c->knob_no_prio = getenv("NLMC_FUSED_NOPRIO") != nullptr;
+    c->knob_no_dbuf = getenv("NLMC_NO_DBUF") != nullptr;
+    if (const char *e = getenv("NLMC_DBG_FLAGS")) c->knob_dbg_flags = atoi(e);
     for (int k = 0; k < n; ++k) hq[k] = (int32_t)rq(h[k], qs);
 
     CT(c->rowptr.reserve((size_t)n + 1));
@@ -1256,15 +1276,17 @@ int nlmc_last_timing(nlmc_ctx *c, float *ms_levelize, float *ms_sweep, int32_t *
 
 int nlmc_timing_reset(nlmc_ctx *c, int enable)
 {
-    if (!c) return NLMC_ERR_ARG;
+    if (!c || enable < 0) return NLMC_ERR_ARG;
     c->ev_used = 0;
     c->ev_call_start = 0;
     c->launches_total = 0;
+    c->launches_timed = 0;
     c->ev_accumulate = enable != 0;
+    c->ev_every = enable > 1 ? enable : 1;
     return NLMC_OK;
 }
 
-int nlmc_timing_total(nlmc_ctx *c, double *ms_levelize, double *ms_sweep, int64_t *launches_sweep)
+int nlmc_timing_total(nlmc_ctx *c, double *ms_levelize, double *ms_sweep, int64_t *launches_sweep, int64_t *launches_timed)
 {
     if (!c) return NLMC_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1278,6 +1300,7 @@ int nlmc_timing_total(nlmc_ctx *c, double *ms_levelize, double *ms_sweep, int64_
     if (ms_levelize) *ms_levelize = lev;
     if (ms_sweep) *ms_sweep = sw;
     if (launches_sweep) *launches_sweep = c->launches_total;
+    if (launches_timed) *launches_timed = c->launches_timed;
     return NLMC_OK;
 }
 

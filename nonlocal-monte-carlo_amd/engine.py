@@ -343,13 +343,15 @@ class Engine:
         self._ck(self._L.nlmc_last_timing(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return {"ms_levelize": a.value, "ms_sweep": b.value, "launches_sweep": c.value}
 
-    def timing_reset(self, enable=True):
-        self._ck(self._L.nlmc_timing_reset(self._ctx, int(bool(enable))))
+    def timing_reset(self, enable=True, every=1):
+        """Accumulate HIP-event timings of the sweep calls from now on (`every` > 1: events around every `every`-th
+        fused-window launch only), or stop accumulating."""
+        self._ck(self._L.nlmc_timing_reset(self._ctx, max(1, int(every)) if enable else 0))
 
     def timing_total(self):
-        a, b, c = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
-        self._ck(self._L.nlmc_timing_total(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
-        return {"ms_levelize": a.value, "ms_sweep": b.value, "launches_sweep": c.value}
+        a, b, c, d = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        self._ck(self._L.nlmc_timing_total(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)))
+        return {"ms_levelize": a.value, "ms_sweep": b.value, "launches_sweep": c.value, "launches_timed": d.value}
 
     def last_schedule_stats(self):
         a, b = ctypes.c_int64(0), ctypes.c_int64(0)

@@ -7,7 +7,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-f64-leg"
+B="python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-f64-leg"
 timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats" -o s -- python3 $REPO/bench.py --no-cpu-baseline > "$OUT/stats.log" 2>&1
 timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o f -- $B > "$OUT/fetch.log" 2>&1
 timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o w -- $B > "$OUT/write.log" 2>&1
