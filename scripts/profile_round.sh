@@ -20,6 +20,6 @@ timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/
 timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c5" -o s -- python3 $REPO/scripts/c5_only.py > "$OUT/c5.log" 2>&1
 cp "$OUT/lbp/s_kernel_stats.csv" "$REPO/profiles/${TAG}_lbp_kernel_stats.csv"
 cp "$OUT/c5/s_kernel_stats.csv" "$REPO/profiles/${TAG}_c5_kernel_stats.csv"
-cp "$REPO"/profiles/${TAG}_* "$OUT"/
+cp "$REPO"/profiles/${TAG}_* "$REPO"/profiles/current_sweep_pmc.json "$OUT"/
 python3 "$REPO/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -1 "$OUT/bench.json"
