@@ -382,6 +382,8 @@ def test_npt_philox_restarts_devices_and_trace_kwargs(product):
         return obj, M, E
     o1, M1, E1 = go()
     assert M1.shape == (R * N, 10) and M1.dtype == np.float64 and o1.swap_pairs.shape == (12, 2)
+    for r in range(R):                       # Energy[r] = replica_energy of replica r's block (NPT/npt.py:685-692)
+        assert E1[r] == o1.replica_energy(M1[r * N:(r + 1) * N, :], 10)[0]
     o2, M2, E2 = go(num_restarts=3)
     assert np.array_equal(M1, M2) and np.array_equal(E1, E2)
     assert o2.restart_energies.shape == (3, R) and np.array_equal(o2.restart_energies[0], E1)
