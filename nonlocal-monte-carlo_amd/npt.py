@@ -19,7 +19,7 @@ import numpy as np
 
 from . import hostlogic
 from .base import Common
-from .engine import Engine, RoundPlanner, trace_layout
+from .engine import Engine, trace_layout
 
 
 class NPT(Common):

@@ -1,5 +1,4 @@
 """Shared test helpers (synthetic instances of SURVEY.md section 8d, fixed-point scale, stream drawing)."""
-import math
 
 import numpy as np
 import scipy.sparse as sp
