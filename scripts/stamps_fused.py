@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from conftest import load_product
 from helpers import make_instance, init_spins
 P = load_product()
-N, R, T, W = 10000, 256, 10, 6
+N, R, T, W = (int(os.environ.get(k, d)) for k, d in (('N', 10000), ('R', 256), ('T', 10), ('W', 6)))
 J, h = make_instance(N)
 eng = P.Engine(J, h, R)
 eng.set_spins(init_spins(R, N)); eng.pt_init(np.geomspace(0.05, 4.0, R))
