@@ -103,6 +103,7 @@ struct nlmc_ctx {
     uint64_t plan_seed = 0;
     // fused-window plan (k_levelize_fused / k_sweep_fused)
     int max_deg = 0;
+    int n_long = 0;                    // rows with more than NLMC_FZ_W entries (two schedule positions in a fused plan)
     int stat_fused_window = -1;          // >= 0: the most recent sweep call ran this fused window
     bool fz_valid = false;
     uint32_t fz_sweep0 = 0;
@@ -304,7 +305,8 @@ int fused_workers(int nt)
     const int waves = nt / 64;
     if (waves < 16) return waves - 1;
     if (const char *s = getenv("NLMC_FUSED_WORKERS")) { const int v = atoi(s); if (v >= 8 && v <= 16) return v; }
-    return 14;
+    return 15;      // (one wave left to pull the next window's schedule towards the chip: 16 workers measured 137 vs 124 us
+                    // per launch when the plans of 256 windows lie cold in HBM)
 }
 
 // LDS of k_sweep_fused: spins (+16: scratch spin of the dummy items) | flags (+16) | 3 threshold tables of n_pad words |
@@ -327,7 +329,9 @@ FusedLds fused_lds(int n, int n_pad, bool has_flags, bool with_out)
     return L;
 }
 
-int fused_pstride(int n, int T) { return (int)((((size_t)T * n + 63) / 64 + NLMC_LCAP) * 64); }
+// schedule positions reserved per window: one per update, two for a row longer than NLMC_FZ_W entries (n_long of them),
+// plus the padding of every level to a chunk boundary
+int fused_pstride(int n, int n_long, int T) { return (int)((((size_t)T * ((size_t)n + n_long) + 63) / 64 + NLMC_LCAP) * 64); }
 
 // first wave that produces thresholds (NLMC_FUSED_GEN0: tuning knob): the trailing half of the workgroup -- the
 // waves that rarely or never hold a chunk
@@ -344,7 +348,7 @@ bool fused_supported(const nlmc_ctx *c, int T)
 {
     if (getenv("NLMC_NO_FUSED")) return false;
     if (c->n < 256 || c->n > NLMC_FZ_SPT * 1024 || c->max_deg > 0x3FFF || T < 3 || T > NLMC_FUSED_TMAX) return false;
-    if ((size_t)T * c->n > ((size_t)1 << 22)) return false;            // 32-bit buffer offsets of the packed planes
+    if ((size_t)T * ((size_t)c->n + c->n_long) > ((size_t)1 << 22)) return false;   // 32-bit buffer offsets of the packed planes
     if (c->n_pad + 16 > 0x3FFF) return false;                          // spin address in 14 bits of the item head
     (void)T;
     const FusedLds L = fused_lds(c->n, c->n_pad, true, false);
@@ -403,14 +407,14 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
     a.lvl_off = c->fz_loff.p + (size_t)w * (NLMC_LCAP + 1);
     a.nlev = c->fz_nlev.p + w;
     a.hi_max = c->fz_himax.p + w;
-    a.ell32 = c->fz_ell.p + (size_t)w * PS * NLMC_ELL_W32;
+    a.ell32 = c->fz_ell.p + (size_t)w * PS * NLMC_FZ_W;
     a.head32 = c->fz_head.p + (size_t)w * PS;
     a.fsend = c->fz_send.p + (size_t)w * T;
     a.fz_pstride = c->fz_pstride;
     a.fz_compact = c->fz_compact ? 1 : 0;
     if (w + 1 < c->fz_windows && c->fz_nlev_host[(size_t)w + 1] > 0 && !c->knob_no_warm) {
         a.warm_head = c->fz_head.p + (size_t)(w + 1) * PS;
-        a.warm_ell = c->fz_ell.p + (size_t)(w + 1) * PS * NLMC_ELL_W32;
+        a.warm_ell = c->fz_ell.p + (size_t)(w + 1) * PS * NLMC_FZ_W;
         a.fz_npos_next = c->fz_npos_host[(size_t)w + 1];
     }
     a.f_workers = c->fz_workers;
@@ -752,10 +756,11 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
     if (n > NLMC_MAX_N) return fail(nullptr, NLMC_ERR_UNSUPPORTED, "nlmc_create: n exceeds NLMC_MAX_N (spins are LDS-resident)");
     if (rowptr[0] != 0 || rowptr[n] != nnz) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: rowptr[0] != 0 or rowptr[n] != nnz");
     bool diag = false, zero_vals = false;
-    int max_deg = 0;
+    int max_deg = 0, n_long = 0;
     for (int k = 0; k < n; ++k) {
         if (rowptr[k + 1] < rowptr[k]) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: rowptr not monotone");
         max_deg = std::max(max_deg, (int)(rowptr[k + 1] - rowptr[k]));
+        n_long += (rowptr[k + 1] - rowptr[k]) > NLMC_FZ_W;
         for (int e = rowptr[k]; e < rowptr[k + 1]; ++e) {
             if (colidx[e] < 0 || colidx[e] >= n) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: column index out of range");
             if (colidx[e] == k && vals[e] != 0.0) diag = true;
@@ -782,6 +787,7 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
     c->has_diag = diag;
     c->has_zero_vals = zero_vals;
     c->max_deg = max_deg;
+    c->n_long = n_long;
 
     // fixed-point scales.  Energies: integers in units of 2^-escale, |E| <= sum|J|/2 + sum|h|.  Couplings of the "f32"
     // throughput path: Jq = rint(J 2^qs), hq = rint(h 2^qs) with qs the largest exponent such that every |Jq| fits a
@@ -1172,11 +1178,11 @@ int nlmc_plan_philox(nlmc_ctx *c, int precision, int order_mode, uint32_t sweep0
 
 static int reserve_fused_plan(nlmc_ctx *c, int n_windows, int T)
 {
-    const size_t W = (size_t)n_windows, TN = (size_t)T * c->n, PS = (size_t)fused_pstride(c->n, T);
+    const size_t W = (size_t)n_windows, TN = (size_t)T * c->n, PS = (size_t)fused_pstride(c->n, c->n_long, T);
     HIP_TRY(c, c->fz_glv.reserve(W * TN));
     HIP_TRY(c, c->fz_perm.reserve(W * PS));
     HIP_TRY(c, c->fz_head.reserve(W * PS));
-    HIP_TRY(c, c->fz_ell.reserve(W * PS * NLMC_ELL_W32));
+    HIP_TRY(c, c->fz_ell.reserve(W * PS * NLMC_FZ_W));
     HIP_TRY(c, c->fz_loff.reserve(W * (NLMC_LCAP + 1)));
     HIP_TRY(c, c->fz_nlev.reserve(W));
     HIP_TRY(c, c->fz_npos.reserve(W));
@@ -1205,7 +1211,7 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     if (n_windows == 0 || !fused_supported(c, window)) return NLMC_OK;
     const int n = c->n, T = window;
     const size_t W = (size_t)n_windows;
-    c->fz_pstride = fused_pstride(n, T);
+    c->fz_pstride = fused_pstride(n, c->n_long, T);
     { int rc = reserve_fused_plan(c, n_windows, T); if (rc) return rc; }
     { int rc = ensure_adjacency(c); if (rc) return rc; }
     FusedLevelizeArgs a{};

@@ -206,6 +206,7 @@ __global__ void k_levelize(LevelizeArgs a)
 // ------------------------------------------------------------------------------------------------------
 #define NLMC_LCAP 1024          // level offsets of one schedule kept in LDS by the sweep kernels
 #define NLMC_FUSED_TMAX 64
+#define NLMC_FZ_W 8              // row entries per schedule position of a fused plan; longer rows take two positions
 struct FusedLevelizeArgs {
     CsrDev g;
     int T;                    // sweeps per window
@@ -220,10 +221,10 @@ struct FusedLevelizeArgs {
     uint32_t *perm;           // scratch [n_windows][pstride]: item id k | t << 16 at its position, ~0 = padding
     long long *stats;         // diagnostic (NLMC_FZ_STATS): [n_windows][8] cycles keys / init / passes, pass count, place 1 / 2
     int2 *head;               // [n_windows][pstride]   { k | LONG << 14 | threshold word << 16, hq_k }
-    EdgeQ *ell;               // [n_windows][8][pstride][2]   row window planes, position-minor
+    EdgeQ *ell;               // [n_windows][NLMC_FZ_W / 2][pstride][2]   row window planes (8 entries per position), position-minor
     int32_t *loff;            // [n_windows][NLMC_LCAP + 1] published level offsets, in chunks of 64 positions
     int32_t *nlev;            // [n_windows] published levels; 0 = deeper than NLMC_LCAP - 1 (caller falls back)
-    int32_t *hi_max;          // [n_windows] leading chunks of a level that may hold rows longer than 8 entries
+    int32_t *hi_max;          // [n_windows] leading chunks of a level that may hold PAIRS (rows longer than 8 entries)
     int32_t *send;            // [n_windows][T] published index of the last level that holds an item of sweep t
     int32_t *npos;            // [n_windows] schedule positions in use (multiple of 64)
 };
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
     uint32_t *hist = reinterpret_cast<uint32_t *>(queue + n4);
     uint32_t *histL = hist + NLMC_LCAP + 2;
     __shared__ int sh_lmax[NLMC_FUSED_TMAX];
-    __shared__ int sh_max, sh_fail, sh_nlev, sh_qn, sh_npos, sh_himax;
+    __shared__ int sh_max, sh_fail, sh_nlev, sh_qn, sh_npos;
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int k = tid; k < n; k += nt) g[k] = 0;
     for (int l = tid; l < 2 * (NLMC_LCAP + 2); l += nt) hist[l] = 0u;      // hist and histL are adjacent
@@ -370,21 +371,24 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
 
     // publish offsets.  Positions are handed out in CHUNKS of 64 (one wave's items of one level): every level starts on
     // a chunk boundary and its last chunk is padded with dummy items, so that the sweep kernel never deals with a
-    // partly filled wave (no per-lane validity: a wave either holds a chunk of a level or it does not).  Levels wider
-    // than level_cap (a multiple of 64) are split.  off[] counts chunks; hist[lv] becomes the level's first position,
-    // histL[lv] (was: its number of long rows) the position behind its last real item.
+    // partly filled wave (no per-lane validity: a wave either holds a chunk of a level or it does not).  A row longer
+    // than NLMC_FZ_W entries takes TWO neighbouring positions (an even / odd lane pair: entries 0-7 and 8-15, the two
+    // partial fields are added with one cross-lane move), so that every wave of a level does the same amount of work;
+    // the pairs come first in their level.  Levels wider than level_cap positions (a multiple of 64) are split.
+    // off[] counts chunks; hist[lv] becomes the level's first position, histL[lv] (was: its number of long rows) the
+    // position behind its last real item.
     if (tid == 0) {
         const int L = sh_lmax[T - 1];
         int32_t *off = a.loff + (size_t)w * (NLMC_LCAP + 1);
         int m = 0, run = 0, t_next = 0, himax = 0;
         if (!sh_fail) {
             for (int lv = 1; lv <= L; ++lv) {
-                const int cnt = (int)hist[lv];
+                const int cl = (int)histL[lv], width = (int)hist[lv] + cl;
                 hist[lv] = (uint32_t)run;
-                himax = max(himax, ((int)histL[lv] + 63) >> 6);
-                histL[lv] = (uint32_t)(run + cnt);
-                for (int p = 0; p < cnt; p += a.level_cap) { if (m < NLMC_LCAP) { off[m] = (run + p) >> 6; mx[m] = (uint32_t)((run + p) >> 6); } ++m; }
-                run += (cnt + 63) & ~63;
+                himax = max(himax, (2 * cl + 63) >> 6);
+                histL[lv] = (uint32_t)(run + width);
+                for (int p = 0; p < width; p += a.level_cap) { if (m < NLMC_LCAP) { off[m] = (run + p) >> 6; mx[m] = (uint32_t)((run + p) >> 6); } ++m; }
+                run += (width + 63) & ~63;
                 while (t_next < T && sh_lmax[t_next] == lv) a.send[(size_t)w * T + t_next++] = m - 1;
             }
             if (m >= NLMC_LCAP || run > a.pstride) sh_fail = 1; else { off[m] = run >> 6; mx[m] = (uint32_t)(run >> 6); }
@@ -394,25 +398,15 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
         a.nlev[w] = sh_nlev;
         a.npos[w] = run;
         a.hi_max[w] = min(himax, a.level_cap >> 6);
-        sh_himax = min(himax, a.level_cap >> 6);
     }
     __syncthreads();
     if (sh_nlev == 0) return;
-    // Which chunks are read with the second half of the row window: the first hi_max chunks of every (sub-)level -- the
-    // waves that take them (k_sweep_fused, role_long) load the upper planes in EVERY level.  Everywhere else those planes
-    // are never read and therefore never written (the placement is bound by its HBM writes).  mx[] (dead by now) holds
-    // the published chunk offsets, the queue's memory the per-chunk flags.
-    uint8_t *lmap = reinterpret_cast<uint8_t *>(queue);
-    for (int i = tid; i < (sh_npos >> 6); i += nt) lmap[i] = 0;
-    __syncthreads();
-    for (int m = tid; m < sh_nlev; m += nt)
-        for (int c = (int)mx[m]; c < min((int)mx[m] + sh_himax, (int)mx[m + 1]); ++c) lmap[c] = 1;
-    __syncthreads();
 
-    // placement: rows longer than 8 entries from the front of their level, the others from the back of its real items.
-    // Two steps so that the 136 B per update are written with coalesced stores: (1) scatter the 4-byte item ids to
-    // their positions, (2) position-major: lane p gathers row k(p) (CSR is cache resident) and writes head[p] and the
-    // planes [q][p] next to its neighbours' -- a direct scatter of 16-byte pieces ran at a tenth of the bandwidth.
+    // placement: the pairs (rows longer than 8 entries) from the front of their level, two positions each, the others
+    // from the back of its real items.  Two steps so that the 40-72 B per position are written with coalesced stores:
+    // (1) scatter the 4-byte item ids to their positions, (2) position-major: lane p gathers its half of row k(p) (CSR is
+    // cache resident) and writes head[p] and the planes [q][p] next to its neighbours' -- a direct scatter of 16-byte
+    // pieces ran at a tenth of the bandwidth.
     const int npos = sh_npos;
     const size_t PS = (size_t)a.pstride;
     long long p0 = (long long)__builtin_readcyclecounter();
@@ -424,61 +418,66 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
         for (int k = tid; k < n; k += nt) {
             const int lv = (int)glv[(size_t)t * n + k];
             const int deg = a.g.rowptr[k + 1] - a.g.rowptr[k];
-            const uint32_t pos = deg > 8 ? atomicAdd(&hist[lv], 1u) : atomicSub(&histL[lv], 1u) - 1u;
-            perm[pos] = (uint32_t)k | ((uint32_t)t << 16);
+            const uint32_t id = (uint32_t)k | ((uint32_t)t << 16);
+            if (deg > NLMC_FZ_W) {
+                const uint32_t pos = atomicAdd(&hist[lv], 2u);                 // even: a level starts on a multiple of 64
+                perm[pos] = id;
+                perm[pos + 1] = id | 0x80000000u;                              // second half of the row
+            } else {
+                perm[atomicSub(&histL[lv], 1u) - 1u] = id;
+            }
         }
     }
     __threadfence_block();
     __syncthreads();
     long long p1 = (long long)__builtin_readcyclecounter();
     st[4] = p1 - p0;
-    // head.x = k | LONG << 14 | thr << 16: k = LDS address of the spin, LONG = row longer than the 16-entry window,
-    // thr = word index of the update's threshold in the three LDS tables (slot t mod 3); head.y = hq_k.
+    // head.x = k | LONG << 14 | PAIR << 15 | thr << 16: k = LDS address of the spin, LONG = row longer than two windows
+    // (the rest is read from the CSR arrays by the first lane of the pair), PAIR = this lane holds half of a row, thr =
+    // word index of the update's threshold in the three LDS tables (slot t mod 3); head.y = hq_k (first half only).
     // A dummy item updates the scratch spin behind the real ones from an all-zero row: harmless by construction.
     int2 *head = a.head + (size_t)w * PS;
-    int4 *ell = reinterpret_cast<int4 *>(a.ell) + (size_t)w * (NLMC_ELL_W32 / 2) * PS;
+    int4 *ell = reinterpret_cast<int4 *>(a.ell) + (size_t)w * (NLMC_FZ_W / 2) * PS;
     for (int pos = tid; pos < npos; pos += nt) {
         const uint32_t it = perm[pos];
         const uint32_t dpack = (uint32_t)a.k_dummy << 16;
-        const bool hi = lmap[pos >> 6] != 0;                       // this chunk is read with its upper planes
         if (it == 0xFFFFFFFFu) {
             // (threshold word 3 tab_words: behind the three tables / snapshot slots, so that a dummy's threshold read and
             // snapshot write touch nothing that belongs to a spin)
             head[pos] = make_int2(a.k_dummy | ((3 * a.tab_words) << 16), 0);
             if (a.compact) {
 #pragma unroll
-                for (int q = 0; q < NLMC_ELL_W32 / 4; ++q)
-                    if (q < 2 || hi) ell[(size_t)q * PS + pos] = make_int4((int)dpack, (int)dpack, (int)dpack, (int)dpack);
+                for (int q = 0; q < NLMC_FZ_W / 4; ++q) ell[(size_t)q * PS + pos] = make_int4((int)dpack, (int)dpack, (int)dpack, (int)dpack);
             } else {
 #pragma unroll
-                for (int q = 0; q < NLMC_ELL_W32; q += 2)
-                    if (q < 8 || hi) ell[(size_t)(q / 2) * PS + pos] = make_int4(a.k_dummy, 0, a.k_dummy, 0);
+                for (int q = 0; q < NLMC_FZ_W; q += 2) ell[(size_t)(q / 2) * PS + pos] = make_int4(a.k_dummy, 0, a.k_dummy, 0);
             }
             continue;
         }
-        const int k = (int)(it & 0xFFFFu), t = (int)(it >> 16);
+        const int second = (int)(it >> 31);
+        const int k = (int)(it & 0xFFFFu), t = (int)((it >> 16) & 0x7FFFu);
         const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
-        head[pos] = make_int2(k | (deg > NLMC_ELL_W32 ? 0x4000 : 0) | (((t % 3) * a.tab_words + k) << 16), a.g.hq[k]);
-        EdgeQ ed[NLMC_ELL_W32];
+        const int thr = ((t % 3) * a.tab_words + k) << 16;
+        head[pos] = second ? make_int2(k | 0x8000 | thr, 0)
+                           : make_int2(k | (deg > 2 * NLMC_FZ_W ? 0x4000 : 0) | (deg > NLMC_FZ_W ? 0x8000 : 0) | thr, a.g.hq[k]);
+        const int e0 = second ? NLMC_FZ_W : 0, left = deg - e0;                 // this lane's entries: e0 .. e0 + 7
+        EdgeQ ed[NLMC_FZ_W];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) ed[q] = a.g.edge32[rs + q];                // unconditional (the array is padded by
-        if (deg > 8) {                                                          // a full window): independent loads
-#pragma unroll
-            for (int q = 8; q < NLMC_ELL_W32; ++q) ed[q] = a.g.edge32[rs + q];
-        }
+        for (int q = 0; q < NLMC_FZ_W; ++q) ed[q] = a.g.edge32[rs + e0 + q];    // unconditional (the array is padded by a
+                                                                                // full window): independent loads
         if (a.compact) {
-            uint32_t pk[NLMC_ELL_W32];
+            uint32_t pk[NLMC_FZ_W];
 #pragma unroll
-            for (int q = 0; q < NLMC_ELL_W32; ++q) pk[q] = q < deg ? ((uint32_t)ed[q].col << 16) | ((uint32_t)ed[q].q & 0xFFFFu) : dpack;
+            for (int q = 0; q < NLMC_FZ_W; ++q) pk[q] = q < left ? ((uint32_t)ed[q].col << 16) | ((uint32_t)ed[q].q & 0xFFFFu) : dpack;
 #pragma unroll
-            for (int q = 0; q < NLMC_ELL_W32; q += 4)
-                if (q < 8 || hi) ell[(size_t)(q / 4) * PS + pos] = make_int4((int)pk[q], (int)pk[q + 1], (int)pk[q + 2], (int)pk[q + 3]);
+            for (int q = 0; q < NLMC_FZ_W; q += 4)
+                ell[(size_t)(q / 4) * PS + pos] = make_int4((int)pk[q], (int)pk[q + 1], (int)pk[q + 2], (int)pk[q + 3]);
         } else {
 #pragma unroll
-            for (int q = 0; q < NLMC_ELL_W32; q += 2) {
+            for (int q = 0; q < NLMC_FZ_W; q += 2) {
                 const EdgeQ z{a.k_dummy, 0};
-                const EdgeQ e0 = q < deg ? ed[q] : z, e1 = q + 1 < deg ? ed[q + 1] : z;
-                if (q < 8 || hi) ell[(size_t)(q / 2) * PS + pos] = make_int4(e0.col, e0.q, e1.col, e1.q);
+                const EdgeQ f0 = q < left ? ed[q] : z, f1 = q + 1 < left ? ed[q + 1] : z;
+                ell[(size_t)(q / 2) * PS + pos] = make_int4(f0.col, f0.q, f1.col, f1.q);
             }
         }
     }
@@ -1249,12 +1248,12 @@ __global__ void k_sweep_philox(SweepArgs a)
 // thresholds (Philox + logit), the waves behind the workers also pull the next window's schedule towards the chip.
 // No per-sweep epilogue: used when the caller wants neither per-sweep energies, nor recorded configurations, nor the
 // running minimum, and beta is constant.
-template <bool COMPACT, bool TAIL> struct FusedItem {
-    // planes of the row window: wide = { col(2q), Jq(2q), col(2q+1), Jq(2q+1) }, 8 entries in 4 planes (16 in 8);
-    // compact = 4 entries of col << 16 | (Jq & 0xFFFF) per plane, 8 entries in 2 planes (16 in 4)
-    static constexpr int NE = TAIL ? NLMC_ELL_W32 : 8;
+template <bool COMPACT> struct FusedItem {
+    // planes of the row window (NLMC_FZ_W = 8 entries per position): wide = { col(2q), Jq(2q), col(2q+1), Jq(2q+1) } in 4
+    // planes; compact = 4 entries of col << 16 | (Jq & 0xFFFF) per plane, 2 planes
+    static constexpr int NE = NLMC_FZ_W;
     static constexpr int NP = COMPACT ? NE / 4 : NE / 2;
-    nlmc_i2 hd;                   // { k | LONG << 14 | threshold word << 16, hq_k }
+    nlmc_i2 hd;                   // { k | LONG << 14 | PAIR << 15 | threshold word << 16, hq_k }
     nlmc_i4 pk[NP];
     __device__ __forceinline__ int word(int i) const { const int p = i >> 2, j = i & 3; return j == 0 ? pk[p].x : j == 1 ? pk[p].y : j == 2 ? pk[p].z : pk[p].w; }
     __device__ __forceinline__ unsigned col(int q) const { return COMPACT ? (unsigned)word(q) >> 16 : (unsigned)word(2 * q); }
@@ -1363,10 +1362,10 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
         a_min = a.emin ? a.argmin[o_c] : 0;
         cqn0 = NLMC_OCQ(1, 0); cqn1 = NLMC_OCQ(1, 1);
     }
-    typedef FusedItem<COMPACT, TAIL> Item;
+    typedef FusedItem<COMPACT> Item;
     constexpr int NP = Item::NP, NE = Item::NE;
     const int plane_bytes = a.fz_pstride * 16;
-    const __amdgpu_buffer_rsrc_t r_ell = __builtin_amdgcn_make_buffer_rsrc(const_cast<EdgeQ *>(a.ell32), 0, (NLMC_ELL_W32 / 2) * plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_ell = __builtin_amdgcn_make_buffer_rsrc(const_cast<EdgeQ *>(a.ell32), 0, (NLMC_FZ_W / 2) * plane_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_head = __builtin_amdgcn_make_buffer_rsrc(const_cast<int2 *>(a.head32), 0, a.fz_pstride * 8, 0x00020000);
     // level offsets in chunks, read with SCALAR loads (uniform index): no VGPR, no VALU, no vector-memory slot
     // (constant address space: the plan is read-only while sweep kernels run, and a uniform index then gives s_load_dword;
@@ -1392,7 +1391,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
     };
     auto update = [&](const Item &it) __attribute__((always_inline)) {
 #ifdef NLMC_DEBUG_KNOBS
-        if (a.dbg_flags & 2) { asm volatile("" :: "v"(it.hd.x), "v"(it.pk[0].x), "v"(it.pk[3].x)); return; }   // timing experiment: loads only
+        if (a.dbg_flags & 2) { asm volatile("" :: "v"(it.hd.x), "v"(it.pk[0].x), "v"(it.pk[Item::NP - 1].x)); return; }   // timing experiment: loads only
 #endif
         const int hx = it.hd.x;
         const unsigned ka = (unsigned)hx & 0x3FFFu;                               // LDS address of the spin
@@ -1400,7 +1399,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
         const int so = (int)*(lds_i8)(uintptr_t)ka;
         unsigned f = 0u;
         if (FLAGS) f = (unsigned)*(lds_u8)(uintptr_t)(ka + (unsigned)a.lds_flags_off);
-        int sj[NLMC_ELL_W32];
+        int sj[NE];
 #pragma unroll
         for (int q = 0; q < NE; ++q) sj[q] = (int)*(lds_i8)(uintptr_t)it.col(q);   // all reads in flight
         int X0 = it.hd.y, X1 = 0, Xd = 0;
@@ -1413,25 +1412,36 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
 #pragma unroll
             for (int q = 0; q < NE; ++q) Xd += (it.col(q) == ka) ? __mul24(it.val(q), sj[q]) : 0;
         }
-        // a row longer than the 16-entry window (such rows sit in the leading chunks of a level: TAIL waves only)
-        if (TAIL && __builtin_amdgcn_ballot_w64((hx & 0x4000) != 0) != 0ull) {
-            if (hx & 0x4000) {
-                const int rs = a.g.rowptr[ka], re = a.g.rowptr[ka + 1];
+        int X = X0 + X1;
+        bool second = false;
+        if (TAIL) {
+            // chunks at the head of a level may hold PAIRS: a row of 9-16 entries on an even / odd lane pair, eight entries
+            // each; both lanes end up with the whole field and take the same decision, the energy counts once.  A row longer
+            // than that: the rest comes from the CSR arrays, in the first lane of the pair.
+            if (__builtin_amdgcn_ballot_w64((hx & 0x4000) != 0) != 0ull) {
+                if (hx & 0x4000) {
+                    const int rs = a.g.rowptr[ka], re = a.g.rowptr[ka + 1];
 #pragma clang loop vectorize(disable) unroll(disable)
-                for (int e = rs + NLMC_ELL_W32; e < re; ++e) {
-                    const EdgeQ t = a.g.edge32[e];
-                    const int pr = __mul24(t.q, (int)*(lds_i8)(uintptr_t)(unsigned)t.col);
-                    X0 += pr;
-                    if (DIAG && (unsigned)t.col == ka) Xd += pr;
+                    for (int e = rs + 2 * NLMC_FZ_W; e < re; ++e) {
+                        const EdgeQ t = a.g.edge32[e];
+                        const int pr = __mul24(t.q, (int)*(lds_i8)(uintptr_t)(unsigned)t.col);
+                        X += pr;
+                        if (DIAG && (unsigned)t.col == ka) Xd += pr;
+                    }
                 }
             }
+            const bool pair = (hx & 0x8000) != 0;
+            const int Xp = __builtin_amdgcn_mov_dpp(X, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]: the neighbour lane
+            X += pair ? Xp : 0;
+            if (DIAG) { const int Xdp = __builtin_amdgcn_mov_dpp(Xd, 0xB1, 0xF, 0xF, true); Xd += pair ? Xdp : 0; }
+            second = pair && (lane & 1);
         }
-        const int X = X0 + X1;
         if (!OUT) {
             const float z = ((FLAGS && f == 1u) ? cq1 : cq0) * (float)X;
             int sn = (z < wk) ? 1 : -1;
             if (FLAGS) sn = (f >= 2u) ? so : sn;                                    // frozen: unchanged
-            e_loc += (long long)(DIAG ? X - Xd : X) * (long long)((so - sn) << a.eshift);
+            const int cv = (TAIL && second) ? 0 : (so - sn) << a.eshift;
+            e_loc += (long long)(DIAG ? X - Xd : X) * (long long)cv;
             *(lds_i8w)(uintptr_t)ka = (int8_t)sn;
         } else {
             const unsigned tw = (unsigned)hx >> 16;                                 // threshold word = slot * n_pad + k
@@ -1440,7 +1450,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             const float z = ((FLAGS && f == 1u) ? cqb : cqa) * (float)X;
             int sn = (z < wk) ? 1 : -1;
             if (FLAGS) sn = (f >= 2u) ? so : sn;
-            const int cv = (so - sn) << a.eshift, cvo = is_old ? cv : 0;
+            const int cv = (TAIL && second) ? 0 : (so - sn) << a.eshift, cvo = is_old ? cv : 0;
             const long long Xt = (long long)(DIAG ? X - Xd : X);
             e_loc += Xt * (long long)cvo;                                           // e_loc: the older sweep's deltas
             e_new += Xt * (long long)(cv - cvo);
@@ -1496,41 +1506,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
 #ifdef NLMC_STAMPS
     long long sw0, sw1, sw2, st_work = 0, st_bar = 0, st_calls = 0;
 #endif
-    if constexpr (TAIL && !COMPACT) {
-        // 16-entry rows with 8-byte entries: two register sets of 34 are what the register file allows (depth 1)
-        Item A, B;
-        int q0 = lo(0), q1 = lo(1), q2 = lo(2), q3 = lo(3);
-        bool hasA = q0 + wv < q1, hasB;
-        issue(A, q0 + wv, hasA);
-        for (int l = 0; l < nl; l += 2) {
-            const int q4 = lo(l + 4), q5 = lo(l + 5);
-            NLMC_FW0
-            hasB = (l + 1 < nl) && (q1 + wv < q2);             // level l from A; level l+1 into B
-            if (GEN) NLMC_GEN(a, gp, l)
-            if (hasA) { update(A); NLMC_FCALL }
-            issue(B, q1 + wv, hasB NLMC_DBG_NOLOAD);
-            const bool end0 = OUT && l == o_end;
-            if (end0) NLMC_OUT_PRE
-            NLMC_FW1
-            __syncthreads();
-            NLMC_FW2
-            if (end0) NLMC_OUT_POST
-            if (l + 1 < nl) {
-                NLMC_FW0
-                hasA = (l + 2 < nl) && (q2 + wv < q3);
-                if (GEN) NLMC_GEN(a, gp, l + 1)
-                if (hasB) { update(B); NLMC_FCALL }
-                issue(A, q2 + wv, hasA NLMC_DBG_NOLOAD);
-                const bool end1 = OUT && l + 1 == o_end;
-                if (end1) NLMC_OUT_PRE
-                NLMC_FW1
-                __syncthreads();
-                NLMC_FW2
-                if (end1) NLMC_OUT_POST
-            }
-            q0 = q2; q1 = q3; q2 = q4; q3 = q5;
-        }
-    } else {
+    {
         Item I0, I1, I2;
         int r0 = lo(0), r1 = lo(1), r2 = lo(2), r3 = lo(3), r4 = lo(4), r5 = lo(5);    // offsets of levels l .. l+5
         bool h0 = r0 + wv < r1, h1 = (1 < nl) && (r1 + wv < r2), h2;
