@@ -1592,7 +1592,10 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
     __syncthreads();
 
     const int g0 = a.f_gen0 * 64, nblk = (n + 3) / 4, gnt = nt - g0;
-    const FusedGenParams gp{gc, tid - g0, gnt, nblk, (nblk + gnt - 1) / gnt, Tn};
+    // calls per sweep of THIS wave: block b = (tid - g0) + call * gnt must lie below nblk for at least one of its lanes
+    // (wave-uniform; the waves at the end of the producing range do one call less when gnt does not divide nblk)
+    const int gwave0 = __builtin_amdgcn_readfirstlane((tid - g0) & ~63);
+    const FusedGenParams gp{gc, tid - g0, gnt, nblk, max(0, (nblk - gwave0 + gnt - 1) / gnt), Tn};
     const bool is_gen = tid >= g0;
     // The producing waves are the youngest of their SIMDs and would get the issue slots the older worker waves leave
     // over (measured: a 150-instruction call stretched to ~3000 cycles while the workers waited at the barrier).
