@@ -54,7 +54,8 @@ L2_PEAK_GBS = 34500.0        # MI355X_MICROARCH.md, L2 (per XCD): ~34.5 TB/s agg
 VALU_LANES_PER_CU_CLK = 128  # 4 SIMD-32 per CU, one wave64 instruction per 2 cycles per SIMD (MI355X_MICROARCH.md)
 CLOCK_GHZ = 2.4
 N_CUS = 256
-SCHEDULE_BYTES_PER_UPDATE = 40   # what the sweep kernel streams per update from L2: item head 8 B + 8 x 4 B row entries
+SCHEDULE_BYTES_PER_POSITION = 40 # what the sweep kernel streams per schedule position from L2: item head 8 B + 8 x 4 B row
+                                 # entries; a row longer than 8 entries takes two positions (an even / odd lane pair)
 
 
 def load_pmc():
@@ -175,6 +176,8 @@ def main():
 
     J, h = make_instance(N_SPINS, seed=INSTANCE_SEED)
     inst = P.Instance(J, h)
+    positions_per_update = 1.0 + float(np.count_nonzero(np.diff(J.indptr) > 8)) / N_SPINS
+    sched_bytes = SCHEDULE_BYTES_PER_POSITION * positions_per_update
     G = REPLICAS_PER_GPU if a.strong else REPLICAS_PER_GPU * world
     if G % world:
         raise SystemExit(f"{G} replicas do not split evenly over {world} ranks")
@@ -279,9 +282,9 @@ def main():
                                  "roofline_issue below (DESIGN.md section 5)"},
             # every workgroup (= chain = CU) streams the whole window schedule through its L1 from its XCD's L2
             "roofline_l2": {"bound": "l2", "unit": "GB/s", "peak": L2_PEAK_GBS,
-                            "achieved": upd_launch * SCHEDULE_BYTES_PER_UPDATE / sec_launch / 1e9 if ms_launch > 0 else 0.0,
-                            "frac": upd_launch * SCHEDULE_BYTES_PER_UPDATE / sec_launch / 1e9 / L2_PEAK_GBS if ms_launch > 0 else 0.0,
-                            "bytes_per_update": SCHEDULE_BYTES_PER_UPDATE},
+                            "achieved": upd_launch * sched_bytes / sec_launch / 1e9 if ms_launch > 0 else 0.0,
+                            "frac": upd_launch * sched_bytes / sec_launch / 1e9 / L2_PEAK_GBS if ms_launch > 0 else 0.0,
+                            "bytes_per_update": sched_bytes, "schedule_positions_per_update": positions_per_update},
             "levels_per_sweep": r["sched"]["levels"] / max(1, r["sched"]["orders"]),
             "min_energy": {"start": float(r["e_start"].min()), "end": float(r["e_end"].min())},
         }
@@ -292,6 +295,7 @@ def main():
                                      "peak": N_CUS * VALU_LANES_PER_CU_CLK * CLOCK_GHZ * 1e9,
                                      "achieved": lane_insts / sec_launch, "frac": t_issue / sec_launch,
                                      "valu_lane_insts_per_update": lane_insts / upd_launch,
+                                     "valu_lane_insts_per_schedule_position": lane_insts / upd_launch / positions_per_update,
                                      "lds_bank_conflict_frac": pmc.get("lds_bank_conflict_frac"),
                                      "wait_any_frac": pmc.get("wait_any_frac"), "source": pmc.get("source")}
         if world == 1 and not a.no_f64_leg:
