@@ -1242,7 +1242,7 @@ __global__ void k_sweep_philox(SweepArgs a)
 // The level loop is the hot loop of the whole path and is written for instruction count: a level is a list of CHUNKS
 // of 64 items (padded with dummy items), wave w of the f_workers worker waves takes chunk w of the level if there is
 // one -- no per-lane validity, no divergent branches; the chunk's position rides in the scalar offset of the buffer
-// loads (one 8-byte head + 4 or 8 16-byte planes, fully coalesced, issued one level ahead into ping-pong registers);
+// loads (one 8-byte head + 2 or 4 16-byte planes, fully coalesced, issued two levels ahead into rotating registers);
 // the update is straight-line: 10 LDS reads, 8 multiply-adds on the int32 field, one compare with the prepared
 // threshold, one 64-bit multiply-add for the energy, one LDS write, one s_barrier.  Waves [f_gen0, nt/64) produce the
 // thresholds (Philox + logit), the waves behind the workers also pull the next window's schedule towards the chip.
@@ -1339,7 +1339,7 @@ struct FusedGenParams { uint32_t gc; int gtid, gnt, nblk, nj, Tn; };
 // when a sweep ends its sum is reduced over the workgroup (one LDS atomic per wave, read after the level's barrier):
 // that gives E after every sweep, the strict running minimum (first argmin, like np.argmin) and, from the snapshot,
 // the argmin / recorded states -- NMC/nmc.py:386-395 -- without giving up the overlap of consecutive sweeps.
-template <bool DIAG, bool FLAGS, bool TAIL, bool GEN, bool COMPACT, bool OUT = false>
+template <bool DIAG, bool FLAGS, bool PAIR, bool GEN, bool COMPACT, bool OUT = false>
 __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *lds_raw, int wv, int lane, int nl, float cq0,
                                              float cq1, long long &e_loc, const FusedGenParams gp)
 {
@@ -1414,7 +1414,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
         }
         int X = X0 + X1;
         bool second = false;
-        if (TAIL) {
+        if (PAIR) {
             // chunks at the head of a level may hold PAIRS: a row of 9-16 entries on an even / odd lane pair, eight entries
             // each; both lanes end up with the whole field and take the same decision, the energy counts once.  A row longer
             // than that: the rest comes from the CSR arrays, in the first lane of the pair.
@@ -1440,7 +1440,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             const float z = ((FLAGS && f == 1u) ? cq1 : cq0) * (float)X;
             int sn = (z < wk) ? 1 : -1;
             if (FLAGS) sn = (f >= 2u) ? so : sn;                                    // frozen: unchanged
-            const int cv = (TAIL && second) ? 0 : (so - sn) << a.eshift;
+            const int cv = (PAIR && second) ? 0 : (so - sn) << a.eshift;
             e_loc += (long long)(DIAG ? X - Xd : X) * (long long)cv;
             *(lds_i8w)(uintptr_t)ka = (int8_t)sn;
         } else {
@@ -1450,7 +1450,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             const float z = ((FLAGS && f == 1u) ? cqb : cqa) * (float)X;
             int sn = (z < wk) ? 1 : -1;
             if (FLAGS) sn = (f >= 2u) ? so : sn;
-            const int cv = (TAIL && second) ? 0 : (so - sn) << a.eshift, cvo = is_old ? cv : 0;
+            const int cv = (PAIR && second) ? 0 : (so - sn) << a.eshift, cvo = is_old ? cv : 0;
             const long long Xt = (long long)(DIAG ? X - Xd : X);
             e_loc += Xt * (long long)cvo;                                           // e_loc: the older sweep's deltas
             e_new += Xt * (long long)(cv - cvo);
@@ -1602,7 +1602,7 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
     if (is_gen && a.f_gen_prio) __builtin_amdgcn_s_setprio(2);
     long long e_loc = 0;
     if (wv < a.f_workers) {
-        const bool role_long = wv < a.hi_max[0];           // chunks that may hold rows longer than 8 entries come first
+        const bool role_long = wv < a.hi_max[0];           // chunks that may hold lane PAIRS (rows longer than 8 entries) come first
         const int variant = (role_long ? 4 : 0) + (is_gen ? 2 : 0) + (a.fz_compact ? 1 : 0);
         switch (variant) {
         case 0: fused_levels<DIAG, FLAGS, false, false, false, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
