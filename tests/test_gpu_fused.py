@@ -205,3 +205,54 @@ def test_fused_windows_with_per_sweep_outputs_equal_the_sweep_by_sweep_kernel(pr
     for k in ("min_energy", "argmin", "argmin_state"):
         assert np.array_equal(a2[k], b2[k]), k
     assert np.array_equal(sa, sb) and np.array_equal(ea, eb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weights", ["pmj", "gauss"])
+def test_fused_lane_pairs_when_most_rows_are_long(product, weights):
+    """Rows longer than 8 entries take an even / odd lane PAIR of the schedule (entries 0-7 / 8-15), rows longer than 16
+    read the rest from the CSR arrays: a graph where most rows are long (mean degree 12, hubs of 17 ... 70 neighbours,
+    a few spins without any), 4-byte (+-J) and 8-byte (Gaussian) schedule entries -- fused windows, with and without
+    per-sweep outputs, against the sweep-by-sweep kernel and the sequential oracle, bit for bit."""
+    N, R, T, W = 1500, 3, 5, 2
+    rng = np.random.default_rng(77)
+    i = rng.integers(20, N, size=6 * N); j = rng.integers(20, N, size=6 * N)
+    hubs = [(1, 17), (2, 24), (3, 33), (4, 70)]
+    for hub, d in hubs:
+        nb = rng.choice(np.arange(20, N), d, replace=False)
+        i = np.concatenate([i, np.full(d, hub)]); j = np.concatenate([j, nb])
+    keep = i != j
+    A = sp.coo_matrix((np.ones(keep.sum()), (i[keep], j[keep])), shape=(N, N)).tocsr()
+    A = ((A + A.T) > 0).astype(np.float64).tocsr()
+    A = sp.triu(A, 1).tocsr()
+    w = rng.choice([-1.0, 1.0], size=A.nnz) if weights == "pmj" else rng.normal(0, 1, A.nnz) / 4.0
+    A.data = w
+    A = (A + A.T).tocsr(); A.sort_indices()
+    deg = np.diff(A.indptr)
+    assert (deg > 8).mean() > 0.6 and deg.max() >= 70 and (deg == 0).sum() > 0 and ((deg > 16) & (deg <= 33)).sum() >= 3
+    hv = rng.normal(0, 0.2, N) if weights == "gauss" else np.zeros(N)
+    inst = product.Instance(A, hv)
+    betas = np.geomspace(0.2, 1.5, R)
+    a = run_windows(product, inst, R, T, W, betas, True)
+    b = run_windows(product, inst, R, T, W, betas, False)
+    assert a[3] == W
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    csr = oracle.Csr(A)
+    m0 = init_spins(R, N)
+    for c in range(R):
+        cb = np.tile(np.array(oracle.cb_pair(betas[c], 1.0, False)), (T * W, 1))
+        M, s_fin, tr = oracle.sweeps_philox(csr, hv, m0[c], cb, SEED, c, escale=a[5], use_f64=False,
+                                            efix0=int(np.rint(oracle.energy(csr, hv, m0[c]) * 2.0 ** a[5])))
+        assert np.array_equal(a[0][c], s_fin)
+    # per-sweep outputs on the same windows (energy trace, running minimum, recorded states)
+    with product.Engine(inst, None, R) as eng:
+        eng.set_spins(m0); eng.pt_init(betas)
+        assert eng.plan_philox_fused(0, W, T, SEED) == W
+        o = eng.sweep_philox(T * W, SEED, sweep0=0, beta=None, record_stride=1, want_energy=True, want_min=True, want_state=True)
+        assert eng.last_schedule_stats()["orders"] == T          # fused windows were used
+        assert np.array_equal(o["spins"][:, -1], a[0])
+        E = eng.energy_of(o["spins"].reshape(-1, N)).reshape(R, T * W)
+        tol = 2.0 ** -(eng.field_scale + 1) * (A.nnz / 2 + N) + 1e-9 * np.abs(E).max()      # DESIGN.md section 2: stated tolerance
+        assert np.abs(o["energy"] - E).max() <= tol
+        k = np.argmin(o["energy"], axis=1)
+        assert np.array_equal(o["argmin"], k) and np.array_equal(o["argmin_state"], o["spins"][np.arange(R), k])
