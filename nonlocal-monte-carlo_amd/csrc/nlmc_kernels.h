@@ -569,7 +569,8 @@ struct SweepArgs {
     int fz_compact;           // 4-byte schedule entries (col << 16 | Jq & 0xFFFF), see FusedItem
     int lds_send_off;
     int lds_snap_off;         // k_sweep_fused<.., OUT>: three snapshot slots of n_pad bytes
-    int dbg_flags;            // -DNLMC_DEBUG_KNOBS builds only (NLMC_DBG_FLAGS): 1 = no threshold production, 2 = no updates, 4 = no item loads
+    int dbg_flags;            // -DNLMC_DEBUG_KNOBS builds only (NLMC_DBG_FLAGS): 1 = no threshold production, 2 = no updates, 4 = no item loads,
+                              // 512 / 1024 = bank-conflict-free addresses for the neighbour gather / the spin's own accesses (wrong results)
 };
 
 // ---- pieces shared by the two sweep kernels ------------------------------------------------------------
@@ -1394,14 +1395,27 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
         if (a.dbg_flags & 2) { asm volatile("" :: "v"(it.hd.x), "v"(it.pk[0].x), "v"(it.pk[Item::NP - 1].x)); return; }   // timing experiment: loads only
 #endif
         const int hx = it.hd.x;
+#ifdef NLMC_DEBUG_KNOBS
+        const unsigned ka = (a.dbg_flags & 1024) ? (unsigned)((lane & 31) * 4 + (lane >> 5)) : (unsigned)hx & 0x3FFFu;
+        const float wk = *(lds_f32)(uintptr_t)(((a.dbg_flags & 1024) ? (unsigned)(lane * 4) : (((unsigned)hx >> 16) << 2)) + (unsigned)a.lds_u_off);
+#else
         const unsigned ka = (unsigned)hx & 0x3FFFu;                               // LDS address of the spin
         const float wk = *(lds_f32)(uintptr_t)((((unsigned)hx >> 16) << 2) + (unsigned)a.lds_u_off);
+#endif
         const int so = (int)*(lds_i8)(uintptr_t)ka;
         unsigned f = 0u;
         if (FLAGS) f = (unsigned)*(lds_u8)(uintptr_t)(ka + (unsigned)a.lds_flags_off);
         int sj[NE];
+#ifdef NLMC_DEBUG_KNOBS
+        if (a.dbg_flags & 512) {                     // timing experiment: conflict-free gathers (wrong results)
 #pragma unroll
-        for (int q = 0; q < NE; ++q) sj[q] = (int)*(lds_i8)(uintptr_t)it.col(q);   // all reads in flight
+            for (int q = 0; q < NE; ++q) sj[q] = (int)*(lds_i8)(uintptr_t)(unsigned)((lane & 31) * 4 + q * 132 + (lane >> 5));
+        } else
+#endif
+        {
+#pragma unroll
+            for (int q = 0; q < NE; ++q) sj[q] = (int)*(lds_i8)(uintptr_t)it.col(q);   // all reads in flight
+        }
         int X0 = it.hd.y, X1 = 0, Xd = 0;
 #pragma unroll
         for (int q = 0; q < NE; q += 2) {
