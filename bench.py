@@ -54,8 +54,9 @@ L2_PEAK_GBS = 34500.0        # MI355X_MICROARCH.md, L2 (per XCD): ~34.5 TB/s agg
 VALU_LANES_PER_CU_CLK = 128  # 4 SIMD-32 per CU, one wave64 instruction per 2 cycles per SIMD (MI355X_MICROARCH.md)
 CLOCK_GHZ = 2.4
 N_CUS = 256
-SCHEDULE_BYTES_PER_POSITION = 40 # what the sweep kernel streams per schedule position from L2: item head 8 B + 8 x 4 B row
-                                 # entries; a row longer than 8 entries takes two positions (an even / odd lane pair)
+SCHEDULE_BYTES_PER_POSITION = 24 # what the sweep kernel streams per schedule position from L2: item head 8 B + 8 x 2 B row
+                                 # entries (the sign format of +-J instances; 8 x 4 B = 40 B with 16-bit couplings); a row
+                                 # longer than 8 entries takes two positions (an even / odd lane pair)
 
 
 def load_pmc():
@@ -177,6 +178,7 @@ def main():
     J, h = make_instance(N_SPINS, seed=INSTANCE_SEED)
     inst = P.Instance(J, h)
     positions_per_update = 1.0 + float(np.count_nonzero(np.diff(J.indptr) > 8)) / N_SPINS
+    assert np.all(np.abs(J.data) == 1.0)                   # the bench instance is +-J: 2-byte schedule entries
     sched_bytes = SCHEDULE_BYTES_PER_POSITION * positions_per_update
     G = REPLICAS_PER_GPU if a.strong else REPLICAS_PER_GPU * world
     if G % world:

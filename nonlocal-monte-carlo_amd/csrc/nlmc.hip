@@ -43,6 +43,7 @@ struct nlmc_ctx {
     int n_chains = 0, chain_base = 0, n_chains_global = 0;
     int escale = 32;
     bool compact16 = false;            // every Jq fits 16 bits: fused-window schedules use 4-byte entries
+    bool sign8 = false;                // every Jq is +-1: fused-window schedules may use 2-byte entries (NLMC_FMT_ADDR)
     // diagnostic switches read ONCE, at nlmc_create (NLMC_NO_WARM, NLMC_FUSED_NOPRIO, NLMC_NO_DBUF, NLMC_DBG_FLAGS): not
     // looked up again on the launch path
     bool knob_no_warm = false, knob_no_prio = false, knob_no_dbuf = false;
@@ -111,7 +112,7 @@ struct nlmc_ctx {
     uint64_t fz_seed = 0;
     std::vector<int32_t> fz_nlev_host, fz_npos_host;
     int fz_pstride = 0, fz_gen0 = 0;
-    bool fz_compact = false;          // the current fused plan was written with 4-byte entries
+    int fz_fmt = 0;                   // entry format of the current fused plan (NLMC_FMT_*)
     DevBuf<int32_t> fz_npos;
     DevBuf<uint16_t> fz_glv;
     DevBuf<uint32_t> fz_perm;
@@ -309,15 +310,17 @@ int fused_workers(int nt)
                     // per launch when the plans of 256 windows lie cold in HBM)
 }
 
-// LDS of k_sweep_fused: spins (+16: scratch spin of the dummy items) | flags (+16) | 3 threshold tables of n_pad words |
-// (per-sweep outputs only) 3 snapshot slots of n_pad bytes | reduction scratch
-struct FusedLds { int flags_off, u_off, u_bytes, snap_off, red_off; size_t total; };
-FusedLds fused_lds(int n, int n_pad, bool has_flags, bool with_out)
+// LDS of k_sweep_fused: spins (+16: scratch spin of the dummy items, zero bytes) | (address format) negated spins (+16) |
+// flags (+16) | 3 threshold tables of n_pad words | (per-sweep outputs only) 3 snapshot slots of n_pad bytes | reduction
+// scratch
+struct FusedLds { int neg_off, flags_off, u_off, u_bytes, snap_off, red_off; size_t total; };
+FusedLds fused_lds(int n, int n_pad, bool has_flags, bool with_out, bool with_neg)
 {
     (void)n;
     FusedLds L{};
-    L.flags_off = n_pad + 16;
-    int cur = (n_pad + 16) * (has_flags ? 2 : 1);
+    L.neg_off = with_neg ? n_pad + 16 : 0;
+    L.flags_off = (n_pad + 16) * (with_neg ? 2 : 1);
+    int cur = L.flags_off + (has_flags ? n_pad + 16 : 0);
     cur = (cur + 15) / 16 * 16;
     L.u_off = cur;
     L.u_bytes = n_pad * 4;               // threshold word of (slot, k) = slot * n_pad + k = its snapshot byte, too
@@ -327,6 +330,13 @@ FusedLds fused_lds(int n, int n_pad, bool has_flags, bool with_out)
     L.red_off = cur;
     L.total = (size_t)cur + 32;
     return L;
+}
+
+// the address format needs the negated copy of the spins next to everything else (flags counted in: they may be switched
+// on after planning)
+bool fused_addr_format(const nlmc_ctx *c)
+{
+    return c->sign8 && 2 * (c->n_pad + 16) <= 0xFFFF && fused_lds(c->n, c->n_pad, true, false, true).total <= (size_t)150 * 1024;
 }
 
 // schedule positions reserved per window: one per update, two for a row longer than NLMC_FZ_W entries (n_long of them),
@@ -351,7 +361,7 @@ bool fused_supported(const nlmc_ctx *c, int T)
     if ((size_t)T * ((size_t)c->n + c->n_long) > ((size_t)1 << 22)) return false;   // 32-bit buffer offsets of the packed planes
     if (c->n_pad + 16 > 0x3FFF) return false;                          // spin address in 14 bits of the item head
     (void)T;
-    const FusedLds L = fused_lds(c->n, c->n_pad, true, false);
+    const FusedLds L = fused_lds(c->n, c->n_pad, true, false, false);
     if (3 * L.u_bytes / 4 > 0xFFFF) return false;                      // threshold word index in 16 bits
     return L.total <= (size_t)150 * 1024;
 }
@@ -372,7 +382,7 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
 {
     const int R = c->n_chains, n = c->n, T = c->fz_T;
     const size_t PS = (size_t)c->fz_pstride;
-    const FusedLds L = fused_lds(c->n, c->n_pad, c->has_flags, outs);
+    const FusedLds L = fused_lds(c->n, c->n_pad, c->has_flags, outs, c->fz_fmt == NLMC_FMT_ADDR);
     const int variant = (outs ? 4 : 0) + (c->has_diag ? 2 : 0) + (c->has_flags ? 1 : 0);
     const void *kfun = nullptr;
     switch (variant) {
@@ -411,7 +421,7 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
     a.head32 = c->fz_head.p + (size_t)w * PS;
     a.fsend = c->fz_send.p + (size_t)w * T;
     a.fz_pstride = c->fz_pstride;
-    a.fz_compact = c->fz_compact ? 1 : 0;
+    a.fz_fmt = c->fz_fmt;
     if (w + 1 < c->fz_windows && c->fz_nlev_host[(size_t)w + 1] > 0 && !c->knob_no_warm) {
         a.warm_head = c->fz_head.p + (size_t)(w + 1) * PS;
         a.warm_ell = c->fz_ell.p + (size_t)(w + 1) * PS * NLMC_FZ_W;
@@ -443,6 +453,7 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
         a.emin = want_min ? c->emin.p : nullptr;
         a.best = (want_min && want_state) ? c->best.p : nullptr;
     }
+    a.lds_neg_off = L.neg_off;
     a.lds_flags_off = L.flags_off; a.lds_u_off = L.u_off; a.lds_u_stride = L.u_bytes; a.lds_red_off = L.red_off;
     a.lds_snap_off = L.snap_off;
 #ifdef NLMC_STAMPS
@@ -542,7 +553,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         if (all_ok && !any_out && tab_ss == 0 && nw == 1)
             return run_fused(c, w0, sweep0, seed, tab_dev, tab_cs, 0, use_slots, false, false, false, false, 0, 0, n_sweeps);
         if (all_ok && (any_out || tab_ss != 0) && !getenv("NLMC_NO_FUSED_OUT") &&
-            fused_lds(c->n, c->n_pad, c->has_flags, true).total <= (size_t)150 * 1024)
+            fused_lds(c->n, c->n_pad, c->has_flags, true, c->fz_fmt == NLMC_FMT_ADDR).total <= (size_t)150 * 1024)
             fused_out = true;
     }
     if (o.out_energy) HIP_TRY(c, c->etrace.reserve((size_t)R * n_sweeps));
@@ -835,11 +846,14 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
     std::vector<EdgeQ> e32((size_t)std::max<int64_t>(nnz, 1));
     std::vector<int32_t> hq((size_t)n);
     bool fits16 = n <= 65535;        // compact schedule entries of the fused windows: col << 16 | (Jq & 0xFFFF)
+    bool pm1 = true;                 // sign format: col | (Jq < 0) << 15
     for (int64_t e = 0; e < nnz; ++e) {
         e32[e].col = colidx[e]; e32[e].q = (int32_t)rq(vals[e], qs);
         if (e32[e].q > 32767 || e32[e].q < -32768) fits16 = false;
+        if (e32[e].q != 1 && e32[e].q != -1) pm1 = false;
     }
     c->compact16 = fits16 && !getenv("NLMC_NO_COMPACT");
+    c->sign8 = c->compact16 && pm1 && nnz > 0 && !getenv("NLMC_NO_SIGNFMT");
     c->knob_no_warm = getenv("NLMC_NO_WARM") != nullptr;
     c->knob_no_prio = getenv("NLMC_FUSED_NOPRIO") != nullptr;
     c->knob_no_dbuf = getenv("NLMC_NO_DBUF") != nullptr;
@@ -1224,8 +1238,10 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     a.pstride = c->fz_pstride;
     a.tab_words = c->n_pad;
     a.k_dummy = c->n_pad;
-    a.compact = c->compact16 ? 1 : 0;
-    c->fz_compact = c->compact16;
+    a.fmt = fused_addr_format(c) ? NLMC_FMT_ADDR : c->compact16 ? NLMC_FMT_COMPACT : NLMC_FMT_WIDE;
+    a.k_zero = c->n_pad + 8;
+    a.neg_off = c->n_pad + 16;
+    c->fz_fmt = a.fmt;
     a.adj = reinterpret_cast<const uint4 *>(c->fz_adj.p); a.glv = c->fz_glv.p; a.perm = c->fz_perm.p; a.head = c->fz_head.p; a.ell = c->fz_ell.p; a.loff = c->fz_loff.p; a.nlev = c->fz_nlev.p;
     a.hi_max = c->fz_himax.p; a.send = c->fz_send.p; a.npos = c->fz_npos.p;
     const size_t n4 = ((size_t)n + 3) & ~(size_t)3;

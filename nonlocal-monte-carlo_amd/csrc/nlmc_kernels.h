@@ -207,6 +207,9 @@ __global__ void k_levelize(LevelizeArgs a)
 #define NLMC_LCAP 1024          // level offsets of one schedule kept in LDS by the sweep kernels
 #define NLMC_FUSED_TMAX 64
 #define NLMC_FZ_W 8              // row entries per schedule position of a fused plan; longer rows take two positions
+#define NLMC_FMT_WIDE 0
+#define NLMC_FMT_COMPACT 1
+#define NLMC_FMT_ADDR 2
 struct FusedLevelizeArgs {
     CsrDev g;
     int T;                    // sweeps per window
@@ -215,7 +218,9 @@ struct FusedLevelizeArgs {
     int pstride;              // schedule positions reserved per window (multiple of 64, >= T n + 64 NLMC_LCAP)
     int tab_words;            // 4-byte words per threshold table of k_sweep_fused (its LDS stride / 4)
     int k_dummy;              // LDS address of the scratch spin that dummy (padding) items update: n_pad
-    int compact;              // every Jq fits 16 bits: planes hold 4 entries of 4 bytes, col << 16 | (Jq & 0xFFFF)
+    int fmt;                  // entry format of the planes: NLMC_FMT_WIDE / _COMPACT / _SIGN (see FusedItem)
+    int k_zero;               // address format: LDS address of a byte that is always 0 (padding entries point at it)
+    int neg_off;              // address format: LDS offset of the negated copy of the spins
     const uint4 *adj;         // [n][2]: the first 16 neighbours of every spin as 16-bit indices (k_fused_adjacency)
     uint16_t *glv;            // scratch [n_windows][T][n]: level of update (t, k), 1-based
     uint32_t *perm;           // scratch [n_windows][pstride]: item id k | t << 16 at its position, ~0 = padding
@@ -445,7 +450,10 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
             // (threshold word 3 tab_words: behind the three tables / snapshot slots, so that a dummy's threshold read and
             // snapshot write touch nothing that belongs to a spin)
             head[pos] = make_int2(a.k_dummy | ((3 * a.tab_words) << 16), 0);
-            if (a.compact) {
+            if (a.fmt == NLMC_FMT_ADDR) {
+                const int z2 = a.k_zero | (a.k_zero << 16);
+                ell[pos] = make_int4(z2, z2, z2, z2);
+            } else if (a.fmt == NLMC_FMT_COMPACT) {
 #pragma unroll
                 for (int q = 0; q < NLMC_FZ_W / 4; ++q) ell[(size_t)q * PS + pos] = make_int4((int)dpack, (int)dpack, (int)dpack, (int)dpack);
             } else {
@@ -458,14 +466,27 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
         const int k = (int)(it & 0xFFFFu), t = (int)((it >> 16) & 0x7FFFu);
         const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
         const int thr = ((t % 3) * a.tab_words + k) << 16;
-        head[pos] = second ? make_int2(k | 0x8000 | thr, 0)
-                           : make_int2(k | (deg > 2 * NLMC_FZ_W ? 0x4000 : 0) | (deg > NLMC_FZ_W ? 0x8000 : 0) | thr, a.g.hq[k]);
         const int e0 = second ? NLMC_FZ_W : 0, left = deg - e0;                 // this lane's entries: e0 .. e0 + 7
         EdgeQ ed[NLMC_FZ_W];
 #pragma unroll
         for (int q = 0; q < NLMC_FZ_W; ++q) ed[q] = a.g.edge32[rs + e0 + q];    // unconditional (the array is padded by a
                                                                                 // full window): independent loads
-        if (a.compact) {
+        const int hy = second ? 0 : a.g.hq[k];
+        if (a.fmt == NLMC_FMT_ADDR) {
+            // 16-bit LDS addresses: s_j for Jq = +1, the negated copy for Jq = -1, the zero byte for padding
+            uint32_t pk[NLMC_FZ_W / 2];
+#pragma unroll
+            for (int q = 0; q < NLMC_FZ_W; q += 2) {
+                const uint32_t lo = q < left ? (uint32_t)(ed[q].col + (ed[q].q < 0 ? a.neg_off : 0)) : (uint32_t)a.k_zero;
+                const uint32_t hi = q + 1 < left ? (uint32_t)(ed[q + 1].col + (ed[q + 1].q < 0 ? a.neg_off : 0)) : (uint32_t)a.k_zero;
+                pk[q / 2] = lo | (hi << 16);
+            }
+            ell[pos] = make_int4((int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]);
+        }
+        head[pos] = second ? make_int2(k | 0x8000 | thr, hy)
+                           : make_int2(k | (deg > 2 * NLMC_FZ_W ? 0x4000 : 0) | (deg > NLMC_FZ_W ? 0x8000 : 0) | thr, hy);
+        if (a.fmt == NLMC_FMT_ADDR) continue;
+        if (a.fmt == NLMC_FMT_COMPACT) {
             uint32_t pk[NLMC_FZ_W];
 #pragma unroll
             for (int q = 0; q < NLMC_FZ_W; ++q) pk[q] = q < left ? ((uint32_t)ed[q].col << 16) | ((uint32_t)ed[q].q & 0xFFFFu) : dpack;
@@ -566,7 +587,8 @@ struct SweepArgs {
     int f_gen0;               // first wave that produces thresholds (waves [f_gen0, nt/64) share that work)
     int fz_pstride;           // schedule positions reserved per window (plane stride of ell32, length of head32)
     int fz_npos_next;         // positions the NEXT window actually uses (for the warm-up touches)
-    int fz_compact;           // 4-byte schedule entries (col << 16 | Jq & 0xFFFF), see FusedItem
+    int fz_fmt;               // entry format of the plan: NLMC_FMT_WIDE / _COMPACT / _ADDR, see FusedItem
+    int lds_neg_off;          // NLMC_FMT_ADDR: LDS offset of the negated copy of the spins (n_pad + 16); 0: none
     int lds_send_off;
     int lds_snap_off;         // k_sweep_fused<.., OUT>: three snapshot slots of n_pad bytes
     int dbg_flags;            // -DNLMC_DEBUG_KNOBS builds only (NLMC_DBG_FLAGS): 1 = no threshold production, 2 = no updates, 4 = no item loads,
@@ -1249,16 +1271,33 @@ __global__ void k_sweep_philox(SweepArgs a)
 // thresholds (Philox + logit), the waves behind the workers also pull the next window's schedule towards the chip.
 // No per-sweep epilogue: used when the caller wants neither per-sweep energies, nor recorded configurations, nor the
 // running minimum, and beta is constant.
-template <bool COMPACT> struct FusedItem {
-    // planes of the row window (NLMC_FZ_W = 8 entries per position): wide = { col(2q), Jq(2q), col(2q+1), Jq(2q+1) } in 4
-    // planes; compact = 4 entries of col << 16 | (Jq & 0xFFFF) per plane, 2 planes
+// Schedule entry formats of a fused plan (8 row entries per position):
+//   NLMC_FMT_WIDE    { col, Jq } 8 bytes per entry, 4 planes of 16 B   (any couplings)
+//   NLMC_FMT_COMPACT col << 16 | (Jq & 0xFFFF), 2 planes               (every |Jq| < 2^15)
+//   NLMC_FMT_ADDR    a 16-bit LDS ADDRESS per entry, 1 plane           (every Jq = +-1): the workgroup keeps a negated copy of
+//                    its spins behind the spins; an entry with Jq = +1 holds the address of s_j, one with Jq = -1 the
+//                    address of -s_j, a padding entry the address of a byte that is always 0 -- the local field is the plain
+//                    sum of the gathered bytes (no unpacking, no multiply), every update writes s and -s.
+// The vector-memory path of the CU is what a level's loads queue on (24 instead of 40 bytes per position measured 9 %
+// off the launch), and the update of the address format is 11 instructions shorter.
+template <int FMT> struct FusedItem {
     static constexpr int NE = NLMC_FZ_W;
-    static constexpr int NP = COMPACT ? NE / 4 : NE / 2;
-    nlmc_i2 hd;                   // { k | LONG << 14 | PAIR << 15 | threshold word << 16, hq_k }
+    static constexpr int NP = FMT == NLMC_FMT_WIDE ? NE / 2 : FMT == NLMC_FMT_COMPACT ? NE / 4 : NE / 8;
+    nlmc_i2 hd;                   // { k | LONG << 14 | PAIR << 15 | threshold word << 16, hq_k (+ sign-format constant) }
     nlmc_i4 pk[NP];
     __device__ __forceinline__ int word(int i) const { const int p = i >> 2, j = i & 3; return j == 0 ? pk[p].x : j == 1 ? pk[p].y : j == 2 ? pk[p].z : pk[p].w; }
-    __device__ __forceinline__ unsigned col(int q) const { return COMPACT ? (unsigned)word(q) >> 16 : (unsigned)word(2 * q); }
-    __device__ __forceinline__ int val(int q) const { return COMPACT ? (int)(short)(word(q) & 0xFFFF) : word(2 * q + 1); }
+    // LDS address of the byte entry q gathers (wide / compact: the neighbour's spin)
+    __device__ __forceinline__ unsigned col(int q) const
+    {
+        if (FMT == NLMC_FMT_WIDE) return (unsigned)word(2 * q);
+        if (FMT == NLMC_FMT_COMPACT) return (unsigned)word(q) >> 16;
+        return (q & 1) ? (unsigned)word(q >> 1) >> 16 : (unsigned)word(q >> 1) & 0xFFFFu;
+    }
+    __device__ __forceinline__ int val(int q) const       // (wide / compact only)
+    {
+        if (FMT == NLMC_FMT_WIDE) return word(2 * q + 1);
+        return (int)(short)(word(q) & 0xFFFF);
+    }
 };
 
 __device__ __forceinline__ float4 thresholds4(const u32x4 &r)
@@ -1340,7 +1379,7 @@ struct FusedGenParams { uint32_t gc; int gtid, gnt, nblk, nj, Tn; };
 // when a sweep ends its sum is reduced over the workgroup (one LDS atomic per wave, read after the level's barrier):
 // that gives E after every sweep, the strict running minimum (first argmin, like np.argmin) and, from the snapshot,
 // the argmin / recorded states -- NMC/nmc.py:386-395 -- without giving up the overlap of consecutive sweeps.
-template <bool DIAG, bool FLAGS, bool PAIR, bool GEN, bool COMPACT, bool OUT = false>
+template <bool DIAG, bool FLAGS, bool PAIR, bool GEN, int FMT, bool OUT = false>
 __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *lds_raw, int wv, int lane, int nl, float cq0,
                                              float cq1, long long &e_loc, const FusedGenParams gp)
 {
@@ -1363,7 +1402,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
         a_min = a.emin ? a.argmin[o_c] : 0;
         cqn0 = NLMC_OCQ(1, 0); cqn1 = NLMC_OCQ(1, 1);
     }
-    typedef FusedItem<COMPACT> Item;
+    typedef FusedItem<FMT> Item;
     constexpr int NP = Item::NP, NE = Item::NE;
     const int plane_bytes = a.fz_pstride * 16;
     const __amdgpu_buffer_rsrc_t r_ell = __builtin_amdgcn_make_buffer_rsrc(const_cast<EdgeQ *>(a.ell32), 0, (NLMC_FZ_W / 2) * plane_bytes, 0x00020000);
@@ -1419,12 +1458,20 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
         int X0 = it.hd.y, X1 = 0, Xd = 0;
 #pragma unroll
         for (int q = 0; q < NE; q += 2) {
-            X0 += __mul24(it.val(q), sj[q]);
-            X1 += __mul24(it.val(q + 1), sj[q + 1]);
+            if (FMT == NLMC_FMT_ADDR) {             // the gathered byte is Jq s already
+                X0 += sj[q];
+                X1 += sj[q + 1];
+            } else {
+                X0 += __mul24(it.val(q), sj[q]);
+                X1 += __mul24(it.val(q + 1), sj[q + 1]);
+            }
         }
         if (DIAG) {
 #pragma unroll
-            for (int q = 0; q < NE; ++q) Xd += (it.col(q) == ka) ? __mul24(it.val(q), sj[q]) : 0;
+            for (int q = 0; q < NE; ++q) {
+                if (FMT == NLMC_FMT_ADDR) Xd += (it.col(q) == ka || it.col(q) == ka + (unsigned)a.lds_neg_off) ? sj[q] : 0;
+                else Xd += (it.col(q) == ka) ? __mul24(it.val(q), sj[q]) : 0;
+            }
         }
         int X = X0 + X1;
         bool second = false;
@@ -1457,6 +1504,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             const int cv = (PAIR && second) ? 0 : (so - sn) << a.eshift;
             e_loc += (long long)(DIAG ? X - Xd : X) * (long long)cv;
             *(lds_i8w)(uintptr_t)ka = (int8_t)sn;
+            if (FMT == NLMC_FMT_ADDR) *(lds_i8w)(uintptr_t)(ka + (unsigned)a.lds_neg_off) = (int8_t)-sn;
         } else {
             const unsigned tw = (unsigned)hx >> 16;                                 // threshold word = slot * n_pad + k
             const bool is_old = tw - o_lo < (unsigned)o_npad;
@@ -1469,6 +1517,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             e_loc += Xt * (long long)cvo;                                           // e_loc: the older sweep's deltas
             e_new += Xt * (long long)(cv - cvo);
             *(lds_i8w)(uintptr_t)ka = (int8_t)sn;
+            if (FMT == NLMC_FMT_ADDR) *(lds_i8w)(uintptr_t)(ka + (unsigned)a.lds_neg_off) = (int8_t)-sn;
             *(lds_i8w)(uintptr_t)(tw + (unsigned)a.lds_snap_off) = (int8_t)sn;      // snapshot slot of the update's sweep
         }
     };
@@ -1590,7 +1639,15 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
         const int4 *src = reinterpret_cast<const int4 *>(a.spins + (size_t)c * n_pad);
         int4 *dst = reinterpret_cast<int4 *>(lds_raw);
         for (int i = tid; i < n_pad / 16; i += nt) dst[i] = src[i];
-        if (tid < 4) reinterpret_cast<int *>(lds_raw + n_pad)[tid] = 0x01010101;
+        if (tid < 4) reinterpret_cast<int *>(lds_raw + n_pad)[tid] = tid < 2 ? 0x01010101 : 0;   // dummy spin | zero bytes (padding entries)
+        if (a.lds_neg_off) {                                       // address format: -s behind s (0x01 <-> 0xFF)
+            int4 *ndst = reinterpret_cast<int4 *>(lds_raw + a.lds_neg_off);
+            for (int i = tid; i < n_pad / 16; i += nt) {
+                const int4 v = src[i];
+                ndst[i] = make_int4(v.x ^ (int)0xFEFEFEFE, v.y ^ (int)0xFEFEFEFE, v.z ^ (int)0xFEFEFEFE, v.w ^ (int)0xFEFEFEFE);
+            }
+            if (tid < 4) reinterpret_cast<int *>(lds_raw + a.lds_neg_off + n_pad)[tid] = (int)0xFFFFFFFF;
+        }
         if (FLAGS) {
             const int4 *fsrc = reinterpret_cast<const int4 *>(a.flags + (size_t)c * n_pad);
             int4 *fdst = reinterpret_cast<int4 *>(lds_raw + a.lds_flags_off);
@@ -1617,17 +1674,15 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
     long long e_loc = 0;
     if (wv < a.f_workers) {
         const bool role_long = wv < a.hi_max[0];           // chunks that may hold lane PAIRS (rows longer than 8 entries) come first
-        const int variant = (role_long ? 4 : 0) + (is_gen ? 2 : 0) + (a.fz_compact ? 1 : 0);
-        switch (variant) {
-        case 0: fused_levels<DIAG, FLAGS, false, false, false, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
-        case 1: fused_levels<DIAG, FLAGS, false, false, true, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
-        case 2: fused_levels<DIAG, FLAGS, false, true, false, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
-        case 3: fused_levels<DIAG, FLAGS, false, true, true, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
-        case 4: fused_levels<DIAG, FLAGS, true, false, false, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
-        case 5: fused_levels<DIAG, FLAGS, true, false, true, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
-        case 6: fused_levels<DIAG, FLAGS, true, true, false, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
-        default: fused_levels<DIAG, FLAGS, true, true, true, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp); break;
-        }
+        const int variant = (role_long ? 2 : 0) + (is_gen ? 1 : 0);
+#define NLMC_FL(P, G, F) fused_levels<DIAG, FLAGS, P, G, F, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp)
+#define NLMC_FL4(F) switch (variant) { case 0: NLMC_FL(false, false, F); break; case 1: NLMC_FL(false, true, F); break; \
+                                       case 2: NLMC_FL(true, false, F); break; default: NLMC_FL(true, true, F); break; }
+        if (a.fz_fmt == NLMC_FMT_ADDR) NLMC_FL4(NLMC_FMT_ADDR)
+        else if (a.fz_fmt == NLMC_FMT_COMPACT) NLMC_FL4(NLMC_FMT_COMPACT)
+        else NLMC_FL4(NLMC_FMT_WIDE)
+#undef NLMC_FL4
+#undef NLMC_FL
     } else {
         // Waves without schedule items: their share of the thresholds, and they pull the NEXT window's schedule towards
         // the chip.  A window's schedule (72 B per update actually touched) is read once per launch and sits in HBM
@@ -1641,7 +1696,7 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
         const unsigned warm_lines = a.warm_head ? (unsigned)(((size_t)a.fz_npos_next * 8 + 127) / 128) : 0u;       // head
         const unsigned warm_lines_p = a.warm_head ? (unsigned)(((size_t)a.fz_pstride * 16 + 127) / 128) : 0u;     // lines per plane
         const unsigned warm_used_p = a.warm_head ? (unsigned)(((size_t)a.fz_npos_next * 16 + 127) / 128) : 0u;     // touched lines per plane
-        const unsigned warm_total = warm_lines + (a.fz_compact ? 2u : 4u) * warm_used_p;
+        const unsigned warm_total = warm_lines + (a.fz_fmt == NLMC_FMT_ADDR ? 1u : a.fz_fmt == NLMC_FMT_COMPACT ? 2u : 4u) * warm_used_p;
         unsigned warm_at = (unsigned)c * (unsigned)hcnt + (unsigned)hid;
         const unsigned warm_step = gridDim.x * (unsigned)hcnt;
         // four touches in flight (a touch of a cold line takes longer than a level: waiting for the previous one every
