@@ -208,11 +208,12 @@ def test_fused_windows_with_per_sweep_outputs_equal_the_sweep_by_sweep_kernel(pr
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("weights", ["pmj", "gauss"])
+@pytest.mark.parametrize("weights", ["pmj", "int3", "gauss"])
 def test_fused_lane_pairs_when_most_rows_are_long(product, weights):
     """Rows longer than 8 entries take an even / odd lane PAIR of the schedule (entries 0-7 / 8-15), rows longer than 16
     read the rest from the CSR arrays: a graph where most rows are long (mean degree 12, hubs of 17 ... 70 neighbours,
-    a few spins without any), 4-byte (+-J) and 8-byte (Gaussian) schedule entries -- fused windows, with and without
+    a few spins without any), all three schedule entry formats -- 16-bit LDS addresses (+-J with integer fields h),
+    4-byte entries (couplings in +-{1,2,3}), 8-byte entries (Gaussian) -- fused windows, with and without
     per-sweep outputs, against the sweep-by-sweep kernel and the sequential oracle, bit for bit."""
     N, R, T, W = 1500, 3, 5, 2
     rng = np.random.default_rng(77)
@@ -225,12 +226,17 @@ def test_fused_lane_pairs_when_most_rows_are_long(product, weights):
     A = sp.coo_matrix((np.ones(keep.sum()), (i[keep], j[keep])), shape=(N, N)).tocsr()
     A = ((A + A.T) > 0).astype(np.float64).tocsr()
     A = sp.triu(A, 1).tocsr()
-    w = rng.choice([-1.0, 1.0], size=A.nnz) if weights == "pmj" else rng.normal(0, 1, A.nnz) / 4.0
+    w = {"pmj": lambda: rng.choice([-1.0, 1.0], size=A.nnz), "int3": lambda: rng.choice([-3.0, -2.0, -1.0, 1.0, 2.0, 3.0], size=A.nnz),
+         "gauss": lambda: rng.normal(0, 1, A.nnz) / 4.0}[weights]()
     A.data = w
-    A = (A + A.T).tocsr(); A.sort_indices()
+    A = (A + A.T).tolil()
+    if weights == "pmj":                          # a few self-couplings: the DIAG kernel on the address format
+        for k in rng.choice(np.arange(20, N), 60, replace=False):
+            A[k, k] = rng.choice([-1.0, 1.0])
+    A = A.tocsr(); A.sort_indices()
     deg = np.diff(A.indptr)
     assert (deg > 8).mean() > 0.6 and deg.max() >= 70 and (deg == 0).sum() > 0 and ((deg > 16) & (deg <= 33)).sum() >= 3
-    hv = rng.normal(0, 0.2, N) if weights == "gauss" else np.zeros(N)
+    hv = rng.normal(0, 0.2, N) if weights == "gauss" else rng.integers(-1, 2, N).astype(np.float64)
     inst = product.Instance(A, hv)
     betas = np.geomspace(0.2, 1.5, R)
     a = run_windows(product, inst, R, T, W, betas, True)
