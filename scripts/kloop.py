@@ -1,5 +1,6 @@
 """Kernel-loop timing of the fused-window sweep kernel on the bench workload (N = 10^4, 256 chains, 10 sweeps per
-launch): us per launch by HIP events.  Knobs: NLMC_LIB (variant build), NLMC_FUSED_WORKERS, W (windows), N, R, T."""
+launch): us per launch by HIP events.  Knobs: NLMC_LIB (variant build), NLMC_FUSED_WORKERS, W (windows), N, R, T,
+GAUSS=1 (Gaussian couplings: 8-byte schedule entries), INT3=1 (couplings in +-{1,2,3}: 4-byte entries)."""
 import os, sys
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,7 +9,9 @@ from conftest import load_product
 from helpers import make_instance, init_spins
 P = load_product()
 N, R, T, W = (int(os.environ.get(k, d)) for k, d in (("N", 10000), ("R", 256), ("T", 10), ("W", 40)))
-J, h = make_instance(N)
+J, h = make_instance(N, gaussian=bool(int(os.environ.get("GAUSS", "0"))))
+if os.environ.get("INT3"):                       # couplings in +-{1,2,3}: the 4-byte entry format
+    J = J.copy(); J.data = J.data * (1 + (np.arange(J.nnz) % 3)); J = ((J + J.T) / 2).tocsr(); J.data = np.sign(J.data) * np.ceil(np.abs(J.data))
 inst = P.Instance(J, h)
 with P.Engine(inst, None, R) as eng:
     eng.set_spins(init_spins(R, N)); eng.pt_init(np.geomspace(0.05, 4.0, R))
