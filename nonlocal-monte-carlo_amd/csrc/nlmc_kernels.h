@@ -1403,6 +1403,11 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
         cqn0 = NLMC_OCQ(1, 0); cqn1 = NLMC_OCQ(1, 1);
     }
     typedef FusedItem<FMT> Item;
+    // launch constants of the update kept in VECTOR registers (there are spare ones; the scalar file is what spills here:
+    // every spilled scalar is re-read with a v_readlane in every level)
+    unsigned v_u_off = (unsigned)a.lds_u_off, v_neg_off = (unsigned)a.lds_neg_off;
+    int v_eshift = a.eshift;
+    asm volatile("" : "+v"(v_u_off), "+v"(v_neg_off), "+v"(v_eshift));
     constexpr int NP = Item::NP, NE = Item::NE;
     const int plane_bytes = a.fz_pstride * 16;
     const __amdgpu_buffer_rsrc_t r_ell = __builtin_amdgcn_make_buffer_rsrc(const_cast<EdgeQ *>(a.ell32), 0, (NLMC_FZ_W / 2) * plane_bytes, 0x00020000);
@@ -1439,7 +1444,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
         const float wk = *(lds_f32)(uintptr_t)(((a.dbg_flags & 1024) ? (unsigned)(lane * 4) : (((unsigned)hx >> 16) << 2)) + (unsigned)a.lds_u_off);
 #else
         const unsigned ka = (unsigned)hx & 0x3FFFu;                               // LDS address of the spin
-        const float wk = *(lds_f32)(uintptr_t)((((unsigned)hx >> 16) << 2) + (unsigned)a.lds_u_off);
+        const float wk = *(lds_f32)(uintptr_t)((((unsigned)hx >> 16) << 2) + v_u_off);
 #endif
         const int so = (int)*(lds_i8)(uintptr_t)ka;
         unsigned f = 0u;
@@ -1469,7 +1474,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
         if (DIAG) {
 #pragma unroll
             for (int q = 0; q < NE; ++q) {
-                if (FMT == NLMC_FMT_ADDR) Xd += (it.col(q) == ka || it.col(q) == ka + (unsigned)a.lds_neg_off) ? sj[q] : 0;
+                if (FMT == NLMC_FMT_ADDR) Xd += (it.col(q) == ka || it.col(q) == ka + v_neg_off) ? sj[q] : 0;
                 else Xd += (it.col(q) == ka) ? __mul24(it.val(q), sj[q]) : 0;
             }
         }
@@ -1501,10 +1506,10 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             const float z = ((FLAGS && f == 1u) ? cq1 : cq0) * (float)X;
             int sn = (z < wk) ? 1 : -1;
             if (FLAGS) sn = (f >= 2u) ? so : sn;                                    // frozen: unchanged
-            const int cv = (PAIR && second) ? 0 : (so - sn) << a.eshift;
+            const int cv = (PAIR && second) ? 0 : (so - sn) << v_eshift;
             e_loc += (long long)(DIAG ? X - Xd : X) * (long long)cv;
             *(lds_i8w)(uintptr_t)ka = (int8_t)sn;
-            if (FMT == NLMC_FMT_ADDR) *(lds_i8w)(uintptr_t)(ka + (unsigned)a.lds_neg_off) = (int8_t)-sn;
+            if (FMT == NLMC_FMT_ADDR) *(lds_i8w)(uintptr_t)(ka + v_neg_off) = (int8_t)-sn;
         } else {
             const unsigned tw = (unsigned)hx >> 16;                                 // threshold word = slot * n_pad + k
             const bool is_old = tw - o_lo < (unsigned)o_npad;
@@ -1512,12 +1517,12 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             const float z = ((FLAGS && f == 1u) ? cqb : cqa) * (float)X;
             int sn = (z < wk) ? 1 : -1;
             if (FLAGS) sn = (f >= 2u) ? so : sn;
-            const int cv = (PAIR && second) ? 0 : (so - sn) << a.eshift, cvo = is_old ? cv : 0;
+            const int cv = (PAIR && second) ? 0 : (so - sn) << v_eshift, cvo = is_old ? cv : 0;
             const long long Xt = (long long)(DIAG ? X - Xd : X);
             e_loc += Xt * (long long)cvo;                                           // e_loc: the older sweep's deltas
             e_new += Xt * (long long)(cv - cvo);
             *(lds_i8w)(uintptr_t)ka = (int8_t)sn;
-            if (FMT == NLMC_FMT_ADDR) *(lds_i8w)(uintptr_t)(ka + (unsigned)a.lds_neg_off) = (int8_t)-sn;
+            if (FMT == NLMC_FMT_ADDR) *(lds_i8w)(uintptr_t)(ka + v_neg_off) = (int8_t)-sn;
             *(lds_i8w)(uintptr_t)(tw + (unsigned)a.lds_snap_off) = (int8_t)sn;      // snapshot slot of the update's sweep
         }
     };
