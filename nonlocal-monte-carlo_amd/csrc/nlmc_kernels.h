@@ -1446,7 +1446,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
         const unsigned ka = (unsigned)hx & 0x3FFFu;                               // LDS address of the spin
         const float wk = *(lds_f32)(uintptr_t)((((unsigned)hx >> 16) << 2) + v_u_off);
 #endif
-        const int so = (int)*(lds_i8)(uintptr_t)ka;
+        int so = (int)*(lds_i8)(uintptr_t)ka;
         unsigned f = 0u;
         if (FLAGS) f = (unsigned)*(lds_u8)(uintptr_t)(ka + (unsigned)a.lds_flags_off);
         int sj[NE];
@@ -1460,6 +1460,9 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
 #pragma unroll
             for (int q = 0; q < NE; ++q) sj[q] = (int)*(lds_i8)(uintptr_t)it.col(q);   // all reads in flight
         }
+        // (pins the read of the spin's own value into the batch of the gathers: left alone, the scheduler sinks it behind
+        // the field sum -- one more LDS round trip on the dependent chain of every level)
+        asm volatile("" : "+v"(so));
         int X0 = it.hd.y, X1 = 0, Xd = 0;
 #pragma unroll
         for (int q = 0; q < NE; q += 2) {
