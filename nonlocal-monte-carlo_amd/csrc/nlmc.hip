@@ -1482,7 +1482,9 @@ int nlmc_pt_swap_philox(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs,
         a.plan_pairs = c->pt_plan_pairs.p + r * (size_t)nl * n_pairs * 2;
         a.plan_ok = c->pt_plan_ok.p + r * (size_t)nl;
     }
-    hipLaunchKernelGGL(k_pt_swap, dim3(nl), dim3(64), 0, c->stream, a);
+    // one lane per selected pair when the selection is planned (the in-kernel selection is written for ONE wave)
+    const int swap_nt = a.plan_pairs ? std::min(256, (n_pairs + 63) / 64 * 64) : 64;
+    hipLaunchKernelGGL(k_pt_swap, dim3(nl), dim3(std::max(64, swap_nt)), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     if (out_pairs || out_accepted) {
         int32_t st = 0;

@@ -105,25 +105,25 @@ __global__ void k_pt_select(PtSelectArgs a)      // grid = n_rounds * n_ladders,
 // (NPT/npt.py:668-671), one lane per selected pair.
 __global__ void k_pt_swap(PtSwapArgs a)
 {
-    const int L = a.ladder_len, g = blockIdx.x, lane = threadIdx.x;     // blockDim.x == 64
+    const int L = a.ladder_len, g = blockIdx.x, lane = threadIdx.x, nt = blockDim.x;     // nt == 64 unless the selection is planned
     int32_t *pairs = a.out_pairs + (size_t)g * a.n_pairs * 2;
+    const int32_t *sel = pairs;          // where the acceptance step reads this round's selection from
     int good;
-    if (a.plan_pairs) {                                                  // selection planned ahead
-        const int32_t *src = a.plan_pairs + (size_t)g * a.n_pairs * 2;
+    if (a.plan_pairs) {                                                  // selection planned ahead: read in place (no copy +
+        sel = a.plan_pairs + (size_t)g * a.n_pairs * 2;                  // barrier + re-read on the latency path of a round)
         good = a.plan_ok[g];
-        if (good) for (int p = lane; p < 2 * a.n_pairs; p += 64) pairs[p] = src[p];
     } else {
         good = pt_select_pairs(L, a.n_pairs, a.round, (uint32_t)g, a.seed_lo, a.seed_hi, pairs, lane);
     }
     if (!good) {
         if (lane == 0) atomicExch(a.status, 1);
-        for (int p = lane; p < a.n_pairs; p += 64) { a.out_acc[(size_t)g * a.n_pairs + p] = 0; pairs[2 * p] = pairs[2 * p + 1] = -1; }
+        for (int p = lane; p < a.n_pairs; p += nt) { a.out_acc[(size_t)g * a.n_pairs + p] = 0; pairs[2 * p] = pairs[2 * p + 1] = -1; }
         return;
     }
-    __syncthreads();      // pairs[] written above are read by all lanes below
+    if (!a.plan_pairs) __syncthreads();      // pairs[] written by the selection are read by all lanes below
     const double inv = __longlong_as_double((long long)(1023 - a.escale) << 52);
-    for (int p = lane; p < a.n_pairs; p += 64) {
-        const int i = pairs[2 * p];
+    for (int p = lane; p < a.n_pairs; p += nt) {
+        const int i = sel[2 * p];
         const int ca = a.chain_of_slot[(size_t)g * L + i], cb = a.chain_of_slot[(size_t)g * L + i + 1];
         const double Ea = a.energies ? a.energies[ca] : (double)a.efix[ca] * inv;
         const double Eb = a.energies ? a.energies[cb] : (double)a.efix[cb] * inv;
@@ -139,6 +139,7 @@ __global__ void k_pt_swap(PtSwapArgs a)
             a.chain_of_slot[(size_t)g * L + i + 1] = ca;
         }
         a.out_acc[(size_t)g * a.n_pairs + p] = acc ? 1 : 0;
+        if (a.plan_pairs) { pairs[2 * p] = i; pairs[2 * p + 1] = sel[2 * p + 1]; }      // the round's log
     }
 }
 
