@@ -22,7 +22,7 @@ the instance, the replica states and the ladder are resident in HBM before the t
 Prints ONE JSON line (rank 0).  `value` = end-to-end spin-updates/s of the whole job; `value_kernel_loop` = the same
 updates over the summed durations of the sweep kernel alone; `roofline` prices the dominant kernel with HIP events
 recorded on the stream it runs on; `cpu_baseline` times the oracle (a C port of the same algorithm, one thread) on a
-bounded sample of the same workload; `cpu_baseline_numpy_path` times the reference's own NumPy loop structure
+bounded sample of the same workload (`cpu_baseline_all_cores`: one such process per host core); `cpu_baseline_numpy_path` times the reference's own NumPy loop structure
 (restated in oracle/numpy_path.py, pinned to a golden) the same way; `f64_field` is a short second leg of the same
 workload with the fp64 field sum of the parity mode (91 algorithmic bytes per update).
 """
@@ -70,20 +70,20 @@ def load_pmc():
         return {}
 
 
-def cpu_baseline(J, h, seconds=12.0):
+def cpu_baseline(J, h, seconds=12.0, chain=0):
     """oracle/nlo.c (kind "port"): sequential C restatement of the same philox-mode sweep, one chain, one thread."""
     import numpy as np
     import oracle
     csr = oracle.Csr(J)
-    s = np.where(np.random.default_rng(1000).random(csr.n) < 0.5, -1, 1).astype(np.int8)
+    s = np.where(np.random.default_rng(1000 + chain).random(csr.n) < 0.5, -1, 1).astype(np.int8)
     chunk = 20
     cb = np.tile(np.array(oracle.cb_pair(1.0)), (chunk, 1))
-    oracle.sweeps_philox(csr, h, s, cb[:1], PHILOX_SEED, 0, want_M=False)     # warm-up / page-in
+    oracle.sweeps_philox(csr, h, s, cb[:1], PHILOX_SEED, chain, want_M=False)     # warm-up / page-in
     esc = oracle.field_scale(csr, h)[1]
     done, t0, emin, ef = 0, time.perf_counter(), None, 0
     ef = int(np.rint(oracle.energy(csr, h, s) * 2.0 ** esc))
     while time.perf_counter() - t0 < seconds:
-        _, s, tr = oracle.sweeps_philox(csr, h, s, cb, PHILOX_SEED, 0, sweep0=done, escale=esc, efix0=ef, want_M=False)
+        _, s, tr = oracle.sweeps_philox(csr, h, s, cb, PHILOX_SEED, chain, sweep0=done, escale=esc, efix0=ef, want_M=False)
         ef = int(tr[-1])
         emin = min(float(tr.min()) * 2.0 ** -esc, emin) if emin is not None else float(tr.min()) * 2.0 ** -esc
         done += chunk
@@ -91,6 +91,34 @@ def cpu_baseline(J, h, seconds=12.0):
     return {"value": done * csr.n / dt, "unit": "spin-updates/s", "cores": 1, "kind": "port",
             "sample": f"1 chain x {csr.n} spins x {done} sweeps at beta=1 ({dt:.1f} s of oracle/nlo.c:nlo_sweeps_philox)",
             "min_energy_seen": emin}
+
+
+def cpu_baseline_all_cores(seconds=8.0):
+    """The same oracle loop in one CHILD process per host core of this process's CPU set (each its own chain; children
+    are started with subprocess and never touch the GPU): what the C port does with the whole host."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                        # a container's CPU share (cgroup v2: "<quota> <period>" or "max <period>")
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            cores = min(cores, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        pass
+    cores = min(cores, 64)
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["OMP_NUM_THREADS"] = "1"
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(seconds), "--cpu-chain", str(i)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for i in range(cores)]
+    vals = []
+    for pr in procs:
+        out, _ = pr.communicate(timeout=seconds * 10 + 120)
+        if pr.returncode == 0 and out.strip():
+            vals.append(json.loads(out.strip().splitlines()[-1])["value"])
+    if not vals:
+        return None
+    return {"value": float(sum(vals)), "unit": "spin-updates/s", "cores": len(vals), "kind": "port",
+            "sample": f"{len(vals)} processes x 1 chain x {N_SPINS} spins, {seconds:.0f} s each of oracle/nlo.c:nlo_sweeps_philox"}
 
 
 def numpy_path_baseline(J, h, seconds=10.0):
@@ -139,7 +167,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f64-leg", action="store_true")
     ap.add_argument("--dry-run-launch", action="store_true", help="print the launcher command of --gpus N and exit")
+    ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)     # child of cpu_baseline_all_cores
+    ap.add_argument("--cpu-chain", type=int, default=0, help=argparse.SUPPRESS)
     a = ap.parse_args()
+
+    if a.cpu_worker > 0:                       # CPU-only child process: never touches the GPU
+        from helpers import make_instance
+        J, h = make_instance(N_SPINS, seed=INSTANCE_SEED)
+        print(json.dumps(cpu_baseline(J, h, seconds=a.cpu_worker, chain=a.cpu_chain)), flush=True)
+        return
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(a, sys.argv[1:]))
@@ -313,6 +349,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(J, h)
             out["cpu_baseline_numpy_path"] = numpy_path_baseline(J, h)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
