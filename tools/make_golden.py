@@ -194,6 +194,21 @@ def gen_mcmc():
          num_sweeps=15, M=M.T.astype(np.int8), energies=energies_of(M, Jn, hn))
 
 
+def gen_mcmc_large():
+    """The same call at sizes where a sweep has many multi-wave levels (N = 1000 +-J, N = 2500 Gaussian with fields):
+    a few sweeps each, so that the fixtures stay small."""
+    for name, (J, h), beta, sweeps, seed in (("pmj1000", inst_pmj_sparse(1000, 31), 1.2, 6, 3),
+                                              ("gsparse2500", inst_gauss_sparse(2500, 41), 1.6, 3, 4)):
+        nf = np.max(np.abs(J))
+        Jn, hn = J / nf, h / nf
+        obj = ref_nmc.NMC(Jn, hn)
+        np.random.seed(seed)
+        m0 = np.sign(2 * np.random.rand(Jn.shape[0]) - 1)
+        M = obj.MCMC(sweeps, m0.copy(), beta, Jn, hn)
+        save(f"mcmc_fixed_{name}_s{seed}", **csr_parts(Jn), h=hn, m_start=m0.astype(np.int8), beta=beta,
+             seed=seed, num_sweeps=sweeps, M=M.T.astype(np.int8), energies=energies_of(M, Jn, hn))
+
+
 # ----------------------------------------------------------------------------------------------
 # G3: NMC_subroutine with clusters PROVIDED (bypasses LBP)   (NMC/nmc.py:320-440, NPT/npt.py:357-477)
 # ----------------------------------------------------------------------------------------------
@@ -435,8 +450,8 @@ def gen_stats():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["mcmc", "nmcsub", "lbp", "npt", "icm", "pre", "known", "stats"]
-    table = dict(mcmc=gen_mcmc, nmcsub=gen_nmc_subroutine, lbp=gen_lbp_and_run, npt=gen_npt, icm=gen_icm,
+    which = sys.argv[1:] or ["mcmc", "large", "nmcsub", "lbp", "npt", "icm", "pre", "known", "stats"]
+    table = dict(mcmc=gen_mcmc, large=gen_mcmc_large, nmcsub=gen_nmc_subroutine, lbp=gen_lbp_and_run, npt=gen_npt, icm=gen_icm,
                  pre=gen_preprocessor, known=gen_known_answers, stats=gen_stats)
     for w in which:
         table[w]()
