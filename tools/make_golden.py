@@ -448,10 +448,31 @@ def gen_stats():
          num_sweeps_MCMC=nsw, num_swap_attempts=nswap, num_swapping_pairs=npairs, attempted=att, accepted=acc)
 
 
+def gen_stats_min():
+    """Minimum energies found by the reference's NPT.run (NPT/npt.py:535-700) on a +-J instance under a fixed budget,
+    40 independent runs: the `min-energy vs reference` half of BASELINE.json's metric as a distribution."""
+    J, h = inst_pmj_sparse(96, 555)
+    R, nsw, nswap, npairs, runs = 6, 48, 6, 2, 40
+    beta_list = np.linspace(0.3, 2.5, R)
+    E_all = np.zeros((runs, R))
+    for s in range(runs):
+        obj = ref_npt.NPT(J.copy(), h.copy())
+        np.random.seed(7000 + s)
+        random.seed(7000 + s)
+        import matplotlib.pyplot as _plt
+        _plt.close("all")
+        with quiet():
+            _, E = obj.run(beta_list=beta_list, num_replicas=R, doNMC=[False] * R, num_sweeps_MCMC=nsw, num_sweeps_read=nsw,
+                           num_swap_attempts=nswap, num_swapping_pairs=npairs, num_cycles=2, use_hash_table=False, num_cores=1)
+        E_all[s] = np.asarray(E).reshape(-1)
+    save("stats_minenergy_pmj96", **csr_parts(J), h=np.asarray(h).reshape(-1), beta_list=beta_list, num_replicas=R,
+         num_sweeps_MCMC=nsw, num_swap_attempts=nswap, num_swapping_pairs=npairs, energies=E_all, min_energy=E_all.min(axis=1))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["mcmc", "large", "nmcsub", "lbp", "npt", "icm", "pre", "known", "stats"]
-    table = dict(mcmc=gen_mcmc, large=gen_mcmc_large, nmcsub=gen_nmc_subroutine, lbp=gen_lbp_and_run, npt=gen_npt, icm=gen_icm,
+    which = sys.argv[1:] or ["mcmc", "large", "nmcsub", "lbp", "npt", "icm", "pre", "known", "stats", "statsmin"]
+    table = dict(mcmc=gen_mcmc, large=gen_mcmc_large, statsmin=gen_stats_min, nmcsub=gen_nmc_subroutine, lbp=gen_lbp_and_run, npt=gen_npt, icm=gen_icm,
                  pre=gen_preprocessor, known=gen_known_answers, stats=gen_stats)
     for w in which:
         table[w]()
