@@ -6,7 +6,8 @@ sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 from conftest import load_product
 from helpers import make_instance, init_spins
 P = load_product()
-N, R, T, ROUNDS, SEED, PAIRS = 10_000, 256, 10, int(os.environ.get("ROUNDS", 600)), 0xA5A50000, 77
+N, R, T, ROUNDS, SEED = 10_000, int(os.environ.get("R", 256)), 10, int(os.environ.get("ROUNDS", 600)), 0xA5A50000
+PAIRS = round(0.3 * R)
 J, h = make_instance(N)
 res = []
 for rep in range(2):
