@@ -307,29 +307,24 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
                 mx[k] = (uint32_t)base;
                 cnt8[k] = (uint8_t)min(c, 255);
                 if (c > 255) sh_fail = 1;          // more than 255 preceding neighbours: no fused schedule
+                if (c == 0) queue[atomicAdd(&sh_qn, 1)] = (uint16_t)k;     // no earlier neighbour: ready at once
             }
         }
         __syncthreads();                           // every old level has been read: g is rewritten below
         c0 = (long long)__builtin_readcyclecounter();
         st[1] += c0 - c1;
-        unsigned todo = 0u;
-        for (int i = 0; i < NLMC_FZ_SPT; ++i) if (tid + i * nt < n) todo |= 1u << i;
         int lmax = 0;
-        // Topological passes with a compacted work queue: (a) every thread looks at its own counters and queues the
-        // spins that became ready; (b) the queue is processed one spin per lane (a wave that handled "its own" spins
-        // would run the body for every i in which ANY of its 64 lanes has a ready spin: 7 % lane efficiency).
+        // Topological passes over a work queue that every spin enters exactly once per sweep: the thread whose decrement
+        // takes a spin's counter of unfinished earlier neighbours to zero appends it (its level is final then: every
+        // earlier neighbour has pushed its level with an atomicMax BEFORE its decrement, and LDS operations are served in
+        // order).  A pass processes the entries appended during the previous one, one spin per lane; nobody scans
+        // counters.
+        int q_lo = 0;
         for (int pass = 0; pass <= n; ++pass) {
-            for (int i = 0; i < NLMC_FZ_SPT; ++i) {
-                const int k = tid + i * nt;
-                if ((todo & (1u << i)) && cnt8[k] == 0) {       // (a wave-aggregated reservation measured slower)
-                    todo &= ~(1u << i);
-                    queue[atomicAdd(&sh_qn, 1)] = (uint16_t)k;
-                }
-            }
+            const int q_hi = sh_qn;                // stable: appended to only between the two barriers below
             __syncthreads();
-            const int qn = sh_qn;
-            if (qn == 0) break;                    // nothing ready: all done (a DAG always has a ready node otherwise)
-            for (int idx = tid; idx < qn; idx += nt) {
+            if (q_lo == q_hi) break;               // nothing became ready: done (a DAG always has a ready node otherwise)
+            for (int idx = q_lo + tid; idx < q_hi; idx += nt) {
                 const int k = (int)queue[idx];
                 const int re = a.g.rowptr[k + 1], rs = a.g.rowptr[k];
                 const uint4 a0 = a.adj[2 * k], a1 = a.adj[2 * k + 1];
@@ -351,22 +346,25 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
                     const int j = (int)((aw[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu);
                     if (j != k && precedes(kk, k, kj[q], j)) {                // k comes before j: j waits for k
                         atomicMax(&mx[j], (uint32_t)lv);
-                        atomicSub(&cnt32[j >> 2], 1u << ((j & 3) * 8));       // after the max (one wave's LDS ops are in order)
+                        const uint32_t old = atomicSub(&cnt32[j >> 2], 1u << ((j & 3) * 8));      // after the max
+                        if (((old >> ((j & 3) * 8)) & 0xFFu) == 1u) queue[atomicAdd(&sh_qn, 1)] = (uint16_t)j;
                     }
                 }
                 for (int e = rs + NLMC_FZ_ADJ; e < re; ++e) {
                     const int j = a.g.col[e];
                     if (j != k && precedes(kk, k, key[j], j)) {
                         atomicMax(&mx[j], (uint32_t)lv);
-                        atomicSub(&cnt32[j >> 2], 1u << ((j & 3) * 8));
+                        const uint32_t old = atomicSub(&cnt32[j >> 2], 1u << ((j & 3) * 8));
+                        if (((old >> ((j & 3) * 8)) & 0xFFu) == 1u) queue[atomicAdd(&sh_qn, 1)] = (uint16_t)j;
                     }
                 }
             }
             st[3] += 1;
-            __syncthreads();
-            if (tid == 0) sh_qn = 0;
+            q_lo = q_hi;
             __syncthreads();
         }
+        __syncthreads();
+        if (tid == 0) sh_qn = 0;                   // (read as q_hi by everybody before the barrier above)
         st[2] += (long long)__builtin_readcyclecounter() - c0;
         atomicMax(&sh_max, lmax);
         __syncthreads();
