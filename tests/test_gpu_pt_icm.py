@@ -126,13 +126,14 @@ def test_icm_round_philox_batch(product):
     assert np.array_equal(got, exp)
 
 
-def test_icm_round_ladders_pairing_and_moves(product):
+@pytest.mark.parametrize("with_h", [False, True])
+def test_icm_round_ladders_pairing_and_moves(product, with_h):
     """nlmc_icm_round_ladders: per temperature slot the K ladders are shuffled by Philox keys and paired
     (NPT/apt_ICM.py:216-222); each pair gets the iso-cluster move of test_icm_round_philox_batch.  Restated on the host
     with the oracle's Philox and cluster routines, after a few swap rounds so that slots are no longer the identity."""
     TAG_ICM_PAIR = 6
     N, R, K = 150, 4, 6
-    J, h = make_instance(N, seed=21)
+    J, h = make_instance(N, seed=21, with_h=with_h)
     csr = oracle.Csr(J)
     G = R * K
     seed, rnd = 99887766, 5
@@ -146,7 +147,12 @@ def test_icm_round_ladders_pairing_and_moves(product):
         m0 = eng.get_spins()
         info = eng.icm_round_ladders(rnd, seed, katzgraber=True, want_info=True)
         got = eng.get_spins()
+        E_tracked = eng.energy_tracked()         # re-synchronised by the round (no drift against a later recomputation)
+        qs = eng.field_scale
         E = eng.energy()
+    # exact for integer couplings and fields; otherwise within the quantisation bound of the fixed-point model
+    tol = 0.0 if not with_h else 2.0 ** -(qs + 1) * (J.nnz / 2 + N) * 4
+    assert np.max(np.abs(E_tracked - E)) <= tol
     assert not np.array_equal(slots, np.arange(G) % R)
     exp = m0.copy()
     p = 0

@@ -249,7 +249,9 @@ def test_c5_size_icm_rounds_properties(product):
                 pl.sweep(r)
                 e_before = eng.energy()
                 info = eng.icm_round_ladders(r, SEED, True, want_info=True)
+                e_tracked = eng.energy_tracked()            # the round leaves the tracked energies in sync
                 e_after = eng.energy()
+                assert np.array_equal(e_tracked, e_after)
                 sums.append((e_before.sum(), e_after.sum(), int((info[:, 1] > 0).sum())))
                 eng.pt_swap_philox(r, SEED, 10, want_log=False)
             spins = eng.get_spins()
