@@ -24,7 +24,7 @@ import os
 import numpy as np
 
 from . import hostlogic
-from .engine import Engine, Instance, trace_layout
+from .engine import Engine, Instance, fused_window, trace_layout
 from .lbp import (EdgeGraph, lbp_convexified, lbp_convexified_device, loopy_bp, atanh_saturated as _atanh_saturated,
                   find_clusters as _find_clusters)
 
@@ -108,11 +108,24 @@ class SweepMixin:
             perm, u = hostlogic.draw_legacy_stream(num_sweeps, n)
             return eng.sweep_stream(perm[None], u[None], np.asarray(beta_run)[None, :], record_stride=rs,
                                     want_energy=True, want_min=True, want_state=True)
-        # single-chain API calls return energy traces: fp64 fields keep them exact to rounding (the fp32 path is the
-        # batched throughput path); very large instances only fit the fp32 layout in LDS
-        o = eng.sweep_philox(num_sweeps, self.seed, sweep0=self._sweep_counter, beta=np.asarray(beta_run)[None, :],
-                             precision="f64" if n <= 12000 else "f32", record_stride=rs,
-                             want_energy=True, want_min=True, want_state=True)
+        beta2 = np.asarray(beta_run)[None, :]
+        # Fused-window schedules (the sweeps of a launch overlap; "f32" arithmetic: fixed-point couplings) when the
+        # instance qualifies and every configuration is recorded: the energies handed back are then the fp64 energies of
+        # the recorded configurations, computed on the device copy of the trace, and the argmin hand-off
+        # (NMC/nmc.py:394-395) uses those -- exact like the reference's list comprehension, 2-3 x the sweep rate.
+        T = fused_window(num_sweeps) if rs == 1 and 256 <= n else 0
+        if T and eng.plan_philox_fused(self._sweep_counter, num_sweeps // T, T, self.seed) == num_sweeps // T:
+            o = eng.sweep_philox(num_sweeps, self.seed, sweep0=self._sweep_counter, beta=beta2, precision="f32",
+                                 record_stride=1, want_energy=True, want_min=True, want_state=True)
+            E = eng.energy_of_recorded(num_sweeps)[0]
+            k = int(np.argmin(E))                                   # first minimum, like np.argmin over the list
+            o["energy"][0] = E
+            o["min_energy"][0], o["argmin"][0], o["argmin_state"][0] = E[k], k, o["spins"][0][k]
+        else:
+            # fp64 fields keep the tracked energies exact to rounding; very large instances only fit the fp32 layout
+            o = eng.sweep_philox(num_sweeps, self.seed, sweep0=self._sweep_counter, beta=beta2,
+                                 precision="f64" if n <= 12000 else "f32", record_stride=rs,
+                                 want_energy=True, want_min=True, want_state=True)
         self._sweep_counter += num_sweeps
         return o
 
