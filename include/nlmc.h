@@ -44,6 +44,12 @@ enum { NLMC_SPIN_NORMAL = 0, NLMC_SPIN_SCALED = 1, NLMC_SPIN_FROZEN_UP = 2, NLMC
 
 #define NLMC_MAX_N 24576 /* spins per chain this build keeps in LDS */
 
+/* Version of this interface; nlmc_abi_version() returns the value the library was built with and the binding refuses a
+ * library whose value differs.  2 (round 3): nlmc_timing_total has a fifth out-pointer and nlmc_timing_reset's argument is
+ * a sampling period (both since round 2), NLMC_F32 means 24-bit fixed-point couplings + logistic thresholds, chain
+ * subsets / plan slots / device-side NMC hand-offs were added. */
+#define NLMC_ABI_VERSION 2
+
 int nlmc_abi_version(void);
 int nlmc_device_count(void);
 
@@ -123,9 +129,9 @@ int nlmc_sweep_philox(nlmc_ctx *ctx, int precision, int order_mode, int n_sweeps
 int nlmc_plan_philox(nlmc_ctx *ctx, int precision, int order_mode, uint32_t sweep0, int n_sweeps, uint64_t seed);
 /* Fused-window schedules for n_windows consecutive launches of exactly `window` sweeps each (sweeps sweep0 + w*window
  * ...): all sweeps of a launch share one level list in which the tail of sweep t overlaps the head of sweep t+1
- * (DESIGN.md section 3).  A later nlmc_sweep_philox call with F32, shared order, n_sweeps == window, a planned
- * sweep0, constant beta and no per-sweep outputs (no recorded spins, energies or minima) runs on it; every other call
- * takes the sweep-by-sweep path.  Results are bit-identical either way.  out_planned: number of windows that got a
+ * (DESIGN.md section 3).  A later nlmc_sweep_philox call with F32, shared order, n_sweeps a multiple of window, a planned
+ * sweep0 (a whole number of planned windows) runs on it -- with per-sweep outputs or a temperature per sweep when the
+ * snapshot slots of that variant fit in LDS; every other call takes the sweep-by-sweep path.  Results are bit-identical either way.  out_planned: number of windows that got a
  * fused schedule (0 when the instance does not qualify: n < 256 or n > 11264,
  * window < 3 or > 64, or the three threshold tables do not fit in LDS next to the spins). */
 int nlmc_plan_philox_fused(nlmc_ctx *ctx, uint32_t sweep0, int n_windows, int window, uint64_t seed, int32_t *out_planned);
@@ -167,6 +173,48 @@ int nlmc_pt_log_read(nlmc_ctx *ctx, int32_t *out_pairs, uint8_t *out_accepted);
  * that return their log, and planned rounds (at nlmc_pt_plan time), report it themselves; call this after a run of
  * unplanned rounds without logs.  One stream synchronisation. */
 int nlmc_pt_check(nlmc_ctx *ctx);
+
+/* ---- replica-exchange rounds whose marked temperature slots run NMC cycles, device-resident -------------------------
+ * NPT.run submits NMC_task (NPT/npt.py:479-512 -> NMC_subroutine :357-477) instead of MCMC_task for the replicas whose
+ * doNMC entry is set (NPT/npt.py:622-647); doNMC belongs to the temperature SLOT.  With label-exchange swaps the chains
+ * that sit on marked slots change from round to round, so a round is driven on chain SUBSETS:
+ *   nlmc_pt_mark_slots(marks)             marks [ladder_len] = doNMC; every ladder must lie inside one context
+ *   nlmc_select_chains(UNMARKED | MARKED) later nlmc_sweep_philox / nlmc_adopt_best / nlmc_backbone_clusters /
+ *                                         nlmc_set_phase calls act on the local chains currently on such slots (ascending
+ *                                         chain id; the list is rebuilt on the device after every swap round); sweep
+ *                                         outputs then have one row per chain of the subset (nlmc_subset_count,
+ *                                         nlmc_get_subset), per-chain beta tables are refused (ladder or one beta)
+ * One NMC_task of all marked chains at once, without a host round trip:
+ *   nlmc_backbone_clusters   LBP_convexified (NPT/npt.py:397-403, :129-202) seeded with each chain's current state, then the
+ *                            union of find_clusters' clusters (NPT/npt.py:294-355) as a per-chain mask: thresholds[0] =
+ *                            threshold_initial selects the seeds, every further entry is one growth step (the host's
+ *                            `current_threshold -= threshold_step` values above threshold_cutoff)
+ *   nlmc_set_phase(kind, temp_x)   per-spin flags of the subset from its masks: BACKBONE_HOT = cluster rows / temp_x, the
+ *                            rest frozen (NPT/npt.py:406-414,425); BACKBONE_FROZEN = cluster spins frozen (:441); ALL =
+ *                            plain (:460)
+ *   nlmc_track_minimum(1)    sweep calls keep the running minimum + argmin configuration of every chain on the device
+ *   nlmc_adopt_best          the argmin configuration becomes the current state, its energy the tracked energy
+ *                            (NPT/npt.py:436-437,454-455,469-470: `m_init = M[:, min_energy_idx]`)
+ *   nlmc_backbone_check      NLMC_ERR_ARG with the reference's message if an inference since the last check diverged at its
+ *                            first lambda (NPT/npt.py:178-180 raises ValueError at once; here it surfaces at the check).
+ * nlmc_get_cluster_mask: [n_chains][n] masks of the most recent inference of every chain (tests, diagnostics). */
+enum { NLMC_CHAINS_ALL = 0, NLMC_CHAINS_UNMARKED = 1, NLMC_CHAINS_MARKED = 2 };
+enum { NLMC_PHASE_ALL = 0, NLMC_PHASE_BACKBONE_HOT = 1, NLMC_PHASE_BACKBONE_FROZEN = 2 };
+int nlmc_pt_mark_slots(nlmc_ctx *ctx, const uint8_t *marks /*[ladder_len] or NULL*/);
+int nlmc_select_chains(nlmc_ctx *ctx, int which);
+int nlmc_subset_count(const nlmc_ctx *ctx);
+int nlmc_get_subset(nlmc_ctx *ctx, int32_t *out_chains /*[nlmc_subset_count] local chain ids*/);
+int nlmc_track_minimum(nlmc_ctx *ctx, int on);
+int nlmc_adopt_best(nlmc_ctx *ctx);
+int nlmc_backbone_clusters(nlmc_ctx *ctx, const double *epsilon /*[n]*/, const double *lambdas, int n_lambdas, double beta,
+                           double tolerance, int max_iterations, double sat, const double *thresholds, int n_thresholds);
+int nlmc_backbone_check(nlmc_ctx *ctx);
+int nlmc_get_cluster_mask(nlmc_ctx *ctx, uint8_t *out /*[n_chains][n]*/);
+int nlmc_set_phase(nlmc_ctx *ctx, int kind, double temp_x);
+/* Fused-window plans live in two slots; nlmc_plan_philox_fused / nlmc_plan_reserve_fused write to the selected one, sweep
+ * calls use whichever slot covers their sweeps (a round sweeps its plain chains on windows of num_sweeps_MCMC_per_swap and
+ * its NMC phases on windows of num_sweeps_per_NMC_phase_per_swap, NPT/npt.py:577-580). */
+int nlmc_plan_slot(nlmc_ctx *ctx, int slot /*0 or 1*/);
 
 /* Houdayer iso-cluster move (NPT/apt_ICM.py:116-143, 215-246) between the current states of local chains a and
  * b: connected components of the disagreement sub-graph, pick component number `pick_index mod n_components`

@@ -18,6 +18,9 @@ F32, F64 = 0, 1
 ORDER_SHARED, ORDER_PER_CHAIN = 0, 1
 SPIN_NORMAL, SPIN_SCALED, SPIN_FROZEN_UP, SPIN_FROZEN_DOWN = 0, 1, 2, 3
 MAX_N = 24576
+ABI_VERSION = 2                      # include/nlmc.h: NLMC_ABI_VERSION
+CHAINS_ALL, CHAINS_UNMARKED, CHAINS_MARKED = 0, 1, 2
+PHASE_ALL, PHASE_BACKBONE_HOT, PHASE_BACKBONE_FROZEN = 0, 1, 2
 
 EXPORTS = [
     "nlmc_abi_version", "nlmc_device_count", "nlmc_create", "nlmc_destroy", "nlmc_last_error", "nlmc_set_spins",
@@ -26,6 +29,8 @@ EXPORTS = [
     "nlmc_pt_apply_swap", "nlmc_pt_swap_philox", "nlmc_pt_plan", "nlmc_pt_check", "nlmc_pt_swap_philox_host", "nlmc_pt_log_begin", "nlmc_pt_log_read", "nlmc_icm_components", "nlmc_icm_move", "nlmc_icm_get_labels", "nlmc_icm_round_philox", "nlmc_icm_round_ladders",
     "nlmc_lbp_convexified", "nlmc_find_clusters", "nlmc_trace_layout", "nlmc_energy_of_recorded",
     "nlmc_last_timing", "nlmc_timing_reset", "nlmc_timing_total", "nlmc_last_schedule_stats",
+    "nlmc_pt_mark_slots", "nlmc_select_chains", "nlmc_subset_count", "nlmc_get_subset", "nlmc_track_minimum", "nlmc_adopt_best",
+    "nlmc_backbone_clusters", "nlmc_backbone_check", "nlmc_get_cluster_mask", "nlmc_set_phase", "nlmc_plan_slot",
 ]
 
 
@@ -63,6 +68,9 @@ def lib():
                           "(there is no CPU fallback for the sweep path)")
     L = ctypes.CDLL(LIB_PATH)
     L.nlmc_abi_version.restype = _i
+    if L.nlmc_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} implements ABI version {L.nlmc_abi_version()}, this binding needs {ABI_VERSION}: "
+                          "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
     L.nlmc_device_count.restype = _i
     L.nlmc_last_error.restype = ctypes.c_char_p
     L.nlmc_last_error.argtypes = [_vp]
@@ -135,6 +143,14 @@ def lib():
     L.nlmc_timing_total.argtypes = [_vp, _vp, _vp, _vp, _vp]
     L.nlmc_last_schedule_stats.restype = _i
     L.nlmc_last_schedule_stats.argtypes = [_vp, _vp, _vp]
+    for name, args in (("nlmc_pt_mark_slots", [_vp, _vp]), ("nlmc_select_chains", [_vp, _i]), ("nlmc_subset_count", [_vp]),
+                       ("nlmc_get_subset", [_vp, _vp]), ("nlmc_track_minimum", [_vp, _i]), ("nlmc_adopt_best", [_vp]),
+                       ("nlmc_backbone_clusters", [_vp, _vp, _vp, _i, _dbl, _dbl, _i, _dbl, _vp, _i]),
+                       ("nlmc_backbone_check", [_vp]), ("nlmc_get_cluster_mask", [_vp, _vp]), ("nlmc_set_phase", [_vp, _i, _dbl]),
+                       ("nlmc_plan_slot", [_vp, _i])):
+        f = getattr(L, name)
+        f.restype = _i
+        f.argtypes = args
     _lib = L
     return L
 

@@ -3,6 +3,7 @@
 #include "nlmc_kernels.h"
 #include "nlmc_pt_icm.h"
 #include "nlmc_lbp.h"
+#include "nlmc_nmc.h"
 #include "nlmc_host.h"
 
 #include <algorithm>
@@ -71,6 +72,22 @@ struct nlmc_ctx {
     DevBuf<uint32_t> keys;
     DevBuf<int8_t> strace, cfg;
     int strace_nrec = 0;          // recorded configurations per chain held in strace by the last sweep call (0: none)
+    int strace_rows = 0;          // chains (rows) of that trace: the subset the call ran on
+    // chain subsets (nlmc_pt_mark_slots / nlmc_select_chains): sweeps, hand-offs and backbone inference of a call act on
+    // the local chains that currently sit on unmarked / marked temperature slots
+    int subset = 0;               // NLMC_CHAINS_ALL / _UNMARKED / _MARKED
+    int n_marked_local = 0;       // marked slots x local ladders (static: ladders are whole inside a context)
+    bool sub_dirty = true;        // slots moved since the list was built
+    DevBuf<uint8_t> slot_mark;    // [ladder_len]
+    DevBuf<int32_t> sub_list_buf; // [n_chains]: unmarked chains ascending, then marked chains ascending
+    int sub_count() const { return subset == 0 ? n_chains : subset == 1 ? n_chains - n_marked_local : n_marked_local; }
+    const int32_t *sub_list() const { return subset == 0 ? nullptr : subset == 1 ? sub_list_buf.p : sub_list_buf.p + (n_chains - n_marked_local); }
+    bool track_min = false;       // sweep calls keep running minimum + argmin state on the device (nlmc_track_minimum)
+    DevBuf<uint8_t> cmask;        // [n_chains][n_pad] backbone mask of the last inference per chain
+    DevBuf<int32_t> nmc_status;   // sticky: a backbone inference diverged at its first lambda
+    DevBuf<double> nmc_thr;       // thresholds of the cluster growth
+    std::vector<double> nmc_thr_host, tab_host, lbp_eps_host, lbp_lams_host;   // contents of the device copies (uploads skipped when unchanged)
+    double lbp_tJ_beta = 0.0; bool lbp_tJ_valid = false;
     // schedule scratch (per call) and plan cache (persistent)
     struct Sched {            // one set of level-schedule buffers (per-call scratch, or the persistent plan)
         DevBuf<int2> order, head32;
@@ -107,22 +124,30 @@ struct nlmc_ctx {
     int max_deg = 0;
     int n_long = 0;                    // rows with more than NLMC_FZ_W entries (two schedule positions in a fused plan)
     int stat_fused_window = -1;          // >= 0: the most recent sweep call ran this fused window
-    bool fz_valid = false;
-    uint32_t fz_sweep0 = 0;
-    int fz_windows = 0, fz_T = 0, fz_workers = 13;
-    uint64_t fz_seed = 0;
-    std::vector<int32_t> fz_nlev_host, fz_npos_host;
-    int fz_pstride = 0, fz_gen0 = 0;
-    int fz_fmt = 0;                   // entry format of the current fused plan (NLMC_FMT_*)
-    DevBuf<int32_t> fz_npos;
-    DevBuf<uint16_t> fz_glv;
+    // Two plan slots (nlmc_plan_slot): a replica-exchange round whose marked slots run NMC cycles sweeps its plain chains
+    // on windows of one length and its NMC phases on windows of another (NPT/npt.py:577-580).
+    struct FusedPlan {
+        bool valid = false;
+        uint32_t sweep0 = 0;
+        int windows = 0, T = 0, workers = 13;
+        uint64_t seed = 0;
+        std::vector<int32_t> nlev_host, npos_host;
+        int pstride = 0, gen0 = 0;
+        int fmt = 0;                  // entry format of the plan (NLMC_FMT_*)
+        DevBuf<int32_t> npos;
+        DevBuf<int2> head;
+        DevBuf<EdgeQ> ell;
+        DevBuf<int32_t> loff, nlev, himax, send;
+        void release() { npos.release(); head.release(); ell.release(); loff.release(); nlev.release(); himax.release(); send.release(); }
+    };
+    FusedPlan fz[2];
+    int fz_slot = 0;                  // slot the planning entry points write to
+    int stat_fused_slot = 0;
+    DevBuf<uint16_t> fz_glv;          // planning scratch, shared by the slots (planning is stream-ordered)
     DevBuf<uint32_t> fz_perm;
     DevBuf<uint16_t> fz_adj;
     DevBuf<long long> fz_stats;
     bool fz_adj_ready = false;
-    DevBuf<int2> fz_head;
-    DevBuf<EdgeQ> fz_ell;
-    DevBuf<int32_t> fz_loff, fz_nlev, fz_himax, fz_send;
     // PT
     int ladder_len = 0;
     bool pt_tab_valid = false;
@@ -378,12 +403,13 @@ struct SweepOut {
 
 // One fused window.  `outs` (nullable): the launch also produces per-sweep outputs into the context's device buffers
 // (etrace / emin / argmin / best / strace, sized by the caller) as sweeps [t0, t0 + T) of a call of n_total sweeps.
-int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *tab_dev, int tab_cs, int tab_ss, bool use_slots,
+int run_fused(nlmc_ctx *c, int slot, int w, uint32_t sweep0, uint64_t seed, const double *tab_dev, int tab_cs, int tab_ss, bool use_slots,
               bool outs, bool want_energy, bool want_min, bool want_state, int rec, int t0, int n_total)
 {
-    const int R = c->n_chains, n = c->n, T = c->fz_T;
-    const size_t PS = (size_t)c->fz_pstride;
-    const FusedLds L = fused_lds(c->n, c->n_pad, c->has_flags, outs, c->fz_fmt == NLMC_FMT_ADDR);
+    const nlmc_ctx::FusedPlan &P = c->fz[slot];
+    const int R = c->sub_count(), n = c->n, T = P.T;
+    const size_t PS = (size_t)P.pstride;
+    const FusedLds L = fused_lds(c->n, c->n_pad, c->has_flags, outs, P.fmt == NLMC_FMT_ADDR);
     const int variant = (outs ? 4 : 0) + (c->has_diag ? 2 : 0) + (c->has_flags ? 1 : 0);
     const void *kfun = nullptr;
     switch (variant) {
@@ -412,24 +438,25 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
     SweepArgs a{};
     a.g = c->g;
     a.chain_base = c->chain_base;
+    a.chain_list = c->sub_list();
     a.spins = c->spins.p;
     a.flags = c->has_flags ? c->flags.p : nullptr;
     a.temp_x = c->temp_x;
-    a.lvl_off = c->fz_loff.p + (size_t)w * (NLMC_LCAP + 1);
-    a.nlev = c->fz_nlev.p + w;
-    a.hi_max = c->fz_himax.p + w;
-    a.ell32 = c->fz_ell.p + (size_t)w * PS * NLMC_FZ_W;
-    a.head32 = c->fz_head.p + (size_t)w * PS;
-    a.fsend = c->fz_send.p + (size_t)w * T;
-    a.fz_pstride = c->fz_pstride;
-    a.fz_fmt = c->fz_fmt;
-    if (w + 1 < c->fz_windows && c->fz_nlev_host[(size_t)w + 1] > 0 && !c->knob_no_warm) {
-        a.warm_head = c->fz_head.p + (size_t)(w + 1) * PS;
-        a.warm_ell = c->fz_ell.p + (size_t)(w + 1) * PS * NLMC_FZ_W;
-        a.fz_npos_next = c->fz_npos_host[(size_t)w + 1];
+    a.lvl_off = P.loff.p + (size_t)w * (NLMC_LCAP + 1);
+    a.nlev = P.nlev.p + w;
+    a.hi_max = P.himax.p + w;
+    a.ell32 = P.ell.p + (size_t)w * PS * NLMC_FZ_W;
+    a.head32 = P.head.p + (size_t)w * PS;
+    a.fsend = P.send.p + (size_t)w * T;
+    a.fz_pstride = P.pstride;
+    a.fz_fmt = P.fmt;
+    if (w + 1 < P.windows && P.nlev_host[(size_t)w + 1] > 0 && !c->knob_no_warm) {
+        a.warm_head = P.head.p + (size_t)(w + 1) * PS;
+        a.warm_ell = P.ell.p + (size_t)(w + 1) * PS * NLMC_FZ_W;
+        a.fz_npos_next = P.npos_host[(size_t)w + 1];
     }
-    a.f_workers = c->fz_workers;
-    a.f_gen0 = c->fz_gen0;
+    a.f_workers = P.workers;
+    a.f_gen0 = P.gen0;
     a.f_gen_prio = c->knob_no_prio ? 0 : 1;
 #ifdef NLMC_DEBUG_KNOBS
     a.dbg_flags = c->knob_dbg_flags;
@@ -478,13 +505,15 @@ int run_fused(nlmc_ctx *c, int w, uint32_t sweep0, uint64_t seed, const double *
     c->launches_sweep++;
     c->launches_total++;
     c->stat_fused_window = w;
+    c->stat_fused_slot = slot;
     return NLMC_OK;
 }
 
-// device result buffers of a sweep call -> the caller's host arrays
+// device result buffers of a sweep call -> the caller's host arrays.  Rows of the recorded traces are dense in the launch's
+// blocks; minima / argmin states live in per-chain rows and are gathered through the subset's chain list.
 int read_sweep_outputs(nlmc_ctx *c, const SweepOut &o, int n_sweeps, int rec, int n_rec)
 {
-    const int R = c->n_chains, n = c->n;
+    const int R = c->sub_count(), RA = c->n_chains, n = c->n;
     bool need_sync = false;
     std::vector<long long> h_ll;
     if (o.out_energy) {
@@ -493,17 +522,24 @@ int read_sweep_outputs(nlmc_ctx *c, const SweepOut &o, int n_sweeps, int rec, in
         need_sync = true;
     }
     std::vector<long long> h_min;
+    std::vector<int32_t> h_arg, h_list;
+    const bool gather = c->subset != 0 && (o.out_min_energy || o.out_argmin || o.out_argmin_state);
+    if (gather) {
+        h_list.resize((size_t)R);
+        HIP_TRY(c, hipMemcpyAsync(h_list.data(), c->sub_list(), sizeof(int32_t) * R, hipMemcpyDeviceToHost, c->stream));
+    }
     if (o.out_min_energy) {
-        h_min.resize(R);
-        HIP_TRY(c, hipMemcpyAsync(h_min.data(), c->emin.p, sizeof(long long) * R, hipMemcpyDeviceToHost, c->stream));
+        h_min.resize((size_t)RA);
+        HIP_TRY(c, hipMemcpyAsync(h_min.data(), c->emin.p, sizeof(long long) * RA, hipMemcpyDeviceToHost, c->stream));
         need_sync = true;
     }
     if (o.out_argmin) {
-        HIP_TRY(c, hipMemcpyAsync(o.out_argmin, c->argmin.p, sizeof(int32_t) * R, hipMemcpyDeviceToHost, c->stream));
+        h_arg.resize((size_t)RA);
+        HIP_TRY(c, hipMemcpyAsync(h_arg.data(), c->argmin.p, sizeof(int32_t) * RA, hipMemcpyDeviceToHost, c->stream));
         need_sync = true;
     }
     if (o.out_argmin_state) {
-        int rc = rows_to_host_begin(c, c->best.p, R);
+        int rc = rows_to_host_begin(c, c->best.p, RA);
         if (rc) return rc;
         need_sync = true;
     }
@@ -512,20 +548,50 @@ int read_sweep_outputs(nlmc_ctx *c, const SweepOut &o, int n_sweeps, int rec, in
         need_sync = true;
     }
     if (need_sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (o.out_argmin_state) rows_to_host_finish(c, o.out_argmin_state, R);
+    auto row = [&](int i) { return gather ? (int)h_list[(size_t)i] : i; };
+    if (o.out_argmin_state)
+        for (int i = 0; i < R; ++i)
+            std::memcpy(o.out_argmin_state + (size_t)i * n, c->stage_out.data() + (size_t)row(i) * c->n_pad, (size_t)n);
     const double inv = std::ldexp(1.0, -c->escale);
     if (o.out_energy) for (size_t i = 0; i < h_ll.size(); ++i) o.out_energy[i] = (double)h_ll[i] * inv;
-    if (o.out_min_energy) for (int i = 0; i < R; ++i) o.out_min_energy[i] = (double)h_min[i] * inv;
+    if (o.out_min_energy) for (int i = 0; i < R; ++i) o.out_min_energy[i] = (double)h_min[(size_t)row(i)] * inv;
+    if (o.out_argmin) for (int i = 0; i < R; ++i) o.out_argmin[i] = h_arg[(size_t)row(i)];
     return NLMC_OK;
 }
 
+// chain list of the selected subset, rebuilt (one small launch) after anything that moved chains between slots
+int ensure_subset(nlmc_ctx *c)
+{
+    if (c->subset == 0 || !c->sub_dirty) return NLMC_OK;
+    hipLaunchKernelGGL(k_subset_build, dim3(1), dim3(1024), 0, c->stream, c->n_chains, c->chain_base, c->slot_of_chain.p, c->slot_mark.p,
+                       c->n_chains - c->n_marked_local, c->sub_list_buf.p);
+    HIP_TRY(c, hipGetLastError());
+    c->sub_dirty = false;
+    return NLMC_OK;
+}
+
+// the fused plan slot whose windows cover sweeps [sweep0, sweep0 + n_sweeps) exactly, or -1
+int fused_plan_for(const nlmc_ctx *c, uint32_t sweep0, int n_sweeps, uint64_t seed)
+{
+    for (int k = 0; k < 2; ++k) {
+        const nlmc_ctx::FusedPlan &P = c->fz[k];
+        if (!P.valid || P.seed != seed || sweep0 < P.sweep0 || (sweep0 - P.sweep0) % (uint32_t)P.T != 0 || n_sweeps % P.T != 0 ||
+            (uint64_t)(sweep0 - P.sweep0) + (uint64_t)n_sweeps > (uint64_t)P.T * (uint64_t)P.windows)
+            continue;
+        const int w0 = (int)((sweep0 - P.sweep0) / (uint32_t)P.T), nw = n_sweeps / P.T;
+        bool all_ok = true;
+        for (int w = w0; w < w0 + nw; ++w) all_ok = all_ok && P.nlev_host[(size_t)w] > 0;
+        if (all_ok) return k;
+    }
+    return -1;
+}
 
 // Shared driver: windows of sweeps -> (levelize) -> k_sweep.  `stream_mode` selects the kernel flavour.
 int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int n_sweeps, uint32_t sweep0,
                uint64_t seed, const double *tab_dev, int tab_cs, int tab_ss, bool use_slots, const uint32_t *keys_dev,
                const double *ustream_dev, const SweepOut &o)
 {
-    const int R = c->n_chains, n = c->n;
+    const int R = c->sub_count(), n = c->n;
     if (!c->ev_accumulate) c->ev_used = 0;
     c->ev_call_start = c->ev_used;
     c->launches_sweep = 0;
@@ -533,51 +599,61 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
     c->stat_levels = 0;
     c->stats_pending = false;
     c->strace_nrec = 0;
+    c->strace_rows = 0;
     if (R == 0 || n_sweeps == 0) return NLMC_OK;
-    const bool want_min = o.out_min_energy || o.out_argmin || o.out_argmin_state;
+    { int rc = ensure_subset(c); if (rc) return rc; }
+    // running minimum + argmin state: asked for through host outputs, or kept on the device for the hand-off between NMC
+    // phases (nlmc_track_minimum; NMC/nmc.py:394-395)
+    const bool want_min = o.out_min_energy || o.out_argmin || o.out_argmin_state || c->track_min;
+    const bool want_state = o.out_argmin_state || c->track_min;
     c->stat_fused_window = -1;
     const int rec = o.out_spins ? std::max(1, o.record_stride) : 0;
     const int n_rec = rec ? (n_sweeps + rec - 1) / rec : 0;
     const bool any_out = o.out_spins || o.out_energy || want_min;
     // Fused-window schedule: planned ahead (nlmc_plan_philox_fused), same results.  Calls without per-sweep outputs
-    // and with one temperature per chain take the plain variant, one window per call; calls WITH outputs (energy trace,
-    // running minimum / argmin state, recorded configurations) or a temperature per sweep take the output variant, any
-    // whole number of planned windows per call, when its three snapshot slots fit in LDS next to the rest.
+    // and with one temperature per chain take the plain variant; calls WITH outputs (energy trace, running minimum /
+    // argmin state, recorded configurations) or a temperature per sweep take the output variant when its three snapshot
+    // slots fit in LDS next to the rest; any whole number of planned windows per call either way.
+    int fslot = -1;
     bool fused_out = false;
-    if (!stream_mode && precision == NLMC_F32 && order_mode == NLMC_ORDER_SHARED && c->fz_valid && c->fz_seed == seed &&
-        sweep0 >= c->fz_sweep0 && (sweep0 - c->fz_sweep0) % (uint32_t)c->fz_T == 0 && n_sweeps % c->fz_T == 0 &&
-        (uint64_t)(sweep0 - c->fz_sweep0) + (uint64_t)n_sweeps <= (uint64_t)c->fz_T * (uint64_t)c->fz_windows &&
-        !getenv("NLMC_NO_FUSED")) {
-        const int w0 = (int)((sweep0 - c->fz_sweep0) / (uint32_t)c->fz_T), nw = n_sweeps / c->fz_T;
-        bool all_ok = true;
-        for (int w = w0; w < w0 + nw; ++w) all_ok = all_ok && c->fz_nlev_host[w] > 0;
-        if (all_ok && !any_out && tab_ss == 0 && nw == 1)
-            return run_fused(c, w0, sweep0, seed, tab_dev, tab_cs, 0, use_slots, false, false, false, false, 0, 0, n_sweeps);
-        if (all_ok && (any_out || tab_ss != 0) && !getenv("NLMC_NO_FUSED_OUT") &&
-            fused_lds(c->n, c->n_pad, c->has_flags, true, c->fz_fmt == NLMC_FMT_ADDR).total <= (size_t)150 * 1024)
+    if (!stream_mode && precision == NLMC_F32 && order_mode == NLMC_ORDER_SHARED && !getenv("NLMC_NO_FUSED"))
+        fslot = fused_plan_for(c, sweep0, n_sweeps, seed);
+    if (fslot >= 0) {
+        const nlmc_ctx::FusedPlan &P = c->fz[fslot];
+        const int w0 = (int)((sweep0 - P.sweep0) / (uint32_t)P.T), nw = n_sweeps / P.T;
+        if (!any_out && tab_ss == 0) {
+            for (int j = 0; j < nw; ++j) {
+                int rc = run_fused(c, fslot, w0 + j, sweep0 + (uint32_t)(j * P.T), seed, tab_dev, tab_cs, 0, use_slots, false, false,
+                                   false, false, 0, 0, n_sweeps);
+                if (rc) return rc;
+            }
+            return NLMC_OK;
+        }
+        if (!getenv("NLMC_NO_FUSED_OUT") &&
+            fused_lds(c->n, c->n_pad, c->has_flags, true, P.fmt == NLMC_FMT_ADDR).total <= (size_t)150 * 1024)
             fused_out = true;
     }
     if (o.out_energy) HIP_TRY(c, c->etrace.reserve((size_t)R * n_sweeps));
     if (rec) HIP_TRY(c, c->strace.reserve((size_t)R * n_rec * n));
     c->strace_nrec = n_rec;
+    c->strace_rows = rec ? R : 0;
     if (want_min) {
-        std::vector<long long> init((size_t)R, LLONG_MAX);
-        HIP_TRY(c, hipMemcpyAsync(c->emin.p, init.data(), sizeof(long long) * R, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->argmin.p, 0, sizeof(int32_t) * R, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));   // `init` is a stack-lifetime host buffer
+        hipLaunchKernelGGL(k_fill_min, dim3((R + 255) / 256), dim3(256), 0, c->stream, R, c->sub_list(), c->emin.p, c->argmin.p);
+        HIP_TRY(c, hipGetLastError());
     }
     if (fused_out) {
-        const int w0 = (int)((sweep0 - c->fz_sweep0) / (uint32_t)c->fz_T), nw = n_sweeps / c->fz_T;
+        const nlmc_ctx::FusedPlan &P = c->fz[fslot];
+        const int w0 = (int)((sweep0 - P.sweep0) / (uint32_t)P.T), nw = n_sweeps / P.T;
         for (int j = 0; j < nw; ++j) {
-            int rc = run_fused(c, w0 + j, sweep0 + (uint32_t)(j * c->fz_T), seed, tab_dev + (size_t)j * c->fz_T * tab_ss, tab_cs,
-                               tab_ss, use_slots, true, o.out_energy != nullptr, want_min, o.out_argmin_state != nullptr, rec,
-                               j * c->fz_T, n_sweeps);
+            int rc = run_fused(c, fslot, w0 + j, sweep0 + (uint32_t)(j * P.T), seed, tab_dev + (size_t)j * P.T * tab_ss, tab_cs,
+                               tab_ss, use_slots, true, o.out_energy != nullptr, want_min, want_state, rec, j * P.T, n_sweeps);
             if (rc) return rc;
         }
         return read_sweep_outputs(c, o, n_sweeps, rec, n_rec);
     }
 
     const int per_chain = (stream_mode || order_mode == NLMC_ORDER_PER_CHAIN) ? 1 : 0;
+    if (per_chain && c->subset != 0) return fail(c, NLMC_ERR_UNSUPPORTED, "chain subsets run shared-order philox sweeps only");
     // plan cache hit?
     const bool f64 = stream_mode || precision == NLMC_F64;
     const int ell_mode = stream_mode ? 0 : (f64 ? 2 : 1);
@@ -646,6 +722,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         SweepArgs a{};
         a.g = c->g;
         a.chain_base = c->chain_base;
+        a.chain_list = c->sub_list();
         a.spins = c->spins.p;
         a.flags = c->has_flags ? c->flags.p : nullptr;
         a.temp_x = c->temp_x;
@@ -679,7 +756,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         a.strace = rec ? c->strace.p : nullptr;
         a.emin = want_min ? c->emin.p : nullptr;
         a.argmin = c->argmin.p;
-        a.best = (want_min && o.out_argmin_state) ? c->best.p : nullptr;
+        a.best = (want_min && want_state) ? c->best.p : nullptr;
 #ifdef NLMC_STAMPS
         HIP_TRY(c, c->dbg.reserve((size_t)R * 16 * 8 + 96));
         HIP_TRY(c, hipMemsetAsync(c->dbg.p, 0, ((size_t)R * 16 * 8 + 96) * sizeof(long long), c->stream));
@@ -745,7 +822,7 @@ extern "C" {
 static int ensure_adjacency(nlmc_ctx *c);
 int nlmc_pt_check(nlmc_ctx *c);
 
-int nlmc_abi_version(void) { return 1; }
+int nlmc_abi_version(void) { return NLMC_ABI_VERSION; }
 
 int nlmc_device_count(void)
 {
@@ -923,8 +1000,8 @@ void nlmc_destroy(nlmc_ctx *c)
     c->spins.release(); c->best.release(); c->flags.release(); c->efix.release(); c->emin.release(); c->etrace.release();
     c->argmin.release(); c->energy.release(); c->tab.release(); c->ustream.release(); c->etrace_d.release();
     c->keys.release(); c->strace.release(); c->cfg.release(); c->scratch.release(); c->plan.release();
-    c->fz_glv.release(); c->fz_perm.release(); c->fz_adj.release(); c->fz_stats.release(); c->fz_head.release(); c->fz_ell.release(); c->fz_loff.release(); c->fz_nlev.release();
-    c->fz_himax.release(); c->fz_send.release(); c->fz_npos.release();
+    c->slot_mark.release(); c->sub_list_buf.release(); c->cmask.release(); c->nmc_status.release(); c->nmc_thr.release();
+    c->fz_glv.release(); c->fz_perm.release(); c->fz_adj.release(); c->fz_stats.release(); c->fz[0].release(); c->fz[1].release();
     c->lbp_src.release(); c->lbp_rev.release(); c->lbp_flag.release(); c->lbp_out_i.release(); c->lbp_tJ.release();
     c->lbp_eps.release(); c->lbp_ms.release(); c->lbp_lams.release(); c->lbp_w0.release(); c->lbp_w1.release();
     c->lbp_bar.release(); c->lbp_part.release();
@@ -1051,7 +1128,7 @@ int nlmc_energy_of_recorded(nlmc_ctx *c, int first, int count, double *out)
     if (first + count > c->strace_nrec)
         return fail(c, NLMC_ERR_STATE, "nlmc_energy_of_recorded: the last sweep call recorded fewer configurations per chain");
     HIP_TRY(c, hipSetDevice(c->device));
-    const int64_t m = (int64_t)c->n_chains * count;
+    const int64_t m = (int64_t)c->strace_rows * count;
     if (m == 0) return NLMC_OK;
     HIP_TRY(c, c->etrace_d.reserve((size_t)m));
     EnergyArgs a{};
@@ -1097,6 +1174,7 @@ int nlmc_sweep_stream(nlmc_ctx *c, int n_sweeps, const int32_t *perm, const doub
         for (int t = 0; t < n_sweeps; ++t) tab[(size_t)r * n_sweeps + t] = beta[(size_t)r * chain_stride + (size_t)t * sweep_stride];
     HIP_TRY(c, c->keys.reserve(tot * n));
     HIP_TRY(c, c->ustream.reserve(tot * n));
+    c->tab_host.clear();
     HIP_TRY(c, c->tab.reserve(tot));
     HIP_TRY(c, hipMemcpyAsync(c->keys.p, rank.data(), sizeof(uint32_t) * tot * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->ustream.p, us.data(), sizeof(double) * tot * n, hipMemcpyHostToDevice, c->stream));
@@ -1120,8 +1198,10 @@ int nlmc_sweep_philox(nlmc_ctx *c, int precision, int order_mode, int n_sweeps, 
         return fail(c, NLMC_ERR_ARG, "nlmc_sweep_philox: bad argument");
     if (!beta && c->ladder_len == 0) return fail(c, NLMC_ERR_STATE, "nlmc_sweep_philox: beta == NULL needs nlmc_pt_init first");
     HIP_TRY(c, hipSetDevice(c->device));
-    const int R = c->n_chains;
+    const int R = c->sub_count();
     if (R == 0 || n_sweeps == 0) return NLMC_OK;
+    if (beta && chain_stride && c->subset != 0)
+        return fail(c, NLMC_ERR_UNSUPPORTED, "nlmc_sweep_philox: a per-chain beta table with a chain subset (use the ladder or one beta)");
     const double *tab_dev;
     int tcs, tss;
     bool use_slots = false;
@@ -1134,9 +1214,13 @@ int nlmc_sweep_philox(nlmc_ctx *c, int precision, int order_mode, int n_sweeps, 
                 tab[((size_t)r * T + t) * 2 + 0] = -2.0 * LOG2E * b;
                 tab[((size_t)r * T + t) * 2 + 1] = -2.0 * LOG2E * (b / c->temp_x);
             }
-        HIP_TRY(c, c->tab.reserve(tab.size()));
-        HIP_TRY(c, hipMemcpyAsync(c->tab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (tab != c->tab_host) {          // (the same table as last time -- every NMC phase of a run -- is not uploaded again)
+            HIP_TRY(c, c->tab.reserve(tab.size()));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));         // launches still reading the previous table
+            HIP_TRY(c, hipMemcpyAsync(c->tab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->tab_host.swap(tab);
+        }
         tab_dev = c->tab.p;
         tcs = chain_stride ? T * 2 : 0;
         tss = sweep_stride ? 2 : 0;
@@ -1193,16 +1277,17 @@ int nlmc_plan_philox(nlmc_ctx *c, int precision, int order_mode, uint32_t sweep0
 
 static int reserve_fused_plan(nlmc_ctx *c, int n_windows, int T)
 {
+    nlmc_ctx::FusedPlan &P = c->fz[c->fz_slot];
     const size_t W = (size_t)n_windows, TN = (size_t)T * c->n, PS = (size_t)fused_pstride(c->n, c->n_long, T);
     HIP_TRY(c, c->fz_glv.reserve(W * TN));
     HIP_TRY(c, c->fz_perm.reserve(W * PS));
-    HIP_TRY(c, c->fz_head.reserve(W * PS));
-    HIP_TRY(c, c->fz_ell.reserve(W * PS * NLMC_FZ_W));
-    HIP_TRY(c, c->fz_loff.reserve(W * (NLMC_LCAP + 1)));
-    HIP_TRY(c, c->fz_nlev.reserve(W));
-    HIP_TRY(c, c->fz_npos.reserve(W));
-    HIP_TRY(c, c->fz_himax.reserve(W));
-    HIP_TRY(c, c->fz_send.reserve(W * T));
+    HIP_TRY(c, P.head.reserve(W * PS));
+    HIP_TRY(c, P.ell.reserve(W * PS * NLMC_FZ_W));
+    HIP_TRY(c, P.loff.reserve(W * (NLMC_LCAP + 1)));
+    HIP_TRY(c, P.nlev.reserve(W));
+    HIP_TRY(c, P.npos.reserve(W));
+    HIP_TRY(c, P.himax.reserve(W));
+    HIP_TRY(c, P.send.reserve(W * T));
     return NLMC_OK;
 }
 
@@ -1212,7 +1297,7 @@ int nlmc_plan_reserve_fused(nlmc_ctx *c, int n_windows, int window)
     if (n_windows < 0 || window < 1) return fail(c, NLMC_ERR_ARG, "nlmc_plan_reserve_fused: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     if (n_windows == 0 || !fused_supported(c, window)) return NLMC_OK;
-    c->fz_valid = false;                          // (growing a buffer drops its contents)
+    c->fz[c->fz_slot].valid = false;              // (growing a buffer drops its contents)
     return reserve_fused_plan(c, n_windows, window);
 }
 
@@ -1221,30 +1306,31 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     if (!c) return NLMC_ERR_ARG;
     if (n_windows < 0 || window < 1) return fail(c, NLMC_ERR_ARG, "nlmc_plan_philox_fused: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
-    c->fz_valid = false;
+    nlmc_ctx::FusedPlan &P = c->fz[c->fz_slot];
+    P.valid = false;
     if (out_planned) *out_planned = 0;
     if (n_windows == 0 || !fused_supported(c, window)) return NLMC_OK;
     const int n = c->n, T = window;
     const size_t W = (size_t)n_windows;
-    c->fz_pstride = fused_pstride(n, c->n_long, T);
+    P.pstride = fused_pstride(n, c->n_long, T);
     { int rc = reserve_fused_plan(c, n_windows, T); if (rc) return rc; }
     { int rc = ensure_adjacency(c); if (rc) return rc; }
     FusedLevelizeArgs a{};
     a.g = c->g;
     a.T = T;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.sweep0 = sweep0;
-    c->fz_workers = fused_workers(fused_block(c->n));
-    c->fz_gen0 = fused_gen0(fused_block(c->n));
-    a.level_cap = c->fz_workers * 64;
-    a.pstride = c->fz_pstride;
+    P.workers = fused_workers(fused_block(c->n));
+    P.gen0 = fused_gen0(fused_block(c->n));
+    a.level_cap = P.workers * 64;
+    a.pstride = P.pstride;
     a.tab_words = c->n_pad;
     a.k_dummy = c->n_pad;
     a.fmt = fused_addr_format(c) ? NLMC_FMT_ADDR : c->compact16 ? NLMC_FMT_COMPACT : NLMC_FMT_WIDE;
     a.k_zero = c->n_pad + 8;
     a.neg_off = c->n_pad + 16;
-    c->fz_fmt = a.fmt;
-    a.adj = reinterpret_cast<const uint4 *>(c->fz_adj.p); a.glv = c->fz_glv.p; a.perm = c->fz_perm.p; a.head = c->fz_head.p; a.ell = c->fz_ell.p; a.loff = c->fz_loff.p; a.nlev = c->fz_nlev.p;
-    a.hi_max = c->fz_himax.p; a.send = c->fz_send.p; a.npos = c->fz_npos.p;
+    P.fmt = a.fmt;
+    a.adj = reinterpret_cast<const uint4 *>(c->fz_adj.p); a.glv = c->fz_glv.p; a.perm = c->fz_perm.p; a.head = P.head.p; a.ell = P.ell.p; a.loff = P.loff.p; a.nlev = P.nlev.p;
+    a.hi_max = P.himax.p; a.send = P.send.p; a.npos = P.npos.p;
     const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
     const size_t lds = (size_t)n * 8 + n4 * 2 + n4 + n4 * 2 + 2 * (size_t)(NLMC_LCAP + 2) * 4 + 16;
     { int rc = ensure_lds(c, 16, reinterpret_cast<const void *>(k_levelize_fused), lds); if (rc) return rc; }
@@ -1262,10 +1348,10 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     hipLaunchKernelGGL(k_levelize_fused, dim3(n_windows), dim3(1024), lds, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     if (pe0) HIP_TRY(c, hipEventRecord(pe2, c->stream));
-    c->fz_nlev_host.assign(W, 0);
-    c->fz_npos_host.assign(W, 0);
-    HIP_TRY(c, hipMemcpyAsync(c->fz_nlev_host.data(), c->fz_nlev.p, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->fz_npos_host.data(), c->fz_npos.p, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
+    P.nlev_host.assign(W, 0);
+    P.npos_host.assign(W, 0);
+    HIP_TRY(c, hipMemcpyAsync(P.nlev_host.data(), P.nlev.p, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(P.npos_host.data(), P.npos.p, sizeof(int32_t) * W, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (fz_diag) {
         long long st[8] = {0};
@@ -1273,9 +1359,9 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
         fprintf(stderr, "k_levelize_fused window 0 (cycles): keys %lld, init %lld, passes %lld (%lld passes), place-1 %lld, place-2 %lld\n", st[0], st[1], st[2], st[3], st[4], st[5]);
     }
     int ok = 0;
-    for (int32_t v : c->fz_nlev_host) ok += v > 0;
-    c->fz_valid = true;
-    c->fz_sweep0 = sweep0; c->fz_windows = n_windows; c->fz_T = T; c->fz_seed = seed;
+    for (int32_t v : P.nlev_host) ok += v > 0;
+    P.valid = true;
+    P.sweep0 = sweep0; P.windows = n_windows; P.T = T; P.seed = seed;
     if (out_planned) *out_planned = ok;
     return NLMC_OK;
 }
@@ -1332,8 +1418,8 @@ int nlmc_last_schedule_stats(nlmc_ctx *c, int64_t *n_orders, int64_t *n_levels)
     if (!c) return NLMC_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->stat_fused_window >= 0) {       // one merged level list for fz_T sweeps
-        if (n_orders) *n_orders = c->fz_T;
-        if (n_levels) *n_levels = c->fz_nlev_host[(size_t)c->stat_fused_window];
+        if (n_orders) *n_orders = c->fz[c->stat_fused_slot].T;
+        if (n_levels) *n_levels = c->fz[c->stat_fused_slot].nlev_host[(size_t)c->stat_fused_window];
         return NLMC_OK;
     }
     const int32_t *p = c->stats_pending ? c->stats_nlev_ptr : (c->plan_valid ? c->plan.nlev.p : nullptr);
@@ -1358,6 +1444,7 @@ int nlmc_pt_init(nlmc_ctx *c, int ladder_len, const double *beta_list)
     if (c->n_chains_global % ladder_len != 0) return fail(c, NLMC_ERR_ARG, "nlmc_pt_init: n_chains_global not a multiple of ladder_len");
     HIP_TRY(c, hipSetDevice(c->device));
     c->ladder_len = ladder_len;
+    c->subset = 0; c->n_marked_local = 0; c->sub_dirty = true;
     c->pt_tab_valid = false;
     c->pt_plan_valid = false;
     c->beta_list.assign(beta_list, beta_list + ladder_len);
@@ -1429,6 +1516,7 @@ int nlmc_pt_set_slots(nlmc_ctx *c, const int32_t *slot_of_chain)
         if (s < 0 || s >= L || cos[(size_t)(i / L) * L + s] != -1) return fail(c, NLMC_ERR_ARG, "nlmc_pt_set_slots: not a permutation per ladder");
         cos[(size_t)(i / L) * L + s] = i;
     }
+    c->sub_dirty = true;
     HIP_TRY(c, hipMemcpyAsync(c->slot_of_chain.p, slot_of_chain, sizeof(int32_t) * G, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->chain_of_slot.p, cos.data(), sizeof(int32_t) * G, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1443,6 +1531,7 @@ int nlmc_pt_apply_swap(nlmc_ctx *c, int ladder, int slot_a, int slot_b)
     if (ladder < 0 || ladder >= c->n_chains_global / L || slot_a < 0 || slot_a >= L || slot_b < 0 || slot_b >= L || slot_a == slot_b)
         return fail(c, NLMC_ERR_ARG, "nlmc_pt_apply_swap: bad ladder/slot");
     HIP_TRY(c, hipSetDevice(c->device));
+    c->sub_dirty = true;
     hipLaunchKernelGGL(k_pt_apply_swap, dim3(1), dim3(1), 0, c->stream, c->slot_of_chain.p, c->chain_of_slot.p, L, ladder, slot_a, slot_b);
     HIP_TRY(c, hipGetLastError());
     return NLMC_OK;
@@ -1485,6 +1574,7 @@ int nlmc_pt_swap_philox(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs,
     }
     // one lane per selected pair when the selection is planned (the in-kernel selection is written for ONE wave)
     const int swap_nt = a.plan_pairs ? std::min(256, (n_pairs + 63) / 64 * 64) : 64;
+    c->sub_dirty = true;
     hipLaunchKernelGGL(k_pt_swap, dim3(nl), dim3(std::max(64, swap_nt)), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     if (out_pairs || out_accepted) {
@@ -1731,17 +1821,11 @@ int nlmc_icm_round_ladders(nlmc_ctx *c, uint32_t round, uint64_t seed, int katzg
 // ------------------------------------------------------------------------------------------------------
 // convexified loopy belief propagation (backbone inference), batched over problems
 // ------------------------------------------------------------------------------------------------------
-int nlmc_lbp_convexified(nlmc_ctx *c, int n_problems, const double *m_star, const double *epsilon, const double *lambdas,
-                         int n_lambdas, double beta, double tolerance, int max_iterations, double sat,
-                         double *out_mag, double *out_mag_all, int32_t *out_n_lambdas, int32_t *out_iters,
-                         int32_t *out_status)
+// graph, buffers, constants of a batch of n_problems inferences; seeds (lbp_ms) are the caller's business
+static int lbp_setup(nlmc_ctx *c, int n_problems, const double *epsilon, const double *lambdas, int n_lambdas, double beta,
+                     bool want_all)
 {
-    if (!c) return NLMC_ERR_ARG;
-    if (n_problems < 1 || n_lambdas < 1 || !m_star || !epsilon || !lambdas || !out_mag || !out_n_lambdas || !out_iters ||
-        !out_status || max_iterations < 0 || !(beta != 0.0))
-        return fail(c, NLMC_ERR_ARG, "nlmc_lbp_convexified: bad sizes or NULL arrays");
     if (c->nnz > (int64_t)INT_MAX / 2) return fail(c, NLMC_ERR_UNSUPPORTED, "nlmc_lbp_convexified: nnz too large");
-    HIP_TRY(c, hipSetDevice(c->device));
     const int n = c->n, nnz = (int)c->nnz;
     const size_t P = (size_t)n_problems, E = (size_t)std::max(nnz, 1);
     if (!c->lbp_graph_ready) {
@@ -1772,23 +1856,42 @@ int nlmc_lbp_convexified(nlmc_ctx *c, int n_problems, const double *m_star, cons
     HIP_TRY(c, c->lbp_tot.reserve(P * n));
     HIP_TRY(c, c->lbp_mag.reserve(P * n));
     HIP_TRY(c, c->lbp_out_i.reserve(P * (2 + (size_t)n_lambdas)));
-    if (out_mag_all) HIP_TRY(c, c->lbp_mag_all.reserve(P * (size_t)n_lambdas * n));
-    HIP_TRY(c, hipMemcpyAsync(c->lbp_eps.p, epsilon, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->lbp_ms.p, m_star, sizeof(double) * P * n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->lbp_lams.p, lambdas, sizeof(double) * n_lambdas, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->lbp_mag.p, 0, sizeof(double) * P * n, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->lbp_out_i.p, 0, sizeof(int32_t) * P * (2 + (size_t)n_lambdas), c->stream));
-    if (nnz > 0) {
+    if (want_all) HIP_TRY(c, c->lbp_mag_all.reserve(P * (size_t)n_lambdas * n));
+    // constants of the run: uploaded when they change only (a replica-exchange run infers backbones once per round with the
+    // same epsilon, lambda list and beta: no host synchronisation on that path)
+    const std::vector<double> eps_h(epsilon, epsilon + n), lam_h(lambdas, lambdas + n_lambdas);
+    if (eps_h != c->lbp_eps_host || lam_h != c->lbp_lams_host) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->lbp_eps.p, eps_h.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->lbp_lams.p, lam_h.data(), sizeof(double) * n_lambdas, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->lbp_eps_host = eps_h;
+        c->lbp_lams_host = lam_h;
+    }
+    if (nnz > 0 && (!c->lbp_tJ_valid || c->lbp_tJ_beta != beta)) {
         hipLaunchKernelGGL(k_lbp_tanhJ, dim3((nnz + 255) / 256), dim3(256), 0, c->stream, nnz, c->val64.p, beta, c->lbp_tJ.p);
         HIP_TRY(c, hipGetLastError());
+        c->lbp_tJ_valid = true;
+        c->lbp_tJ_beta = beta;
     }
+    return NLMC_OK;
+}
+
+// the batched lambda loop on the seeds in lbp_ms (stream-ordered, no synchronisation)
+static int lbp_launch(nlmc_ctx *c, int n_problems, int n_lambdas, double beta, double tolerance, int max_iterations, double sat,
+                      bool want_all)
+{
+    const int n = c->n, nnz = (int)c->nnz;
+    const size_t P = (size_t)n_problems;
+    HIP_TRY(c, hipMemsetAsync(c->lbp_mag.p, 0, sizeof(double) * P * n, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->lbp_out_i.p, 0, sizeof(int32_t) * P * (2 + (size_t)n_lambdas), c->stream));
     LbpArgs a{};
     a.n = n; a.nnz = nnz; a.n_lams = n_lambdas; a.max_iter = max_iterations;
     a.rowptr = c->rowptr.p; a.col = c->col.p; a.src = c->lbp_src.p; a.rev = c->lbp_rev.p;
     a.val = c->val64.p; a.tJ = c->lbp_tJ.p; a.h = c->h64.p; a.eps = c->lbp_eps.p; a.m_star = c->lbp_ms.p; a.lams = c->lbp_lams.p;
     a.beta = beta; a.inv_beta = 1.0 / beta; a.tol = tolerance; a.sat = sat; a.usat = std::atanh(sat) / beta;
     a.w0 = c->lbp_w0.p; a.w1 = c->lbp_w1.p; a.hm = c->lbp_hm.p; a.tot = c->lbp_tot.p; a.mag = c->lbp_mag.p;
-    a.mag_all = out_mag_all ? c->lbp_mag_all.p : nullptr;
+    a.mag_all = want_all ? c->lbp_mag_all.p : nullptr;
     a.out_nlam = c->lbp_out_i.p; a.out_status = c->lbp_out_i.p + P; a.out_iters = c->lbp_out_i.p + 2 * P;
     // Workgroups per problem (a problem is bound by the fp64 VALU of the CUs it runs on): up to 8 when FEW problems
     // are in flight and each has work for them.  The group barrier costs two agent-scope fences per iteration, and L2
@@ -1807,6 +1910,24 @@ int nlmc_lbp_convexified(nlmc_ctx *c, int n_problems, const double *m_star, cons
     a.bar = c->lbp_bar.p; a.part = c->lbp_part.p;
     hipLaunchKernelGGL(k_lbp, dim3(n_problems * group), dim3(NLMC_LBP_THREADS), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
+    return NLMC_OK;
+}
+
+int nlmc_lbp_convexified(nlmc_ctx *c, int n_problems, const double *m_star, const double *epsilon, const double *lambdas,
+                         int n_lambdas, double beta, double tolerance, int max_iterations, double sat,
+                         double *out_mag, double *out_mag_all, int32_t *out_n_lambdas, int32_t *out_iters,
+                         int32_t *out_status)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (n_problems < 1 || n_lambdas < 1 || !m_star || !epsilon || !lambdas || !out_mag || !out_n_lambdas || !out_iters ||
+        !out_status || max_iterations < 0 || !(beta != 0.0))
+        return fail(c, NLMC_ERR_ARG, "nlmc_lbp_convexified: bad sizes or NULL arrays");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int n = c->n;
+    const size_t P = (size_t)n_problems;
+    { int rc = lbp_setup(c, n_problems, epsilon, lambdas, n_lambdas, beta, out_mag_all != nullptr); if (rc) return rc; }
+    HIP_TRY(c, hipMemcpyAsync(c->lbp_ms.p, m_star, sizeof(double) * P * n, hipMemcpyHostToDevice, c->stream));
+    { int rc = lbp_launch(c, n_problems, n_lambdas, beta, tolerance, max_iterations, sat, out_mag_all != nullptr); if (rc) return rc; }
     std::vector<int32_t> oi(P * (2 + (size_t)n_lambdas));
     HIP_TRY(c, hipMemcpyAsync(oi.data(), c->lbp_out_i.p, sizeof(int32_t) * oi.size(), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(out_mag, c->lbp_mag.p, sizeof(double) * P * n, hipMemcpyDeviceToHost, c->stream));
@@ -1818,6 +1939,161 @@ int nlmc_lbp_convexified(nlmc_ctx *c, int n_problems, const double *m_star, cons
     std::memcpy(out_n_lambdas, oi.data(), sizeof(int32_t) * P);
     std::memcpy(out_status, oi.data() + P, sizeof(int32_t) * P);
     std::memcpy(out_iters, oi.data() + 2 * P, sizeof(int32_t) * P * (size_t)n_lambdas);
+    return NLMC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// replica-exchange rounds whose marked temperature slots run NMC cycles: chain subsets, device-side hand-offs
+// ------------------------------------------------------------------------------------------------------
+int nlmc_pt_mark_slots(nlmc_ctx *c, const uint8_t *marks)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (c->ladder_len == 0) return fail(c, NLMC_ERR_STATE, "nlmc_pt_mark_slots: call nlmc_pt_init first");
+    const int L = c->ladder_len;
+    if (c->chain_base % L != 0 || c->n_chains % L != 0)
+        return fail(c, NLMC_ERR_UNSUPPORTED, "nlmc_pt_mark_slots: every ladder must lie inside one context");
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<uint8_t> m((size_t)L, 0);
+    int k = 0;
+    if (marks) for (int r = 0; r < L; ++r) { m[(size_t)r] = marks[r] ? 1 : 0; k += m[(size_t)r]; }
+    HIP_TRY(c, c->slot_mark.reserve((size_t)L));
+    HIP_TRY(c, c->sub_list_buf.reserve((size_t)std::max(c->n_chains, 1)));
+    HIP_TRY(c, c->cmask.reserve((size_t)std::max(c->n_chains, 1) * c->n_pad));
+    HIP_TRY(c, c->nmc_status.reserve(1));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->slot_mark.p, m.data(), (size_t)L, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(c->nmc_status.p, 0, sizeof(int32_t)));
+    HIP_TRY(c, hipMemset(c->cmask.p, 0, (size_t)std::max(c->n_chains, 1) * c->n_pad));
+    c->n_marked_local = k * (c->n_chains / L);
+    c->subset = 0;
+    c->sub_dirty = true;
+    return NLMC_OK;
+}
+
+int nlmc_select_chains(nlmc_ctx *c, int which)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (which < NLMC_CHAINS_ALL || which > NLMC_CHAINS_MARKED) return fail(c, NLMC_ERR_ARG, "nlmc_select_chains: bad selector");
+    if (which != NLMC_CHAINS_ALL && !c->slot_mark.p) return fail(c, NLMC_ERR_STATE, "nlmc_select_chains: call nlmc_pt_mark_slots first");
+    c->subset = which;
+    return NLMC_OK;
+}
+
+int nlmc_subset_count(const nlmc_ctx *c) { return c ? c->sub_count() : 0; }
+
+int nlmc_get_subset(nlmc_ctx *c, int32_t *out_chains)
+{
+    if (!c || !out_chains) return fail(c, NLMC_ERR_ARG, "nlmc_get_subset: NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int R = c->sub_count();
+    if (c->subset == 0) { for (int i = 0; i < R; ++i) out_chains[i] = i; return NLMC_OK; }
+    { int rc = ensure_subset(c); if (rc) return rc; }
+    HIP_TRY(c, hipMemcpyAsync(out_chains, c->sub_list(), sizeof(int32_t) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NLMC_OK;
+}
+
+int nlmc_track_minimum(nlmc_ctx *c, int on)
+{
+    if (!c) return NLMC_ERR_ARG;
+    c->track_min = on != 0;
+    return NLMC_OK;
+}
+
+int nlmc_adopt_best(nlmc_ctx *c)
+{
+    if (!c) return NLMC_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int R = c->sub_count();
+    if (R == 0) return NLMC_OK;
+    { int rc = ensure_subset(c); if (rc) return rc; }
+    hipLaunchKernelGGL(k_adopt_best, dim3(R), dim3(256), 0, c->stream, c->n_pad, c->sub_list(), c->spins.p, c->best.p, c->efix.p, c->emin.p);
+    HIP_TRY(c, hipGetLastError());
+    return NLMC_OK;
+}
+
+int nlmc_backbone_clusters(nlmc_ctx *c, const double *epsilon, const double *lambdas, int n_lambdas, double beta, double tolerance,
+                           int max_iterations, double sat, const double *thresholds, int n_thresholds)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (!epsilon || !lambdas || n_lambdas < 1 || !thresholds || n_thresholds < 1 || max_iterations < 0 || !(beta != 0.0))
+        return fail(c, NLMC_ERR_ARG, "nlmc_backbone_clusters: bad sizes or NULL arrays");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int P = c->sub_count();
+    if (P == 0) return NLMC_OK;
+    { int rc = ensure_subset(c); if (rc) return rc; }
+    { int rc = lbp_setup(c, P, epsilon, lambdas, n_lambdas, beta, false); if (rc) return rc; }
+    HIP_TRY(c, c->cmask.reserve((size_t)c->n_chains * c->n_pad));
+    HIP_TRY(c, c->nmc_status.reserve(1));
+    const std::vector<double> thr(thresholds, thresholds + n_thresholds);
+    if (thr != c->nmc_thr_host) {
+        HIP_TRY(c, c->nmc_thr.reserve((size_t)n_thresholds));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpy(c->nmc_thr.p, thr.data(), sizeof(double) * thr.size(), hipMemcpyHostToDevice));
+        c->nmc_thr_host = thr;
+    }
+    hipLaunchKernelGGL(k_lbp_seeds, dim3(P), dim3(256), 0, c->stream, c->n, c->n_pad, c->sub_list(), c->spins.p, c->lbp_ms.p);
+    HIP_TRY(c, hipGetLastError());
+    { int rc = lbp_launch(c, P, n_lambdas, beta, tolerance, max_iterations, sat, false); if (rc) return rc; }
+    hipLaunchKernelGGL(k_cluster_mask, dim3(P), dim3(256), (size_t)2 * c->n_pad, c->stream, c->g, c->sub_list(), c->lbp_mag.p,
+                       c->lbp_out_i.p + P, c->nmc_thr.p, n_thresholds, c->cmask.p, c->nmc_status.p);
+    HIP_TRY(c, hipGetLastError());
+    return NLMC_OK;
+}
+
+int nlmc_backbone_check(nlmc_ctx *c)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (!c->nmc_status.p) return NLMC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int32_t st = 0;
+    HIP_TRY(c, hipMemcpyAsync(&st, c->nmc_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (st != 0) {
+        HIP_TRY(c, hipMemset(c->nmc_status.p, 0, sizeof(int32_t)));
+        if (st & 2) return fail(c, NLMC_ERR_HIP, "nlmc_backbone_clusters: the workgroups of a problem lost each other (group barrier timed out)");
+        return fail(c, NLMC_ERR_ARG, "LBP diverged at initial lambda, please try a larger lambda_start or increase max_iterations or beta");
+    }
+    return NLMC_OK;
+}
+
+int nlmc_get_cluster_mask(nlmc_ctx *c, uint8_t *out)
+{
+    if (!c || !out) return fail(c, NLMC_ERR_ARG, "nlmc_get_cluster_mask: NULL argument");
+    if (!c->cmask.p) return fail(c, NLMC_ERR_STATE, "nlmc_get_cluster_mask: no backbone inference has run");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->n_chains == 0) return NLMC_OK;
+    int rc = rows_to_host_begin(c, c->cmask.p, c->n_chains);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    rows_to_host_finish(c, out, c->n_chains);
+    return NLMC_OK;
+}
+
+int nlmc_set_phase(nlmc_ctx *c, int kind, double temp_x)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (kind < NLMC_PHASE_ALL || kind > NLMC_PHASE_BACKBONE_FROZEN) return fail(c, NLMC_ERR_ARG, "nlmc_set_phase: bad phase");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (kind == NLMC_PHASE_ALL) { c->has_flags = false; return NLMC_OK; }     // (temp_x stays: the uploaded temperature tables stay valid)
+    if (!(temp_x > 0.0) && !(temp_x < 0.0)) return fail(c, NLMC_ERR_ARG, "nlmc_set_phase: temp_x must be non-zero");
+    if (!c->cmask.p) return fail(c, NLMC_ERR_STATE, "nlmc_set_phase: no backbone inference has run");
+    const int R = c->sub_count();
+    if (R > 0) {
+        { int rc = ensure_subset(c); if (rc) return rc; }
+        hipLaunchKernelGGL(k_phase_flags, dim3(R), dim3(256), 0, c->stream, c->n_pad, c->sub_list(), c->cmask.p, kind, c->flags.p);
+        HIP_TRY(c, hipGetLastError());
+    }
+    c->has_flags = true;
+    c->temp_x = temp_x;
+    return NLMC_OK;
+}
+
+int nlmc_plan_slot(nlmc_ctx *c, int slot)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (slot < 0 || slot > 1) return fail(c, NLMC_ERR_ARG, "nlmc_plan_slot: slot must be 0 or 1");
+    c->fz_slot = slot;
     return NLMC_OK;
 }
 

@@ -539,6 +539,8 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
 struct SweepArgs {
     CsrDev g;
     int chain_base;
+    const int32_t *chain_list; // launch over a SUBSET of the context's chains: block b runs local chain chain_list[b] (state rows
+                              // and RNG use the chain id, recorded traces / energy traces are dense in b); nullptr: block b = chain b
     int8_t *spins;            // [n_chains][n_pad]
     const uint8_t *flags;     // [n_chains][n_pad] or nullptr
     double temp_x;
@@ -600,7 +602,7 @@ struct ChainCtx {
     int8_t *s;
     uint8_t *fl;
     long long *red;
-    int tid, nt, c, n, n_pad;
+    int tid, nt, c, ob, n, n_pad;   // c: local chain id (state rows, RNG), ob: block index (rows of the recorded outputs)
     int ustride;              // fused schedule: bytes between the uniform tables of consecutive table slots
     long long e_loc, E, Emin;
     int amin;
@@ -613,7 +615,8 @@ __device__ __forceinline__ void chain_load(const SweepArgs &a, unsigned char *ld
     x.lvl_t = nullptr;
     x.ustride = a.lds_u_stride;
     x.n = a.g.n; x.n_pad = a.g.n_pad;
-    x.tid = threadIdx.x; x.nt = blockDim.x; x.c = blockIdx.x;
+    x.tid = threadIdx.x; x.nt = blockDim.x; x.ob = blockIdx.x;
+    x.c = a.chain_list ? a.chain_list[blockIdx.x] : (int)blockIdx.x;
     x.s = reinterpret_cast<int8_t *>(lds_raw);
     x.fl = a.flags ? (lds_raw + a.lds_flags_off) : nullptr;
     x.red = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);   // [0] sweep sum, [1] broadcast flag
@@ -647,7 +650,7 @@ __device__ __forceinline__ void sweep_epilogue(const SweepArgs &a, ChainCtx &x, 
         if (x.tid == 0) {
             x.E += x.red[0];
             x.red[0] = 0;
-            if (a.etrace) a.etrace[(size_t)x.c * a.trace_sweeps + tg] = x.E;
+            if (a.etrace) a.etrace[(size_t)x.ob * a.trace_sweeps + tg] = x.E;
             int better = 0;
             if (a.emin && x.E < x.Emin) { x.Emin = x.E; x.amin = tg; better = 1; }   // strict <: first argmin (np.argmin)
             x.red[1] = better;
@@ -661,7 +664,7 @@ __device__ __forceinline__ void sweep_epilogue(const SweepArgs &a, ChainCtx &x, 
     }
     if (rec) {
         const int n_rec = (a.trace_sweeps + a.rec_stride - 1) / a.rec_stride;
-        int8_t *dst = a.strace + ((size_t)x.c * n_rec + (size_t)(tg / a.rec_stride)) * x.n;
+        int8_t *dst = a.strace + ((size_t)x.ob * n_rec + (size_t)(tg / a.rec_stride)) * x.n;
         for (int i = x.tid; i < x.n; i += x.nt) dst[i] = x.s[i];
     }
     if (x.per_sweep || rec) __syncthreads();   // LDS spins / red[1] are rewritten next sweep
@@ -1156,7 +1159,7 @@ __global__ void k_sweep_philox(SweepArgs a)
     const bool dbuf = a.lds_u_stride != 0;
     bool prefilled = false;
     for (int t = 0; t < a.n_sweeps; ++t) {
-        const int oid = a.per_chain ? (c * a.n_sweeps + t) : t;
+        const int oid = a.per_chain ? (x.ob * a.n_sweeps + t) : t;
         const int32_t *__restrict__ off = a.lvl_off + (size_t)oid * (n + 1);
         const int nl = a.nlev[oid];
         // "f32" mode: z = cb * (X 2^-qs) with the int32 field X -> fold the exact power of two into the coefficient
@@ -1203,7 +1206,7 @@ __global__ void k_sweep_philox(SweepArgs a)
             // While wave 0 finishes the narrow tail of this sweep, the other waves prepare the next one in the second
             // set of LDS buffers: its uniforms (the Philox work of a whole sweep) and its level offsets.
             if (dbuf && t + 1 < a.n_sweeps) {
-                const int oid_n = a.per_chain ? (c * a.n_sweeps + t + 1) : (t + 1);
+                const int oid_n = a.per_chain ? (x.ob * a.n_sweeps + t + 1) : (t + 1);
                 const int nl_n = a.nlev[oid_n];
                 const bool wave0_busy = n_bar < nl;
                 if (nl_n < NLMC_LCAP && (!wave0_busy || nt > 64)) {
@@ -1385,7 +1388,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
     NLMC_GEN_ARM(a, gp)
     typedef const int32_t __attribute__((address_space(4))) *const_i32o;
     typedef const double __attribute__((address_space(4))) *const_f64o;
-    const int o_npad = a.g.n_pad, o_c = blockIdx.x, o_tid = wv * 64 + lane;
+    const int o_npad = a.g.n_pad, o_b = blockIdx.x, o_c = a.chain_list ? a.chain_list[o_b] : o_b, o_tid = wv * 64 + lane;
     int o_t = 0, o_end = 0;                                // older live sweep and its last level
     unsigned o_lo = 0u;                                    // its threshold-word range is [o_lo, o_lo + n_pad)
     long long e_new = 0, E_run = 0, E_min = 0;
@@ -1545,7 +1548,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
         if (better_) { E_min = E_run; a_min = tg_; }                                                                    \
         if (o_tid == 0) {                                                                                               \
             red_[(o_t + 2) % 3] = 0;                          /* read a sweep ago, next used two sweeps from now */      \
-            if (a.etrace) a.etrace[(size_t)o_c * a.trace_sweeps + tg_] = E_run;                                         \
+            if (a.etrace) a.etrace[(size_t)o_b * a.trace_sweeps + tg_] = E_run;                                         \
         }                                                                                                               \
         const unsigned char *snap_ = lds_raw + a.lds_snap_off + (size_t)slot_ * o_npad;                                 \
         if (better_ && a.best) {                                                                                        \
@@ -1555,7 +1558,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
         }                                                                                                               \
         if (a.strace && tg_ % a.rec_stride == 0) {            /* M[:, ::M_skip]  (NMC/nmc.py:390) */                     \
             const int n_rec_ = (a.trace_sweeps + a.rec_stride - 1) / a.rec_stride;                                      \
-            int8_t *dst_ = a.strace + ((size_t)o_c * n_rec_ + (size_t)(tg_ / a.rec_stride)) * a.g.n;                   \
+            int8_t *dst_ = a.strace + ((size_t)o_b * n_rec_ + (size_t)(tg_ / a.rec_stride)) * a.g.n;                   \
             for (int i_ = o_tid; i_ < a.g.n; i_ += a.f_workers * 64) dst_[i_] = (int8_t)snap_[i_];                      \
         }                                                                                                               \
         e_loc = e_new; e_new = 0;                                                                                       \
@@ -1622,7 +1625,8 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     if ((unsigned)reinterpret_cast<size_t>(lds_raw) != 0u) __builtin_trap();   // spins at LDS offset 0: column == address
-    const int n = a.g.n, n_pad = a.g.n_pad, tid = threadIdx.x, nt = blockDim.x, c = blockIdx.x;
+    const int n = a.g.n, n_pad = a.g.n_pad, tid = threadIdx.x, nt = blockDim.x;
+    const int c = a.chain_list ? a.chain_list[blockIdx.x] : (int)blockIdx.x;      // local chain id (state rows, RNG)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     float *ur = reinterpret_cast<float *>(lds_raw + a.lds_u_off);
     long long *red = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);
@@ -1703,7 +1707,7 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
         const unsigned warm_lines_p = a.warm_head ? (unsigned)(((size_t)a.fz_pstride * 16 + 127) / 128) : 0u;     // lines per plane
         const unsigned warm_used_p = a.warm_head ? (unsigned)(((size_t)a.fz_npos_next * 16 + 127) / 128) : 0u;     // touched lines per plane
         const unsigned warm_total = warm_lines + (a.fz_fmt == NLMC_FMT_ADDR ? 1u : a.fz_fmt == NLMC_FMT_COMPACT ? 2u : 4u) * warm_used_p;
-        unsigned warm_at = (unsigned)c * (unsigned)hcnt + (unsigned)hid;
+        unsigned warm_at = (unsigned)blockIdx.x * (unsigned)hcnt + (unsigned)hid;
         const unsigned warm_step = gridDim.x * (unsigned)hcnt;
         // four touches in flight (a touch of a cold line takes longer than a level: waiting for the previous one every
         // level made these waves the last to reach the barrier)
@@ -1762,7 +1766,7 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
         }
     }
 #ifdef NLMC_STAMPS
-    if (a.dbg && lane == 0) a.dbg[((size_t)c * 16 + wv) * 8 + 7] = (long long)__builtin_readcyclecounter() - st_begin;
+    if (a.dbg && lane == 0) a.dbg[((size_t)blockIdx.x * 16 + wv) * 8 + 7] = (long long)__builtin_readcyclecounter() - st_begin;
 #endif
 }
 

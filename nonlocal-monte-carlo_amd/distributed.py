@@ -137,32 +137,101 @@ class LocalTempering:
             raise
         self.sweeps_done = self.rounds_done = 0
         self._planners = None
+        self.nmc = None
+        self._nmc_planners = None
 
     def set_spins(self, spins_global):
         for e, (base, count) in zip(self.engs, self.parts):
             e.set_spins(np.asarray(spins_global)[base:base + count])
 
+    def configure_nmc(self, doNMC, phases, sweeps_per_phase, global_beta, temp_x, epsilon, lambdas, tolerance, max_iterations,
+                      sat, thresholds):
+        """Temperature slots with doNMC run NMC_task instead of MCMC_task every round (NPT/npt.py:622-647): backbone inference
+        seeded with the chain's state, then `phases` ("C" / "NC" / "ALL") of `sweeps_per_phase` sweeps at `global_beta`,
+        each starting from the argmin-energy configuration of the one before (NPT/npt.py:357-477).  Everything stays on the
+        device (include/nlmc.h: nlmc_pt_mark_slots ... nlmc_set_phase)."""
+        marks = np.asarray(doNMC).astype(bool)
+        if not marks.any():
+            self.nmc = None
+            return
+        for e in self.engs:
+            e.mark_slots(marks)
+        self.nmc = dict(phases=list(phases), S=int(sweeps_per_phase), beta=float(global_beta), temp_x=float(temp_x),
+                        epsilon=np.asarray(epsilon, dtype=np.float64), lambdas=np.asarray(lambdas, dtype=np.float64),
+                        tol=float(tolerance), max_it=int(max_iterations), sat=float(sat),
+                        thresholds=np.asarray(thresholds, dtype=np.float64))
+
+    def sweeps_per_round(self, n_sweeps):
+        """Sweep indices (RNG counters) one round of `n_sweeps` plain sweeps consumes: the plain chains' plus the NMC phases'."""
+        return n_sweeps + (len(self.nmc["phases"]) * self.nmc["S"] if self.nmc else 0)
+
     def plan(self, n_sweeps, n_rounds, chunk_rounds=None):
-        self._planners = [RoundPlanner(e, self.sweeps_done, n_rounds, n_sweeps // max(1, n_rounds), self.seed,
+        S = n_sweeps // max(1, n_rounds)
+        self._planners = [RoundPlanner(e, self.sweeps_done, n_rounds, S, self.seed,
                                        precision=self.precision, budget_bytes=8 << 30, chunk_rounds=chunk_rounds,
-                                       pt_pairs=self.n_pairs, pt_round0=self.rounds_done) for e in self.engs]
+                                       pt_pairs=self.n_pairs, pt_round0=self.rounds_done, slot=0, fused_outputs=True) for e in self.engs]
         self._planner_round0 = self.rounds_done
+        self._nmc_planners = None
+        if self.nmc:
+            # the NMC phases draw from their own range of sweep indices, behind the plain sweeps of all planned rounds: both
+            # ranges are contiguous over the rounds, so each is served by one fused-window plan (slots 0 and 1)
+            n_ph = len(self.nmc["phases"])
+            self._nmc_sweep0 = self.sweeps_done + n_rounds * S
+            self._nmc_planners = [RoundPlanner(e, self._nmc_sweep0, n_rounds * n_ph, self.nmc["S"], self.seed,
+                                               precision=self.precision, budget_bytes=4 << 30,
+                                               chunk_rounds=None if chunk_rounds is None else chunk_rounds * n_ph,
+                                               slot=1, beta=self.nmc["beta"], fused_outputs=True) for e in self.engs]
+            self._planned_rounds = n_rounds
 
     def log_begin(self, n_rounds):
         for e in self.engs:
             e.pt_log_begin(self.rounds_done, n_rounds, self.n_pairs)
 
-    def round(self, n_sweeps, **outputs):
+    def round(self, n_sweeps, energy_columns=0, **outputs):
         """Sweeps of every block (launched back to back: the devices work concurrently), then one swap round.  Returns
-        the per-context sweep outputs."""
+        the per-context sweep outputs; with NMC slots configured (configure_nmc) every entry is a dict
+        {"plain": outputs of the chains on plain slots, "plain_chains": their local ids, "nmc": [outputs per phase],
+        "nmc_chains": ids, "plain_energy_columns": fp64 energies of the first `energy_columns` recorded columns}."""
         ii = self.rounds_done - (self._planner_round0 if self._planners else 0)
         outs = []
+        wants = any(outputs.get(k) for k in ("record_stride", "want_energy", "want_min", "want_state"))
         for k, e in enumerate(self.engs):
+            if self.nmc:
+                e.set_phase("ALL")                   # (not set_flags(None): temp_x stays, so do the uploaded temperature tables)
+                e.select("unmarked")
             if self._planners and 0 <= ii < self._planners[k].R and n_sweeps == self._planners[k].S:
-                outs.append(self._planners[k].sweep(ii, **outputs))
+                o = self._planners[k].sweep(ii, **outputs)
             else:
-                outs.append(e.sweep_philox(n_sweeps, self.seed, sweep0=self.sweeps_done, beta=None, precision=self.precision,
-                                           **outputs))
+                o = e.sweep_philox(n_sweeps, self.seed, sweep0=self.sweeps_done, beta=None, precision=self.precision, **outputs)
+            if not self.nmc:
+                outs.append(o)
+                continue
+            rec = dict(plain=o, nmc=[])
+            if wants:
+                rec["plain_chains"] = e.subset()
+                if energy_columns and outputs.get("record_stride"):
+                    rec["plain_energy_columns"] = e.energy_of_recorded(energy_columns)
+            q = self.nmc
+            e.select("marked")
+            if wants:
+                rec["nmc_chains"] = e.subset()
+            e.backbone_clusters(q["epsilon"], q["lambdas"], q["beta"], q["tol"], q["max_it"], q["sat"], q["thresholds"])
+            e.track_minimum(True)
+            n_ph = len(q["phases"])
+            planned = self._nmc_planners is not None and 0 <= ii < self._planned_rounds
+            for p, kind in enumerate(q["phases"]):
+                if p > 0:
+                    e.adopt_best()                   # NPT/npt.py:436-437,454-455: the next phase starts from the argmin column
+                e.set_phase(kind, q["temp_x"])
+                if planned:
+                    rec["nmc"].append(self._nmc_planners[k].sweep(ii * n_ph + p, **outputs))
+                else:
+                    rec["nmc"].append(e.sweep_philox(q["S"], self.seed, sweep0=self.sweeps_done + n_sweeps + p * q["S"],
+                                                     beta=q["beta"], precision=self.precision, **outputs))
+            e.track_minimum(False)
+            e.set_phase("ALL")
+            e.select("all")
+            outs.append(rec)
         self.sweeps_done += n_sweeps
         if self.n_pairs > 0:
             if len(self.engs) == 1:
@@ -187,6 +256,9 @@ class LocalTempering:
         if self.n_pairs > 0:
             for e in self.engs:
                 e.pt_check()
+        if self.nmc:
+            for e in self.engs:
+                e.backbone_check()      # ValueError('LBP diverged at initial lambda ...') of NPT/npt.py:178-180
 
     def close(self):
         for e in self.engs:

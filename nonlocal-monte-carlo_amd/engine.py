@@ -135,15 +135,20 @@ class Engine:
         return out
 
     def energy_of_recorded(self, count, first=0):
-        """fp64 energies of recorded configurations first .. first+count-1 of every chain, taken from the device copy of
-        the trace of the most recent sweep call (`record_stride` > 0) -> [n_chains, count]."""
-        out = np.empty((self.n_chains, int(count)), dtype=np.float64)
+        """fp64 energies of recorded configurations first .. first+count-1 of every chain of the most recent sweep call
+        (`record_stride` > 0), taken from the device copy of its trace -> [rows of that call, count]."""
+        out = np.empty((getattr(self, "_last_rows", self.n_chains), int(count)), dtype=np.float64)
         self._ck(self._L.nlmc_energy_of_recorded(self._ctx, int(first), int(count), _abi.ptr(out)))
         return out
 
     # -- sweeps -----------------------------------------------------------------------------------------
+    def rows(self):
+        """Chains a sweep call acts on: all of them, or the selected subset (select())."""
+        return int(self._L.nlmc_subset_count(self._ctx))
+
     def _outputs(self, S, record_stride, want_energy, want_min, want_state):
-        R, n = self.n_chains, self.n
+        R, n = self.rows(), self.n
+        self._last_rows = R
         o = {}
         o["spins"] = np.empty((R, (S + record_stride - 1) // record_stride, n), np.int8) if record_stride else None
         o["energy"] = np.empty((R, S), np.float64) if want_energy else None
@@ -197,7 +202,7 @@ class Engine:
     def sweep_philox(self, n_sweeps, seed, sweep0=0, beta=None, precision="f32", order="shared", record_stride=0,
                      want_energy=False, want_min=False, want_state=False):
         """Throughput sweeps (device Philox).  beta: scalar | [R,S] table | None (= PT ladder)."""
-        R = self.n_chains
+        R = self.rows()
         S = int(n_sweeps)
         if beta is None:
             tabp, cs, ss = None, 0, 0
@@ -224,6 +229,10 @@ class Engine:
         self._ck(self._L.nlmc_plan_philox_fused(self._ctx, int(sweep0) & 0xFFFFFFFF, int(n_windows), int(window), int(seed),
                                                 ctypes.byref(k)))
         return int(k.value)
+
+    def plan_slot(self, slot):
+        """Fused-window plans live in two slots (include/nlmc.h: nlmc_plan_slot); planning calls write to the selected one."""
+        self._ck(self._L.nlmc_plan_slot(self._ctx, int(slot)))
 
     def plan_reserve_fused(self, n_windows, window):
         """Allocate the fused-window plan buffers for up to n_windows windows (no schedule is built)."""
@@ -284,6 +293,47 @@ class Engine:
     def pt_check(self):
         """ValueError("Cannot find non-overlapping pairs.") if a device-decided swap round ran out of pairs (NPT/npt.py:526)."""
         self._ck(self._L.nlmc_pt_check(self._ctx))
+
+    # -- rounds whose marked temperature slots run NMC cycles (include/nlmc.h) -----------------------------
+    def mark_slots(self, marks):
+        m = None if marks is None else _abi.as_c(np.asarray(marks).astype(bool), np.uint8).reshape(self.ladder_len)
+        self._ck(self._L.nlmc_pt_mark_slots(self._ctx, _abi.ptr(m)))
+
+    def select(self, which):
+        """Later sweep_philox / adopt_best / backbone_clusters / set_phase calls act on: "all" chains, or the local chains
+        currently on "unmarked" / "marked" temperature slots."""
+        w = {"all": _abi.CHAINS_ALL, "unmarked": _abi.CHAINS_UNMARKED, "marked": _abi.CHAINS_MARKED}[which]
+        self._ck(self._L.nlmc_select_chains(self._ctx, w))
+
+    def subset(self):
+        out = np.empty(self.rows(), dtype=np.int32)
+        self._ck(self._L.nlmc_get_subset(self._ctx, _abi.ptr(out)))
+        return out
+
+    def track_minimum(self, on=True):
+        self._ck(self._L.nlmc_track_minimum(self._ctx, int(bool(on))))
+
+    def adopt_best(self):
+        self._ck(self._L.nlmc_adopt_best(self._ctx))
+
+    def backbone_clusters(self, epsilon, lambdas, beta, tolerance, max_iterations, sat, thresholds):
+        eps = _abi.as_c(epsilon, np.float64).reshape(self.n)
+        lam = _abi.as_c(lambdas, np.float64).reshape(-1)
+        thr = _abi.as_c(thresholds, np.float64).reshape(-1)
+        self._ck(self._L.nlmc_backbone_clusters(self._ctx, _abi.ptr(eps), _abi.ptr(lam), lam.shape[0], float(beta), float(tolerance),
+                                                int(max_iterations), float(sat), _abi.ptr(thr), thr.shape[0]))
+
+    def backbone_check(self):
+        self._ck(self._L.nlmc_backbone_check(self._ctx))
+
+    def cluster_mask(self):
+        out = np.empty((self.n_chains, self.n), dtype=np.uint8)
+        self._ck(self._L.nlmc_get_cluster_mask(self._ctx, _abi.ptr(out)))
+        return out
+
+    def set_phase(self, kind, temp_x=1.0):
+        k = {"ALL": _abi.PHASE_ALL, "C": _abi.PHASE_BACKBONE_HOT, "NC": _abi.PHASE_BACKBONE_FROZEN}[kind]
+        self._ck(self._L.nlmc_set_phase(self._ctx, k, float(temp_x)))
 
     # -- iso-cluster move -------------------------------------------------------------------------------
     def icm_components(self, chain_a, chain_b):
@@ -411,8 +461,12 @@ class RoundPlanner:
     BYTES_PER_UPDATE = 140              # packed schedule: head 8 + row window 128 + scratch
 
     def __init__(self, eng, sweep0, n_rounds, sweeps_per_round, seed, precision="f32", budget_bytes=1 << 30,
-                 chunk_rounds=None, pt_pairs=0, pt_round0=0):
+                 chunk_rounds=None, pt_pairs=0, pt_round0=0, slot=0, beta=None, fused_outputs=False):
+        """`slot`: fused-plan slot of the engine this planner owns; `beta`: None = the ladder temperatures, or one inverse
+        temperature for every chain; `fused_outputs`: rounds with per-sweep outputs also run on fused windows (the
+        output variant of the kernel) when the plan covers them."""
         self.eng, self.sweep0, self.R, self.S, self.seed, self.precision = eng, int(sweep0), int(n_rounds), int(sweeps_per_round), int(seed), precision
+        self.slot, self.beta, self.fused_outputs = int(slot), beta, bool(fused_outputs)
         self.window = fused_window(self.S) if precision == "f32" else 0
         per_round = max(1, self.S * eng.n * self.BYTES_PER_UPDATE)
         self.chunk = max(1, min(self.R, int(budget_bytes // per_round)))
@@ -428,6 +482,8 @@ class RoundPlanner:
         if self.pt_pairs > 0 and hasattr(self.eng, "pt_plan"):
             self.eng.pt_plan(self.pt_round0 + r0, r1 - r0, self.seed, self.pt_pairs)
         if want_fused and self.window:
+            if hasattr(self.eng, "plan_slot"):
+                self.eng.plan_slot(self.slot)
             k = self.eng.plan_philox_fused(self.sweep0 + r0 * self.S, (r1 - r0) * (self.S // self.window), self.window, self.seed)
             if k == (r1 - r0) * (self.S // self.window):
                 self._fused_from, self._fused_to = r0, r1
@@ -440,20 +496,17 @@ class RoundPlanner:
 
     def sweep(self, ii, **outputs):
         """The sweeps of round ii at the PT ladder temperatures.  `outputs`: record_stride / want_* of sweep_philox."""
-        needs_plain = any(outputs.get(k) for k in ("record_stride", "want_energy", "want_min", "want_state"))
+        needs_plain = any(outputs.get(k) for k in ("record_stride", "want_energy", "want_min", "want_state")) and not self.fused_outputs
         if self.S == 0:
-            return self.eng.sweep_philox(0, self.seed, sweep0=self.sweep0, beta=None, precision=self.precision, **outputs)
+            return self.eng.sweep_philox(0, self.seed, sweep0=self.sweep0, beta=self.beta, precision=self.precision, **outputs)
         if not needs_plain and self.window:
             if not (self._fused_from <= ii < self._fused_to):
                 self._plan(ii, True)
-            if self._fused_from <= ii < self._fused_to:
-                o = None
-                for j in range(self.S // self.window):
-                    o = self.eng.sweep_philox(self.window, self.seed, sweep0=self.sweep0 + ii * self.S + j * self.window,
-                                              beta=None, precision=self.precision)
-                return o
+            if self._fused_from <= ii < self._fused_to:      # one call: the library walks the windows of the round
+                return self.eng.sweep_philox(self.S, self.seed, sweep0=self.sweep0 + ii * self.S, beta=self.beta,
+                                             precision=self.precision, **outputs)
         if not (self._plain_from <= ii < self._plain_to) and not needs_plain:
             self._plan(ii, False)
         # (a round with outputs outside the planned range builds its schedule inside the call)
-        return self.eng.sweep_philox(self.S, self.seed, sweep0=self.sweep0 + ii * self.S, beta=None, precision=self.precision,
+        return self.eng.sweep_philox(self.S, self.seed, sweep0=self.sweep0 + ii * self.S, beta=self.beta, precision=self.precision,
                                      **outputs)

@@ -9,9 +9,11 @@ program order (replica 1's sweeps, replica 2's, ..., then pair selection, then o
 after `np.random.seed(s); random.seed(s)` M, Energy and the swap log equal the reference run with its pool executed
 in order (the pool itself is not reproducible for num_cores > 1).
 
-rng="philox": throughput mode.  Without NMC replicas the whole run stays on the device: replica states never leave
-HBM, swaps are label exchanges decided by a kernel (include/nlmc.h: nlmc_pt_swap_philox), and only the last round's
-trace is read back for the return value.
+rng="philox": throughput mode.  The whole run stays on the device: replica states never leave HBM, swaps are label
+exchanges decided by a kernel (include/nlmc.h: nlmc_pt_swap_philox), replicas on doNMC slots run their NMC_task
+(backbone inference, phase flags, argmin hand-offs; include/nlmc.h: nlmc_pt_mark_slots ... nlmc_set_phase) without a host
+round trip, `num_restarts` independent ladders advance in the same launches, and only the last round's trace is read back
+for the return value.
 """
 import random as _pyrandom
 
@@ -72,8 +74,10 @@ class NPT(Common):
 
         Additive keyword arguments (defaults = the reference's behaviour): `num_restarts` independent ladders advanced
         together and `device_ids` (GPUs the chains are sharded over; the reference's knob is num_cores, NPT/npt.py:616)
-        -- both for rng="philox" runs without NMC replicas; M and Energy describe restart 0, `self.restart_energies`
-        [num_restarts, R] all of them.  `return_trace`: "float64" (reference dtype), "int8", or None (M is not built)."""
+        -- both for rng="philox" runs (with NMC replicas: M_skip == 1); M and Energy describe restart 0,
+        `self.restart_energies` [num_restarts, R] all of them.  `return_trace`: "float64" (reference dtype), "int8", or
+        None (M is not built).  Dynamics of the philox mode: 24-bit fixed-point couplings + logistic thresholds (DESIGN.md
+        section 2 states the tolerance); the argmin hand-off between NMC phases uses the energies tracked in that model."""
         self.num_replicas = num_replicas
         self.num_sweeps_MCMC = num_sweeps_MCMC
         self.num_sweeps_read = num_sweeps_read
@@ -94,14 +98,21 @@ class NPT(Common):
 
         if return_trace not in ("float64", "int8", None):
             raise ValueError("return_trace must be 'float64', 'int8' or None")
-        device_resident = self.rng == "philox" and not any(bool(v) for v in doNMC)
+        any_nmc = any(bool(v) for v in doNMC)
+        device_resident = self.rng == "philox" and (not any_nmc or M_skip == 1)
         if (int(num_restarts) != 1 or (device_ids is not None and len(list(device_ids)) > 1)) and not device_resident:
-            raise ValueError("num_restarts / device_ids need rng='philox' and no NMC replicas (the reference's own stream "
-                             "order has one ladder in one process)")
+            raise ValueError("num_restarts / device_ids need rng='philox' (and M_skip == 1 with NMC replicas): the "
+                             "reference's own stream order has one ladder in one process")
         if int(num_restarts) < 1:
             raise ValueError("num_restarts must be >= 1")
         if device_resident:
-            M, Energy = self._run_device_resident(beta_list, int(num_restarts), device_ids, return_trace)
+            nmc = None
+            if any_nmc:
+                nmc = dict(num_cycles=num_cycles, full_update_frequency=full_update_frequency, temp_x=temp_x,
+                           global_beta=global_beta, lambda_start=lambda_start, lambda_end=lambda_end,
+                           lambda_reduction_factor=lambda_reduction_factor, threshold_initial=threshold_initial,
+                           threshold_cutoff=threshold_cutoff, max_iterations=max_iterations, tolerance=tolerance)
+            M, Energy = self._run_device_resident(beta_list, int(num_restarts), device_ids, return_trace, nmc)
         else:
             M, Energy = self._run_host_managed(beta_list, num_cycles, full_update_frequency, M_skip, temp_x, global_beta,
                                                lambda_start, lambda_end, lambda_reduction_factor, threshold_initial,
@@ -256,11 +267,13 @@ class NPT(Common):
         return selected
 
     # ------------------------------------------------------------------------------------------------
-    def _run_device_resident(self, beta_list, n_restarts=1, device_ids=None, return_trace="float64"):
+    def _run_device_resident(self, beta_list, n_restarts=1, device_ids=None, return_trace="float64", nmc=None):
         """Throughput path: all replicas (x restarts) stay on the device(s); label-exchange swaps decided by a kernel; the
         swap log is kept on the device and read once; only the last round's trace comes back (as int8 until the
-        reference-shaped float64 M is asked for)."""
+        reference-shaped float64 M is asked for).  `nmc`: NMC_task parameters when some slots have doNMC set -- those
+        chains run backbone inference + the NMC phases inside every round, on the device (distributed.LocalTempering)."""
         from .distributed import LocalTempering
+        from .lbp import lambda_list, _SAT, EPS as _EPS
         inst = self._cache.instance(self.J, self.h)
         R, N = self.num_replicas, inst.n
         self._n = N
@@ -270,8 +283,26 @@ class NPT(Common):
         devs = [self._cache.device] if not device_ids else [int(d) for d in device_ids]
         if G % len(devs):
             raise ValueError("num_replicas * num_restarts must be a multiple of len(device_ids)")
+        if nmc and n_restarts % len(devs):
+            raise ValueError("with NMC replicas every ladder must lie on one device: num_restarts % len(device_ids) != 0")
+        phases, S_nmc = [], self.num_sweeps_per_NMC_phase_per_swap
+        if nmc:
+            for cycle in range(nmc["num_cycles"]):
+                phases += ["C", "NC"] + (["ALL"] if cycle % nmc["full_update_frequency"] == 0 else [])
+            if S > 0 and len(phases) * S_nmc < S:          # NPT/npt.py:643-644: M[block] = M_nmc[:, -S:] cannot be filled
+                raise ValueError(f"could not broadcast input array from shape ({N},{len(phases) * S_nmc}) into shape ({N},{S})")
+            lams = lambda_list(nmc["lambda_start"], nmc["lambda_end"], nmc["lambda_reduction_factor"])
+            if not lams:                # the reference's lambda loop never runs: find_clusters(None) raises TypeError there
+                raise TypeError("bad operand type for abs(): 'NoneType'")
+            thr, t = [float(nmc["threshold_initial"])], nmc["threshold_initial"] - 0.01     # NMC/nmc.py:300-316
+            while t > nmc["threshold_cutoff"]:
+                thr.append(float(t))
+                t -= 0.01
         lt = LocalTempering(inst, beta_list, G, self.seed, self.num_swapping_pairs, devs)
         try:
+            if nmc:
+                lt.configure_nmc(self.doNMC, phases, S_nmc, nmc["global_beta"], nmc["temp_x"], self._graph(inst).epsilon(inst.h),
+                                 lams, nmc["tolerance"], nmc["max_iterations"], _SAT - _EPS, thr)
             m0 = (2 * np.random.default_rng(self.seed).integers(0, 2, size=(G, N), dtype=np.int8) - 1).astype(np.int8)
             lt.set_spins(m0)
             lt.sweeps_done = self._sweep_counter
@@ -287,15 +318,23 @@ class NPT(Common):
                 if not is_last:
                     lt.round(S)
                 elif return_trace is not None:
-                    outs = lt.round(S, record_stride=1)
-                    last = outs[0]["spins"] if len(outs) == 1 else np.concatenate([o["spins"] for o in outs])  # [G, S, N] int8
-                    if 0 < k and S > 0:
-                        # replica_energy (NPT/npt.py:31-45, :685-692) of every replica: fp64 energies of the FIRST R_swap
-                        # recorded columns, computed on the device copy of the trace (one launch per context)
-                        E_cols = np.concatenate([e.energy_of_recorded(min(k, S)) for e in lt.engs])
+                    outs = lt.round(S, record_stride=1, energy_columns=min(k, S) if (0 < k and S > 0) else 0)
+                    if nmc:
+                        last, E_cols = self._assemble_mixed(lt, outs, S, N, min(k, S) if (0 < k and S > 0) else 0, "spins")
+                    else:
+                        last = outs[0]["spins"] if len(outs) == 1 else np.concatenate([o["spins"] for o in outs])  # [G, S, N] int8
+                        if 0 < k and S > 0:
+                            # replica_energy (NPT/npt.py:31-45, :685-692) of every replica: fp64 energies of the FIRST R_swap
+                            # recorded columns, computed on the device copy of the trace (one launch per context)
+                            E_cols = np.concatenate([e.energy_of_recorded(min(k, S)) for e in lt.engs])
                 else:
-                    e_last = np.concatenate([o["energy"] for o in lt.round(S, want_energy=True)])   # [G, S] tracked
-            self._sweep_counter += rounds * S
+                    outs = lt.round(S, want_energy=True)
+                    if nmc:
+                        e_last, _ = self._assemble_mixed(lt, outs, S, N, 0, "energy")
+                    else:
+                        e_last = np.concatenate([o["energy"] for o in outs])   # [G, S] tracked
+            self._sweep_counter += rounds * lt.sweeps_per_round(S)
+            lt.check()
             Energy = np.zeros(R)
             E_all = np.zeros((n_restarts, R))
             if last is not None and S > 0:
@@ -331,6 +370,24 @@ class NPT(Common):
         finally:
             lt.close()
         return M, Energy
+
+    @staticmethod
+    def _assemble_mixed(lt, outs, S, N, k, key):
+        """Last-round outputs of a ladder set with NMC slots -> per global chain: the block NPT.run keeps (NPT/npt.py:640-644):
+        the S sweeps of a plain replica, the LAST S columns of an NMC replica's phases laid end to end.  key "spins": returns
+        ([G, S, N] int8, fp64 energies of the first k columns [G, k] or None); key "energy": ([G, S] tracked energies, None)."""
+        G = lt.G
+        full = np.zeros((G, S, N), dtype=np.int8) if key == "spins" else np.zeros((G, S))
+        E_cols = np.zeros((G, k)) if (key == "spins" and k > 0) else None
+        for e, (base, _), rec in zip(lt.engs, lt.parts, outs):
+            pc, nc = rec["plain_chains"], rec["nmc_chains"]
+            full[base + pc] = rec["plain"][key]
+            tail = np.concatenate([o[key] for o in rec["nmc"]], axis=1)[:, -S:] if S > 0 else np.zeros_like(full[base + nc])
+            full[base + nc] = tail
+            if E_cols is not None:
+                E_cols[base + pc] = rec["plain_energy_columns"]
+                E_cols[base + nc] = e.energy_of(tail[:, :k]).reshape(len(nc), k)
+        return full, E_cols
 
     def plot_energies(self, EE1_list, beta_list):
         """NPT/npt.py:702-717 (presentation only)."""

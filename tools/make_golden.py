@@ -469,10 +469,42 @@ def gen_stats_min():
          num_sweeps_MCMC=nsw, num_swap_attempts=nswap, num_swapping_pairs=npairs, energies=E_all, min_energy=E_all.min(axis=1))
 
 
+def gen_stats_min_mixed():
+    """The same distribution with NMC replicas in the ladder (NPT/npt.py:622-647 submits NMC_task :479-512 for the doNMC
+    slots -- the house configuration runs the coldest replicas as NMC, NPT/examples/general_example.py:64-84): the two
+    coldest of six slots do backbone inference + the three NMC phases every swap round, 40 independent runs.  Also kept:
+    the backbone (cluster) sizes the reference printed, as a yardstick for the device-side inference."""
+    J, h = inst_pmj_sparse(96, 555)
+    R, nsw, nswap, npairs, runs = 6, 48, 6, 2, 40
+    doNMC = [False, False, False, False, True, True]
+    beta_list = np.linspace(0.3, 2.5, R)
+    kw = dict(num_cycles=1, full_update_frequency=1, M_skip=1, temp_x=20, global_beta=2.5, lambda_start=3.0, lambda_end=0.05,
+              lambda_reduction_factor=0.8, threshold_initial=0.9999, threshold_cutoff=0.97, max_iterations=100)
+    E_all = np.zeros((runs, R))
+    sizes = []
+    for s in range(runs):
+        obj = ref_npt.NPT(J.copy(), h.copy())
+        np.random.seed(8000 + s)
+        random.seed(8000 + s)
+        import matplotlib.pyplot as _plt
+        _plt.close("all")
+        with quiet() as buf:
+            _, E = obj.run(beta_list=beta_list, num_replicas=R, doNMC=list(doNMC), num_sweeps_MCMC=nsw, num_sweeps_read=nsw,
+                           num_swap_attempts=nswap, num_swapping_pairs=npairs, tolerance=np.finfo(float).eps,
+                           use_hash_table=False, num_cores=1, **kw)
+        E_all[s] = np.asarray(E).reshape(-1)
+        sizes += [int(m) for m in re.findall(r"cluster size = (\d+)", buf.getvalue())]
+        print(f"[golden] mixed run {s}: min {E_all[s].min():.1f}, clusters so far {len(sizes)}", file=sys.__stdout__, flush=True)
+    save("stats_minenergy_pmj96_mixed", **csr_parts(J), h=np.asarray(h).reshape(-1), beta_list=beta_list, num_replicas=R,
+         doNMC=np.array(doNMC, dtype=np.int8), num_sweeps_MCMC=nsw, num_swap_attempts=nswap, num_swapping_pairs=npairs,
+         energies=E_all, min_energy=E_all.min(axis=1), cluster_sizes=np.array(sizes, dtype=np.int64),
+         **{k: np.float64(v) for k, v in kw.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["mcmc", "large", "nmcsub", "lbp", "npt", "icm", "pre", "known", "stats", "statsmin"]
-    table = dict(mcmc=gen_mcmc, large=gen_mcmc_large, statsmin=gen_stats_min, nmcsub=gen_nmc_subroutine, lbp=gen_lbp_and_run, npt=gen_npt, icm=gen_icm,
+    which = sys.argv[1:] or ["mcmc", "large", "nmcsub", "lbp", "npt", "icm", "pre", "known", "stats", "statsmin", "statsmix"]
+    table = dict(statsmix=gen_stats_min_mixed, mcmc=gen_mcmc, large=gen_mcmc_large, statsmin=gen_stats_min, nmcsub=gen_nmc_subroutine, lbp=gen_lbp_and_run, npt=gen_npt, icm=gen_icm,
                  pre=gen_preprocessor, known=gen_known_answers, stats=gen_stats)
     for w in which:
         table[w]()
