@@ -58,7 +58,7 @@ struct nlmc_ctx {
     bool has_diag = false;
     bool has_zero_vals = false;   // a stored entry is 0.0 (or underflows to 0 in fp32)
     size_t lds_opt[24] = {};      // dynamic-LDS opt-in already granted, one slot per kernel: 0 k_levelize, 1 k_icm_components,
-                                  // 2..7 sweep-by-sweep kernels, 8..15 k_sweep_fused variants, 16 k_levelize_fused
+                                  // 2..7 sweep-by-sweep kernels, 8..15 k_sweep_fused variants, 16 k_levelize_fused, 17..20 k_lbp_lds
 
     DevBuf<int32_t> rowptr, col;
     DevBuf<double> val64, h64;
@@ -1908,6 +1908,26 @@ static int lbp_launch(nlmc_ctx *c, int n_problems, int n_lambdas, double beta, d
     HIP_TRY(c, c->lbp_part.reserve(P * 2 * (size_t)group * 4));
     HIP_TRY(c, hipMemsetAsync(c->lbp_bar.p, 0, sizeof(unsigned int) * P, c->stream));
     a.bar = c->lbp_bar.p; a.part = c->lbp_part.p;
+    // small instances: messages in LDS, a thread's edges in registers (k_lbp_lds; same bits)
+    const int mpt = (nnz + NLMC_LBP_LDS_THREADS - 1) / NLMC_LBP_LDS_THREADS;
+    if (group == 1 && n <= 4 * NLMC_LBP_LDS_THREADS && mpt <= 12 && !getenv("NLMC_LBP_GLOBAL")) {
+        const int mpt_v = mpt <= 6 ? 6 : 12;
+        const size_t lds_small = ((size_t)2 * (mpt_v * NLMC_LBP_LDS_THREADS + 1) + 4 * NLMC_LBP_LDS_THREADS + 1 + 64) * sizeof(double);
+        const int variant = (mpt_v / 6 - 1) * 2 + (c->has_diag ? 1 : 0);
+        const void *kf = variant == 0 ? reinterpret_cast<const void *>(k_lbp_lds<6, false>)
+                         : variant == 1 ? reinterpret_cast<const void *>(k_lbp_lds<6, true>)
+                         : variant == 2 ? reinterpret_cast<const void *>(k_lbp_lds<12, false>)
+                                        : reinterpret_cast<const void *>(k_lbp_lds<12, true>);
+        { int rc = ensure_lds(c, 17 + variant, kf, lds_small); if (rc) return rc; }
+        switch (variant) {
+        case 0: hipLaunchKernelGGL((k_lbp_lds<6, false>), dim3(n_problems), dim3(NLMC_LBP_LDS_THREADS), lds_small, c->stream, a); break;
+        case 1: hipLaunchKernelGGL((k_lbp_lds<6, true>), dim3(n_problems), dim3(NLMC_LBP_LDS_THREADS), lds_small, c->stream, a); break;
+        case 2: hipLaunchKernelGGL((k_lbp_lds<12, false>), dim3(n_problems), dim3(NLMC_LBP_LDS_THREADS), lds_small, c->stream, a); break;
+        default: hipLaunchKernelGGL((k_lbp_lds<12, true>), dim3(n_problems), dim3(NLMC_LBP_LDS_THREADS), lds_small, c->stream, a); break;
+        }
+        HIP_TRY(c, hipGetLastError());
+        return NLMC_OK;
+    }
     hipLaunchKernelGGL(k_lbp, dim3(n_problems * group), dim3(NLMC_LBP_THREADS), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return NLMC_OK;

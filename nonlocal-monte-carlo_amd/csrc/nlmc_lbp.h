@@ -69,38 +69,56 @@ __global__ void k_lbp_tanhJ(int nnz, const double *val, double beta, double *tJ)
 }
 
 // u = atanh(clip(a tanh(y), +-sat)) / beta with one exponential, one logarithm and two divisions instead of
-// tanh + atanh (330 fp64 instructions with the library functions, 135 like this):
+// tanh + atanh (330 fp64 instructions with the library functions, ~105 like this):
 //   E = exp(-2|y|), a' = a sign(y):  a tanh(y) = a'(1-E)/(1+E),
 //   atanh(x) = log((1+x)/(1-x))/2 = log1p( 2a'(1-E) / ((1-a') + E(1+a')) )/2     (no cancellation: 1-E from expm1)
 // |x| > sat  <=>  |a'|(1-E) > sat(1+E): the saturated value usat = atanh(sat)/beta comes from the host.
 // expm1 / log1p are plain polynomial kernels (Taylor to r^13 after the usual 2^n split; fdlibm's log series with the
-// rounding error of 1+z fed back): measured on 2*10^7 random (a, y) with |atanh a| <= 3 against long double, the
-// message is within 1.6e-14 relative (tanh + atanh of the C library: 3.6e-15; both are limited by the conditioning
-// 1/(1-x^2) of atanh near the saturated messages).
+// rounding error of 1+z fed back).  Round 3 instruction diet (the kernel is fp64-VALU bound; 211 -> ~105 instructions per
+// message): every multiply-add is an explicit three-address v_fma_f64 (the compiler's two-address v_fmac_f64 form copied
+// each polynomial coefficient into the accumulator first: 54 moves per message), the divisions are reciprocal + two
+// Newton steps + one correction without the scaling / fix-up instructions of the general-purpose expansion (operands are
+// far from the ends of the exponent range here), and the feedback term c/u (|c| <= ulp(1+z)) takes the raw reciprocal.
+// Measured on 2*10^7 random (a, y) with |atanh a| <= 3 against long double (tools-free check in tests/test_law_cpu.py's
+// spirit: oracle-independent, see scripts/lbp_message_check.py): the message stays within 2e-14 relative, limited by the
+// conditioning 1/(1-x^2) of atanh near the saturated messages like the library functions are (3.6e-15).
+__device__ __forceinline__ double lbp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+__device__ __forceinline__ double lbp_div(double num, double den)           // num / den, normal-range operands
+{
+    double r = __builtin_amdgcn_rcp(den);
+    double e = lbp_fma(-den, r, 1.0);
+    r = lbp_fma(r, e, r);
+    e = lbp_fma(-den, r, 1.0);
+    r = lbp_fma(r, e, r);
+    const double q = num * r;
+    return lbp_fma(lbp_fma(-den, q, num), r, q);
+}
+
 __device__ __forceinline__ double lbp_expm1_neg(double x, double &E)      // x <= 0; returns e^x - 1, E = e^x
 {
     const double LOG2E = 1.4426950408889634, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
     x = fmax(x, -80.0);
     const double nf = rint(x * LOG2E);
-    double r = fma(-nf, LN2_HI, x);
-    r = fma(-nf, LN2_LO, r);                                               // |r| <= ln2 / 2
+    double r = lbp_fma(-nf, LN2_HI, x);
+    r = lbp_fma(-nf, LN2_LO, r);                                           // |r| <= ln2 / 2
     double q = 1.0 / 87178291200.0;                                        // (e^r - 1)/r = sum r^i / (i+1)!
-    q = fma(q, r, 1.0 / 6227020800.0);
-    q = fma(q, r, 1.0 / 479001600.0);
-    q = fma(q, r, 1.0 / 39916800.0);
-    q = fma(q, r, 1.0 / 3628800.0);
-    q = fma(q, r, 1.0 / 362880.0);
-    q = fma(q, r, 1.0 / 40320.0);
-    q = fma(q, r, 1.0 / 5040.0);
-    q = fma(q, r, 1.0 / 720.0);
-    q = fma(q, r, 1.0 / 120.0);
-    q = fma(q, r, 1.0 / 24.0);
-    q = fma(q, r, 1.0 / 6.0);
-    q = fma(q, r, 0.5);
-    q = fma(q, r, 1.0);
+    q = lbp_fma(q, r, 1.0 / 6227020800.0);
+    q = lbp_fma(q, r, 1.0 / 479001600.0);
+    q = lbp_fma(q, r, 1.0 / 39916800.0);
+    q = lbp_fma(q, r, 1.0 / 3628800.0);
+    q = lbp_fma(q, r, 1.0 / 362880.0);
+    q = lbp_fma(q, r, 1.0 / 40320.0);
+    q = lbp_fma(q, r, 1.0 / 5040.0);
+    q = lbp_fma(q, r, 1.0 / 720.0);
+    q = lbp_fma(q, r, 1.0 / 120.0);
+    q = lbp_fma(q, r, 1.0 / 24.0);
+    q = lbp_fma(q, r, 1.0 / 6.0);
+    q = lbp_fma(q, r, 0.5);
+    q = lbp_fma(q, r, 1.0);
     const double em1r = r * q;
     const double s = ldexp(1.0, (int)nf);
-    E = fma(s, em1r, s);
+    E = lbp_fma(s, em1r, s);
     return nf == 0.0 ? em1r : E - 1.0;
 }
 
@@ -118,15 +136,15 @@ __device__ __forceinline__ double lbp_log1p(double z)                      // z 
     m = low ? m * 2.0 : m;
     k = low ? k - 1 : k;
     const double f = m - 1.0;
-    const double s = f / (2.0 + f);
+    const double s = lbp_div(f, 2.0 + f);
     const double z2 = s * s, w = z2 * z2;
-    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
-    const double t2 = z2 * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double t1 = w * lbp_fma(w, lbp_fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z2 * lbp_fma(w, lbp_fma(w, lbp_fma(w, Lg7, Lg5), Lg3), Lg1);
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     const double dk = (double)k;
-    const double lo = dk * LN2_LO + c / u;
-    return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + lo)) - f);
+    const double lo = lbp_fma(dk, LN2_LO, c * __builtin_amdgcn_rcp(u));
+    return lbp_fma(dk, LN2_HI, -((hfsq - lbp_fma(s, hfsq + R, lo)) - f));
 }
 
 __device__ __forceinline__ double lbp_message(double a, double y, double sat, double usat, double inv_beta)
@@ -134,8 +152,85 @@ __device__ __forceinline__ double lbp_message(double a, double y, double sat, do
     const double ap = copysign(a, a * y);
     double E;
     const double em1 = lbp_expm1_neg(-2.0 * fabs(y), E);                   // E - 1 in (-1, 0]
-    const double u = 0.5 * inv_beta * lbp_log1p((-2.0 * ap * em1) / ((1.0 - ap) + E * (1.0 + ap)));
+    const double u = 0.5 * inv_beta * lbp_log1p(lbp_div(-2.0 * ap * em1, lbp_fma(E, 1.0 + ap, 1.0 - ap)));
     return (fabs(ap) * (-em1) > sat * (1.0 + E)) ? copysign(usat, ap) : u;
+}
+
+// Two messages at once, step by step in lock step: the fp64 pipeline wants ~4 independent instruction streams per SIMD
+// and k_lbp_lds runs 2 waves per SIMD (register budget), so each wave carries two dependent chains.  The arithmetic of
+// each element is exactly lbp_message's (same operations, same order): results are the same bits.
+struct LbpD2 { double a, b; };
+__device__ __forceinline__ LbpD2 d2(double x) { return LbpD2{x, x}; }
+__device__ __forceinline__ LbpD2 operator+(LbpD2 x, LbpD2 y) { return LbpD2{x.a + y.a, x.b + y.b}; }
+__device__ __forceinline__ LbpD2 operator-(LbpD2 x, LbpD2 y) { return LbpD2{x.a - y.a, x.b - y.b}; }
+__device__ __forceinline__ LbpD2 operator*(LbpD2 x, LbpD2 y) { return LbpD2{x.a * y.a, x.b * y.b}; }
+__device__ __forceinline__ LbpD2 operator-(LbpD2 x) { return LbpD2{-x.a, -x.b}; }
+__device__ __forceinline__ LbpD2 fma2(LbpD2 x, LbpD2 y, LbpD2 z) { return LbpD2{__builtin_fma(x.a, y.a, z.a), __builtin_fma(x.b, y.b, z.b)}; }
+__device__ __forceinline__ LbpD2 fma2(LbpD2 x, LbpD2 y, double z) { return LbpD2{__builtin_fma(x.a, y.a, z), __builtin_fma(x.b, y.b, z)}; }
+
+__device__ __forceinline__ LbpD2 lbp_div2(LbpD2 num, LbpD2 den)
+{
+    LbpD2 r{__builtin_amdgcn_rcp(den.a), __builtin_amdgcn_rcp(den.b)};
+    LbpD2 e = fma2(-den, r, 1.0);
+    r = fma2(r, e, r);
+    e = fma2(-den, r, 1.0);
+    r = fma2(r, e, r);
+    const LbpD2 q = num * r;
+    return fma2(fma2(-den, q, num), r, q);
+}
+
+__device__ __forceinline__ LbpD2 lbp_message2(LbpD2 a, LbpD2 y, double sat, double usat, double inv_beta)
+{
+    const double LOG2E = 1.4426950408889634, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    const LbpD2 ap{copysign(a.a, a.a * y.a), copysign(a.b, a.b * y.b)};
+    // ---- E = exp(x), em1 = E - 1, x = -2|y|   (lbp_expm1_neg)
+    LbpD2 x{fmax(-2.0 * fabs(y.a), -80.0), fmax(-2.0 * fabs(y.b), -80.0)};
+    const LbpD2 nf{rint(x.a * LOG2E), rint(x.b * LOG2E)};
+    LbpD2 r = fma2(-nf, d2(LN2_HI), x);
+    r = fma2(-nf, d2(LN2_LO), r);
+    LbpD2 q = d2(1.0 / 87178291200.0);
+    q = fma2(q, r, 1.0 / 6227020800.0);
+    q = fma2(q, r, 1.0 / 479001600.0);
+    q = fma2(q, r, 1.0 / 39916800.0);
+    q = fma2(q, r, 1.0 / 3628800.0);
+    q = fma2(q, r, 1.0 / 362880.0);
+    q = fma2(q, r, 1.0 / 40320.0);
+    q = fma2(q, r, 1.0 / 5040.0);
+    q = fma2(q, r, 1.0 / 720.0);
+    q = fma2(q, r, 1.0 / 120.0);
+    q = fma2(q, r, 1.0 / 24.0);
+    q = fma2(q, r, 1.0 / 6.0);
+    q = fma2(q, r, 0.5);
+    q = fma2(q, r, 1.0);
+    const LbpD2 em1r = r * q;
+    const LbpD2 sc{ldexp(1.0, (int)nf.a), ldexp(1.0, (int)nf.b)};
+    const LbpD2 E = fma2(sc, em1r, sc);
+    const LbpD2 em1{nf.a == 0.0 ? em1r.a : E.a - 1.0, nf.b == 0.0 ? em1r.b : E.b - 1.0};
+    // ---- z = 2a'(1-E) / ((1-a') + E(1+a')),  log1p(z)   (lbp_log1p)
+    const LbpD2 z = lbp_div2(d2(-2.0) * ap * em1, fma2(E, d2(1.0) + ap, d2(1.0) - ap));
+    const LbpD2 u = d2(1.0) + z;
+    const LbpD2 c = z - (u - d2(1.0));
+    int ka, kb;
+    double ma = frexp(u.a, &ka), mb = frexp(u.b, &kb);
+    const bool la = ma < 0.70710678118654752440, lb = mb < 0.70710678118654752440;
+    ma = la ? ma * 2.0 : ma; mb = lb ? mb * 2.0 : mb;
+    ka = la ? ka - 1 : ka; kb = lb ? kb - 1 : kb;
+    const LbpD2 f{ma - 1.0, mb - 1.0};
+    const LbpD2 s = lbp_div2(f, d2(2.0) + f);
+    const LbpD2 z2 = s * s, w = z2 * z2;
+    const LbpD2 t1 = w * fma2(w, fma2(w, d2(Lg6), Lg4), Lg2);
+    const LbpD2 t2 = z2 * fma2(w, fma2(w, fma2(w, d2(Lg7), Lg5), Lg3), Lg1);
+    const LbpD2 R = t2 + t1;
+    const LbpD2 hfsq = d2(0.5) * f * f;
+    const LbpD2 dk{(double)ka, (double)kb};
+    const LbpD2 lo = fma2(dk, d2(LN2_LO), c * LbpD2{__builtin_amdgcn_rcp(u.a), __builtin_amdgcn_rcp(u.b)});
+    const LbpD2 lg = fma2(dk, d2(LN2_HI), -((hfsq - fma2(s, hfsq + R, lo)) - f));
+    const double ua = 0.5 * inv_beta * lg.a, ub = 0.5 * inv_beta * lg.b;
+    return LbpD2{(fabs(ap.a) * (-em1.a) > sat * (1.0 + E.a)) ? copysign(usat, ap.a) : ua,
+                 (fabs(ap.b) * (-em1.b) > sat * (1.0 + E.b)) ? copysign(usat, ap.b) : ub};
 }
 
 __device__ __forceinline__ double lbp_wave_max(double v)
@@ -282,4 +377,177 @@ __global__ __launch_bounds__(NLMC_LBP_THREADS) void k_lbp(LbpArgs a)
         __syncthreads();
     }
     if (tid == 0 && (g == 0 || dead)) { a.out_nlam[p] = dead ? 0 : n_done; a.out_status[p] = dead ? 2 : status; }
+}
+
+// ---- small instances: messages in LDS, edge constants in registers -----------------------------------------------
+// k_lbp walks global-memory arrays (L2-resident) with two dependent loads per message: at n = 10^3 (6 messages per
+// thread) an iteration took 17 us against a ~5.4 us fp64 VALU floor (scripts/lbp_c3_probe.py).  When both message buffers
+// and the node totals fit in LDS (16 nnz + 8 n bytes) and a thread's share of the edges (MPT) and nodes (<= 2) fits in
+// registers, everything an iteration touches is LDS or registers: thread t owns edges t, t + 1024, ... for the whole
+// launch (source, reverse position, tanh(beta J), its cavity field h_msgs), the iteration is node totals -> barrier ->
+// messages -> ONE barrier (the convergence maxima go through a 16-lane butterfly that every wave repeats, so the decision
+// is uniform without a broadcast).  Same operations in the same order as k_lbp: results are bit-identical
+// (tests/test_gpu_lbp.py).
+// 512 threads (2 waves per SIMD, 256 registers per lane): with 1024 the 128-register cap spilled ~100 registers per lane.
+// No per-lane predicates in the loop (a bool per edge is a 64-bit scalar mask each: 56 scalar registers, which pushed the
+// polynomial coefficients out of the scalar file): edge slots past nnz are harmless dummies (source = a node slot that
+// always holds 0, tanh(beta J) = 0, reads from message slots that stay 0, writes to a scratch slot: their message is
+// exactly 0 and every maximum they feed is 0), node slots past n likewise; diagonal entries only in the HAS_DIAG variant.
+#define NLMC_LBP_LDS_THREADS 512
+#ifndef NLMC_LBP_ILV
+#define NLMC_LBP_ILV 2            // message computations the scheduler may interleave
+#endif
+template <int MPT, bool HAS_DIAG>
+__global__ __launch_bounds__(NLMC_LBP_LDS_THREADS) void k_lbp_lds(LbpArgs a)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    constexpr int NT = NLMC_LBP_LDS_THREADS, NPT = 4, NW = NT / 64, ESLOTS = MPT * NT;
+    static_assert(NW <= 16, "red rows hold 16 waves");
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = a.n, nnz = a.nnz;
+    // message buffers [ESLOTS + 1] (slot ESLOTS: scratch), node totals [NPT NT + 1] (slot NPT NT: always 0), red [4][16]
+    double *wc = reinterpret_cast<double *>(lds_raw), *wn = wc + ESLOTS + 1, *tot = wn + ESLOTS + 1, *red = tot + NPT * NT + 1;
+    double *mag = a.mag + (size_t)p * n;
+    const double *ms = a.m_star + (size_t)p * n;
+
+    // this thread's edges
+    int e_src[MPT], e_rev[MPT];
+    double e_tJ[MPT], e_hm[MPT];
+    unsigned bits = 0u;                 // bit k: node slot k exists; 4 + k: its dense h_msgs row has non-edge entries; 8 + k: edge k is diagonal
+#pragma unroll
+    for (int k = 0; k < MPT; ++k) {
+        const int e = tid + k * NT;
+        const bool on = e < nnz;
+        const int ec = on ? e : 0;
+        const int si = a.src[ec], ri = a.rev[ec];
+        e_src[k] = on ? si : NPT * NT;
+        e_rev[k] = on ? ri : ESLOTS;
+        e_tJ[k] = on ? a.tJ[ec] : 0.0;
+        e_hm[k] = 0.0;
+        if (HAS_DIAG && on && a.col[ec] == si) bits |= 1u << (8 + k);
+        // h_msgs = 0, u_msgs = J * m_star.reshape(1, -1)  (NMC/nmc.py:128-129): u_msgs[j, i] = J[j, i] * m_star[i]
+        wc[e] = on ? a.val[ri] * ms[si] : 0.0;
+        wn[e] = 0.0;
+    }
+    // this thread's nodes
+    int v_r0[NPT], v_deg[NPT];
+    double v_h[NPT], v_me[NPT];
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int i = tid + k * NT;
+        const bool on = i < n;
+        const int ic = on ? i : 0;
+        v_r0[k] = a.rowptr[ic]; v_deg[k] = on ? a.rowptr[ic + 1] - v_r0[k] : 0;
+        v_h[k] = on ? a.h[ic] : 0.0; v_me[k] = on ? ms[ic] * a.eps[ic] : 0.0;
+        int offdiag = 0;
+        for (int e = v_r0[k]; e < v_r0[k] + v_deg[k]; ++e) offdiag += a.col[e] != ic;
+        if (on) bits |= 1u << k;
+        if (on && offdiag < n - 1) bits |= 1u << (4 + k);      // row i of the dense h_msgs has non-edge entries, all equal to total_i
+        tot[i] = 0.0;
+    }
+    if (tid == 0) { wc[ESLOTS] = 0.0; wn[ESLOTS] = 0.0; tot[NPT * NT] = 0.0; }
+    __syncthreads();
+
+    // row sum of the current messages of node slot k, sequential in ascending neighbour index
+    auto row_sum = [&](int k) __attribute__((always_inline)) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = q < v_deg[k] ? wc[v_r0[k] + q] : 0.0;       // all reads in flight
+        double sum = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sum = q < v_deg[k] ? sum + v[q] : sum;
+        for (int q = 8; q < v_deg[k]; ++q) sum += wc[v_r0[k] + q];
+        return sum;
+    };
+
+    int n_done = 0, status = 0;
+    for (int l = 0; l < a.n_lams; ++l) {
+        const double lam = a.lams[l];
+        int it = 0;
+        for (int iter = 0; iter < a.max_iter; ++iter) {
+            it = iter;
+            double dh_n = 0.0, dh_d = 0.0, du_n = 0.0, du_d = 0.0;
+            // ---- node totals: total_i = h_lam[i] + sum_k u_msgs[k, i]   (NMC/nmc.py:199-201)
+#pragma unroll
+            for (int k = 0; k < NPT; ++k) {
+                const int i = tid + k * NT;
+                const double hl = v_h[k] + lam * v_me[k];
+                const double t_new = hl + row_sum(k), t_old = tot[i];
+                if (bits & (1u << k)) tot[i] = t_new;
+                if (bits & (1u << (4 + k))) {
+                    dh_n = fmax(dh_n, fabs(t_new - t_old));
+                    dh_d = fmax(dh_d, fabs(t_new) + fabs(t_old));
+                }
+            }
+            __syncthreads();
+            // ---- messages: h_msgs[i, j] = total_i - u_msgs[j, i];  u_msgs[i, j] = atanh_sat(tanh(bJ) tanh(b h_msgs)) / b
+            // (two messages at a time, the LDS reads of the next pair in flight meanwhile: left to itself the scheduler
+            // interleaves all MPT message computations and spills)
+            static_assert(MPT % 2 == 0, "messages are processed in pairs");
+            double t_n[2] = {tot[e_src[0]], tot[e_src[1]]}, w_n[2] = {wc[tid], wc[tid + NT]}, u_n[2] = {wc[e_rev[0]], wc[e_rev[1]]};
+#pragma unroll
+            for (int k = 0; k < MPT; k += 2) {
+                const double t_i[2] = {t_n[0], t_n[1]}, w_e[2] = {w_n[0], w_n[1]}, u_o[2] = {u_n[0], u_n[1]};
+                if (k + 2 < MPT) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int kn = k + 2 + j < MPT ? k + 2 + j : 0;
+                        t_n[j] = tot[e_src[kn]];
+                        w_n[j] = wc[tid + kn * NT];
+                        u_n[j] = wc[e_rev[kn]];
+                    }
+                }
+                LbpD2 h_new{t_i[0] - w_e[0], t_i[1] - w_e[1]};
+                if (HAS_DIAG) {
+                    h_new.a = (bits & (1u << (8 + k))) ? 0.0 : h_new.a;
+                    h_new.b = (bits & (1u << (9 + k))) ? 0.0 : h_new.b;
+                }
+                const LbpD2 u_new = lbp_message2(LbpD2{e_tJ[k], e_tJ[k + 1]}, LbpD2{a.beta * h_new.a, a.beta * h_new.b}, a.sat, a.usat, a.inv_beta);
+                const double h_old0 = e_hm[k], h_old1 = e_hm[k + 1];
+                e_hm[k] = h_new.a; e_hm[k + 1] = h_new.b;
+                wn[e_rev[k]] = u_new.a;
+                wn[e_rev[k + 1]] = u_new.b;
+                dh_n = fmax(dh_n, fabs(h_new.a - h_old0));
+                dh_d = fmax(dh_d, fabs(h_new.a) + fabs(h_old0));
+                du_n = fmax(du_n, fabs(u_new.a - u_o[0]));
+                du_d = fmax(du_d, fabs(u_new.a) + fabs(u_o[0]));
+                dh_n = fmax(dh_n, fabs(h_new.b - h_old1));
+                dh_d = fmax(dh_d, fabs(h_new.b) + fabs(h_old1));
+                du_n = fmax(du_n, fabs(u_new.b - u_o[1]));
+                du_d = fmax(du_d, fabs(u_new.b) + fabs(u_o[1]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            dh_n = lbp_wave_max(dh_n); dh_d = lbp_wave_max(dh_d); du_n = lbp_wave_max(du_n); du_d = lbp_wave_max(du_d);
+            if (lane == 0) { red[0 * 16 + wv] = dh_n; red[1 * 16 + wv] = dh_d; red[2 * 16 + wv] = du_n; red[3 * 16 + wv] = du_d; }
+            __syncthreads();
+            // every wave reduces the 4 x NW partial maxima itself: lanes [16 q, 16 q + 16) hold quantity q
+            double m = (lane & 15) < NW ? red[lane] : 0.0;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+            const double r0 = __shfl(m, 0, 64), r1 = __shfl(m, 16, 64), r2 = __shfl(m, 32, 64), r3 = __shfl(m, 48, 64);
+            { double *t = wc; wc = wn; wn = t; }
+            // 0/0 = NaN compares false, like the reference's `du < tolerance and dh < tolerance` (NMC/nmc.py:212-213)
+            const double dh = r0 / r1, du = r2 / r3;
+            if (du < a.tol && dh < a.tol) break;
+        }
+        if (tid == 0) a.out_iters[(size_t)p * a.n_lams + l] = it;
+        const bool exhausted = (it == a.max_iter - 1);
+        if (exhausted && l == 0) { status = 1; break; }          // NMC/nmc.py:142-144
+        if (!exhausted) {
+            // magnetizations = tanh(beta (h_lam + sum_k u_msgs[k, :]))  (NMC/nmc.py:216-217), rows added in ascending k
+#pragma unroll
+            for (int k = 0; k < NPT; ++k)
+                if (bits & (1u << k)) mag[tid + k * NT] = tanh(a.beta * ((v_h[k] + lam * v_me[k]) + row_sum(k)));
+        }
+        // exhausted at a later lambda: keep the previous marginals and stop (NMC/nmc.py:145-148)
+        if (a.mag_all) {
+            double *dst = a.mag_all + ((size_t)p * a.n_lams + l) * n;
+            __syncthreads();
+            for (int i = tid; i < n; i += NT) dst[i] = mag[i];
+        }
+        n_done = l + 1;
+        if (exhausted) break;
+        __syncthreads();               // red / the message buffers are rewritten by the next lambda's first iteration
+    }
+    if (tid == 0) { a.out_nlam[p] = n_done; a.out_status[p] = status; }
 }

@@ -150,3 +150,27 @@ def test_device_lbp_does_not_depend_on_workgroups_per_problem(product, monkeypat
         for k in ("mag", "n_lambdas", "iters", "status", "mag_all"):
             assert np.array_equal(res[grp][k], res[1][k]), (grp, k)
     assert res[1]["n_lambdas"].min() >= 2
+
+
+@pytest.mark.parametrize("N,P", [(300, 3), (1000, 16), (1500, 5)])
+def test_lds_resident_kernel_equals_the_global_memory_kernel(product, N, P, monkeypatch):
+    """k_lbp_lds (small instances: messages in LDS, a thread's edges in registers) does the operations of k_lbp in the same
+    order: marginals, lambda counts and iteration counts are the same bits."""
+    J, h = make_instance(N, seed=N, with_h=True)
+    inst = product.Instance(J, h)
+    graph = product.lbp.EdgeGraph(inst)
+    eps = graph.epsilon(inst.h)
+    ms = low_energy_states(J, h, P, seed=3, sweeps=60).astype(np.float64)
+    lams = product.lbp.lambda_list(3.0, 0.05, 0.85)
+    sat = float(np.tanh(19.06)) - EPS
+    with product.Engine(inst, None, 1) as eng:
+        a = eng.lbp_convexified(ms, eps, lams, 2.5, EPS, 100, sat, want_all=True)
+        monkeypatch.setenv("NLMC_LBP_GLOBAL", "1")
+        b = eng.lbp_convexified(ms, eps, lams, 2.5, EPS, 100, sat, want_all=True)
+    for k in ("mag", "n_lambdas", "status"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["n_lambdas"].min() >= 3
+    for q in range(P):                        # (rows behind the last processed lambda are not written)
+        m = int(a["n_lambdas"][q])
+        assert np.array_equal(a["iters"][q, :m], b["iters"][q, :m])
+        assert np.array_equal(a["mag_all"][q, :m], b["mag_all"][q, :m])
