@@ -202,6 +202,11 @@ enum { NLMC_CHAINS_ALL = 0, NLMC_CHAINS_UNMARKED = 1, NLMC_CHAINS_MARKED = 2 };
 enum { NLMC_PHASE_ALL = 0, NLMC_PHASE_BACKBONE_HOT = 1, NLMC_PHASE_BACKBONE_FROZEN = 2 };
 int nlmc_pt_mark_slots(nlmc_ctx *ctx, const uint8_t *marks /*[ladder_len] or NULL*/);
 int nlmc_select_chains(nlmc_ctx *ctx, int which);
+/* on != 0: the work of the MARKED subset (inference, phases, hand-offs) is queued on a second HIP stream of the context, forked
+ * from the context's stream where a round first selects a subset and joined where it selects all chains again, so that the
+ * unmarked chains' sweeps (select UNMARKED first) run beside it -- the reference's pool runs MCMC_task and NMC_task side by
+ * side too (NPT/npt.py:616-640).  Same results either way. */
+int nlmc_overlap_subsets(nlmc_ctx *ctx, int on);
 int nlmc_subset_count(const nlmc_ctx *ctx);
 int nlmc_get_subset(nlmc_ctx *ctx, int32_t *out_chains /*[nlmc_subset_count] local chain ids*/);
 int nlmc_track_minimum(nlmc_ctx *ctx, int on);

@@ -109,22 +109,20 @@ class SweepMixin:
             return eng.sweep_stream(perm[None], u[None], np.asarray(beta_run)[None, :], record_stride=rs,
                                     want_energy=True, want_min=True, want_state=True)
         beta2 = np.asarray(beta_run)[None, :]
-        # Fused-window schedules (the sweeps of a launch overlap; "f32" arithmetic: fixed-point couplings) when the
-        # instance qualifies and every configuration is recorded: the energies handed back are then the fp64 energies of
-        # the recorded configurations, computed on the device copy of the trace, and the argmin hand-off
-        # (NMC/nmc.py:394-395) uses those -- exact like the reference's list comprehension, 2-3 x the sweep rate.
-        T = fused_window(num_sweeps) if rs == 1 and 256 <= n else 0
-        if T and eng.plan_philox_fused(self._sweep_counter, num_sweeps // T, T, self.seed) == num_sweeps // T:
-            o = eng.sweep_philox(num_sweeps, self.seed, sweep0=self._sweep_counter, beta=beta2, precision="f32",
-                                 record_stride=1, want_energy=True, want_min=True, want_state=True)
-            E = eng.energy_of_recorded(num_sweeps)[0]
-            k = int(np.argmin(E))                                   # first minimum, like np.argmin over the list
-            o["energy"][0] = E
-            o["min_energy"][0], o["argmin"][0], o["argmin_state"][0] = E[k], k, o["spins"][0][k]
+        # Arithmetic of the single-chain device-RNG calls (MCMC(), the phases of NMC.run / NMC_subroutine): a property of the
+        # INSTANCE alone -- not of M_skip, not of the number of sweeps.  n >= 256: the "f32" dynamics of the
+        # batched path (24-bit fixed-point couplings + logistic thresholds; DESIGN.md section 2 states the tolerance: the
+        # chain samples the Boltzmann law of (Jq, hq) 2^-qs with |Jq 2^-qs - J| <= 2^-(qs+1), nothing lost for +-J / integer
+        # instances), on fused windows planned piece by piece within a memory budget where the instance qualifies, sweep by
+        # sweep otherwise (same bits).  Smaller instances: fp64 fields.  The argmin hand-off (NMC/nmc.py:394-395) takes the
+        # first minimum of the energies tracked by the kernel (exact integers of the quantised model in the "f32"
+        # arithmetic); o["energy_recorded"] holds the fp64 energies of the recorded configurations, computed on the device
+        # copy of the trace -- what the reference's list comprehension (NMC/nmc.py:386-387) would give for them.
+        if n >= 256:
+            o = eng.sweep_philox_windows(num_sweeps, self.seed, sweep0=self._sweep_counter, beta=beta2, record_stride=rs,
+                                         want_energy=True, want_min=True, want_state=True, want_recorded_energy=True)
         else:
-            # fp64 fields keep the tracked energies exact to rounding; very large instances only fit the fp32 layout
-            o = eng.sweep_philox(num_sweeps, self.seed, sweep0=self._sweep_counter, beta=beta2,
-                                 precision="f64" if n <= 12000 else "f32", record_stride=rs,
+            o = eng.sweep_philox(num_sweeps, self.seed, sweep0=self._sweep_counter, beta=beta2, precision="f64", record_stride=rs,
                                  want_energy=True, want_min=True, want_state=True)
         self._sweep_counter += num_sweeps
         return o
@@ -162,7 +160,9 @@ class Common(SweepMixin):
     def MCMC(self, num_sweeps, m_start, beta, J, h, anneal=False, sweeps_per_beta=1, initial_beta=0,
              hash_table=None, use_hash_table=False):
         """Heat-bath sweeps with a fresh random permutation per sweep (NMC/nmc.py:28-91).
-        Returns M [N, num_sweeps] float64, column jj = state after sweep jj."""
+        Returns M [N, num_sweeps] float64, column jj = state after sweep jj.  rng="numpy": the reference's stream and fp64
+        arithmetic, bit for bit.  rng="philox": device RNG; N >= 256: couplings in 24-bit fixed point (exact for +-J /
+        integer instances, |dJ| <= 2^-(qs+1) max|J| 2^-23 otherwise -- DESIGN.md section 2), smaller N: fp64 fields."""
         N = J.shape[0]
         M = np.zeros((N, num_sweeps))           # negative counts raise ValueError exactly like the reference (:52)
         if num_sweeps == 0:
@@ -269,7 +269,8 @@ class Common(SweepMixin):
             else:
                 M = o["spins"][0].T.astype(np.float64)
                 M_overall[:, at:at + w] = M[:, ::M_skip]   # shape mismatch raises like the reference when S % M_skip
-            energy_overall[at:at + w] = en[::M_skip]
+            er = o.get("energy_recorded")                  # fp64 energies of the recorded columns (device-RNG mode, n >= 256)
+            energy_overall[at:at + w] = en[::M_skip] if er is None else (er[0] if strided else er[0][::M_skip])
             at += w
             m_init = o["argmin_state"][0].astype(np.float64)
             return o

@@ -39,6 +39,11 @@ template <typename T> struct DevBuf {
 struct nlmc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // Work on the MARKED chain subset may run on a second stream beside the unmarked chains' sweeps (nlmc_overlap_subsets):
+    // `cur` is the stream the subset-aware launches go to, forked from / joined to `stream` by nlmc_select_chains.
+    hipStream_t aux = nullptr, cur = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = false, forked = false;
     int n = 0, n_pad = 0;
     int64_t nnz = 0;
     int n_chains = 0, chain_base = 0, n_chains_global = 0;
@@ -57,8 +62,8 @@ struct nlmc_ctx {
     bool has_flags = false;
     bool has_diag = false;
     bool has_zero_vals = false;   // a stored entry is 0.0 (or underflows to 0 in fp32)
-    size_t lds_opt[24] = {};      // dynamic-LDS opt-in already granted, one slot per kernel: 0 k_levelize, 1 k_icm_components,
-                                  // 2..7 sweep-by-sweep kernels, 8..15 k_sweep_fused variants, 16 k_levelize_fused, 17..20 k_lbp_lds
+    size_t lds_opt[48] = {};      // dynamic-LDS opt-in already granted, one slot per kernel: 0 k_levelize, 1 k_icm_components,
+                                  // 2..7 sweep-by-sweep kernels, 8..15 k_sweep_fused variants, 16 k_levelize_fused, 17..20 k_lbp_lds, 24..47 k_sweep_fused variants
 
     DevBuf<int32_t> rowptr, col;
     DevBuf<double> val64, h64;
@@ -258,6 +263,14 @@ int sweep_block(int n)
     return std::min(1024, std::max(64, nt));
 }
 
+// fp64-field philox kernels: 8 waves at most (256 registers per lane; with 16 waves the 128-register cap spilled 13-27
+// registers per lane to scratch inside the level loop); levels wider than the workgroup are split when the schedule is built
+// (fixed-point kernel with self-couplings: 12 waves, 170 registers: at 16 waves it spilled 2)
+int sweep_block_for(int n, bool f64_philox, bool f32_diag = false)
+{
+    return std::min(f64_philox ? 512 : f32_diag ? 768 : 1024, sweep_block(n));
+}
+
 // beyond the default dynamic-LDS window a kernel has to opt in (once per size step)
 int ensure_lds(nlmc_ctx *c, int slot, const void *func, size_t bytes)
 {
@@ -304,7 +317,7 @@ int run_levelize(nlmc_ctx *c, int n_orders, const uint32_t *keys_in, int per_cha
     a.per_chain = per_chain;
     a.n_sweeps = n_sweeps;
     a.chain_base = c->chain_base;
-    a.level_cap = sweep_block(c->n);
+    a.level_cap = sweep_block_for(c->n, ell_mode == 2, ell_mode == 1 && c->has_diag);
     a.ord2 = sc.order.p;
     a.lvl_off = sc.lvl_off.p;
     a.nlev = sc.nlev.p;
@@ -316,7 +329,7 @@ int run_levelize(nlmc_ctx *c, int n_orders, const uint32_t *keys_in, int per_cha
     a.two_sided = lds_two + 16 <= (size_t)150 * 1024;
     const size_t lds = (a.two_sided ? lds_two : lds_one) + 16;
     { int rc = ensure_lds(c, 0, reinterpret_cast<const void *>(k_levelize), lds); if (rc) return rc; }
-    hipLaunchKernelGGL(k_levelize, dim3(n_orders), dim3(level_block(c->n)), lds, c->stream, a);
+    hipLaunchKernelGGL(k_levelize, dim3(n_orders), dim3(level_block(c->n)), lds, c->cur, a);
     HIP_TRY(c, hipGetLastError());
     return NLMC_OK;
 }
@@ -392,6 +405,19 @@ bool fused_supported(const nlmc_ctx *c, int T)
     return L.total <= (size_t)150 * 1024;
 }
 
+// k_sweep_fused<DIAG, FLAGS, OUT, FMT>: 24 kernels, picked by the instance (self-couplings, entry format of the plan) and the
+// call (phase flags on, per-sweep outputs)
+const void *fused_kernel(bool diag, bool flags, bool outs, int fmt)
+{
+#define NLMC_K(D, F, O) {reinterpret_cast<const void *>(k_sweep_fused<D, F, O, NLMC_FMT_WIDE>), reinterpret_cast<const void *>(k_sweep_fused<D, F, O, NLMC_FMT_COMPACT>), \
+                         reinterpret_cast<const void *>(k_sweep_fused<D, F, O, NLMC_FMT_ADDR>)}
+    static const void *const table[2][2][2][3] = {{{NLMC_K(false, false, false), NLMC_K(false, false, true)}, {NLMC_K(false, true, false), NLMC_K(false, true, true)}},
+                                                  {{NLMC_K(true, false, false), NLMC_K(true, false, true)}, {NLMC_K(true, true, false), NLMC_K(true, true, true)}}};
+#undef NLMC_K
+    static_assert(NLMC_FMT_WIDE == 0 && NLMC_FMT_COMPACT == 1 && NLMC_FMT_ADDR == 2, "table order");
+    return table[diag][flags][outs][fmt];
+}
+
 struct SweepOut {
     int record_stride;
     int8_t *out_spins;
@@ -411,18 +437,8 @@ int run_fused(nlmc_ctx *c, int slot, int w, uint32_t sweep0, uint64_t seed, cons
     const size_t PS = (size_t)P.pstride;
     const FusedLds L = fused_lds(c->n, c->n_pad, c->has_flags, outs, P.fmt == NLMC_FMT_ADDR);
     const int variant = (outs ? 4 : 0) + (c->has_diag ? 2 : 0) + (c->has_flags ? 1 : 0);
-    const void *kfun = nullptr;
-    switch (variant) {
-    case 0: kfun = reinterpret_cast<const void *>(k_sweep_fused<false, false, false>); break;
-    case 1: kfun = reinterpret_cast<const void *>(k_sweep_fused<false, true, false>); break;
-    case 2: kfun = reinterpret_cast<const void *>(k_sweep_fused<true, false, false>); break;
-    case 3: kfun = reinterpret_cast<const void *>(k_sweep_fused<true, true, false>); break;
-    case 4: kfun = reinterpret_cast<const void *>(k_sweep_fused<false, false, true>); break;
-    case 5: kfun = reinterpret_cast<const void *>(k_sweep_fused<false, true, true>); break;
-    case 6: kfun = reinterpret_cast<const void *>(k_sweep_fused<true, false, true>); break;
-    default: kfun = reinterpret_cast<const void *>(k_sweep_fused<true, true, true>); break;
-    }
-    { int rc = ensure_lds(c, 8 + variant, kfun, L.total); if (rc) return rc; }
+    const void *kfun = fused_kernel(c->has_diag, c->has_flags, outs, P.fmt);
+    { int rc = ensure_lds(c, 24 + variant * 3 + P.fmt, kfun, L.total); if (rc) return rc; }
     // events around the launch (two stream commands) only while timings accumulate (nlmc_timing_reset): every launch or
     // every ev_every-th one.  An event record costs ~2.5 us of stream time: none on the plain product path.
     const bool timed = c->ev_accumulate && (c->ev_every <= 1 || c->launches_total % c->ev_every == 0);
@@ -433,7 +449,7 @@ int run_fused(nlmc_ctx *c, int slot, int w, uint32_t sweep0, uint64_t seed, cons
         e2 = next_event(c);
         if (!e0 || !e1 || !e2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
         tag_triple(c, 1);
-        HIP_TRY(c, hipEventRecord(e0, c->stream));
+        HIP_TRY(c, hipEventRecord(e0, c->cur));
     }
     SweepArgs a{};
     a.g = c->g;
@@ -486,22 +502,14 @@ int run_fused(nlmc_ctx *c, int slot, int w, uint32_t sweep0, uint64_t seed, cons
     a.lds_snap_off = L.snap_off;
 #ifdef NLMC_STAMPS
     HIP_TRY(c, c->dbg.reserve((size_t)R * 16 * 8 + 96));
-    HIP_TRY(c, hipMemsetAsync(c->dbg.p, 0, ((size_t)R * 16 * 8 + 96) * sizeof(long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dbg.p, 0, ((size_t)R * 16 * 8 + 96) * sizeof(long long), c->cur));
     a.dbg = c->dbg.p;
 #endif
     const int nt = fused_block(n);
-    switch (variant) {
-    case 0: hipLaunchKernelGGL((k_sweep_fused<false, false, false>), dim3(R), dim3(nt), L.total, c->stream, a); break;
-    case 1: hipLaunchKernelGGL((k_sweep_fused<false, true, false>), dim3(R), dim3(nt), L.total, c->stream, a); break;
-    case 2: hipLaunchKernelGGL((k_sweep_fused<true, false, false>), dim3(R), dim3(nt), L.total, c->stream, a); break;
-    case 3: hipLaunchKernelGGL((k_sweep_fused<true, true, false>), dim3(R), dim3(nt), L.total, c->stream, a); break;
-    case 4: hipLaunchKernelGGL((k_sweep_fused<false, false, true>), dim3(R), dim3(nt), L.total, c->stream, a); break;
-    case 5: hipLaunchKernelGGL((k_sweep_fused<false, true, true>), dim3(R), dim3(nt), L.total, c->stream, a); break;
-    case 6: hipLaunchKernelGGL((k_sweep_fused<true, false, true>), dim3(R), dim3(nt), L.total, c->stream, a); break;
-    default: hipLaunchKernelGGL((k_sweep_fused<true, true, true>), dim3(R), dim3(nt), L.total, c->stream, a); break;
-    }
+    void *kargs[] = {&a};
+    HIP_TRY(c, hipLaunchKernel(kfun, dim3(R), dim3(nt), kargs, L.total, c->cur));
     HIP_TRY(c, hipGetLastError());
-    if (timed) { HIP_TRY(c, hipEventRecord(e2, c->stream)); c->launches_timed++; }
+    if (timed) { HIP_TRY(c, hipEventRecord(e2, c->cur)); c->launches_timed++; }
     c->launches_sweep++;
     c->launches_total++;
     c->stat_fused_window = w;
@@ -518,7 +526,7 @@ int read_sweep_outputs(nlmc_ctx *c, const SweepOut &o, int n_sweeps, int rec, in
     std::vector<long long> h_ll;
     if (o.out_energy) {
         h_ll.resize((size_t)R * n_sweeps);
-        HIP_TRY(c, hipMemcpyAsync(h_ll.data(), c->etrace.p, sizeof(long long) * h_ll.size(), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(h_ll.data(), c->etrace.p, sizeof(long long) * h_ll.size(), hipMemcpyDeviceToHost, c->cur));
         need_sync = true;
     }
     std::vector<long long> h_min;
@@ -526,16 +534,16 @@ int read_sweep_outputs(nlmc_ctx *c, const SweepOut &o, int n_sweeps, int rec, in
     const bool gather = c->subset != 0 && (o.out_min_energy || o.out_argmin || o.out_argmin_state);
     if (gather) {
         h_list.resize((size_t)R);
-        HIP_TRY(c, hipMemcpyAsync(h_list.data(), c->sub_list(), sizeof(int32_t) * R, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(h_list.data(), c->sub_list(), sizeof(int32_t) * R, hipMemcpyDeviceToHost, c->cur));
     }
     if (o.out_min_energy) {
         h_min.resize((size_t)RA);
-        HIP_TRY(c, hipMemcpyAsync(h_min.data(), c->emin.p, sizeof(long long) * RA, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(h_min.data(), c->emin.p, sizeof(long long) * RA, hipMemcpyDeviceToHost, c->cur));
         need_sync = true;
     }
     if (o.out_argmin) {
         h_arg.resize((size_t)RA);
-        HIP_TRY(c, hipMemcpyAsync(h_arg.data(), c->argmin.p, sizeof(int32_t) * RA, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(h_arg.data(), c->argmin.p, sizeof(int32_t) * RA, hipMemcpyDeviceToHost, c->cur));
         need_sync = true;
     }
     if (o.out_argmin_state) {
@@ -544,10 +552,10 @@ int read_sweep_outputs(nlmc_ctx *c, const SweepOut &o, int n_sweeps, int rec, in
         need_sync = true;
     }
     if (rec) {
-        HIP_TRY(c, hipMemcpyAsync(o.out_spins, c->strace.p, (size_t)R * n_rec * n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(o.out_spins, c->strace.p, (size_t)R * n_rec * n, hipMemcpyDeviceToHost, c->cur));
         need_sync = true;
     }
-    if (need_sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (need_sync) HIP_TRY(c, hipStreamSynchronize(c->cur));
     auto row = [&](int i) { return gather ? (int)h_list[(size_t)i] : i; };
     if (o.out_argmin_state)
         for (int i = 0; i < R; ++i)
@@ -638,7 +646,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
     c->strace_nrec = n_rec;
     c->strace_rows = rec ? R : 0;
     if (want_min) {
-        hipLaunchKernelGGL(k_fill_min, dim3((R + 255) / 256), dim3(256), 0, c->stream, R, c->sub_list(), c->emin.p, c->argmin.p);
+        hipLaunchKernelGGL(k_fill_min, dim3((R + 255) / 256), dim3(256), 0, c->cur, R, c->sub_list(), c->emin.p, c->argmin.p);
         HIP_TRY(c, hipGetLastError());
     }
     if (fused_out) {
@@ -652,6 +660,8 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         return read_sweep_outputs(c, o, n_sweeps, rec, n_rec);
     }
 
+    // (sweep-by-sweep path from here on: its schedule buffers are shared with whatever the main stream is sweeping)
+    if (c->cur != c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
     const int per_chain = (stream_mode || order_mode == NLMC_ORDER_PER_CHAIN) ? 1 : 0;
     if (per_chain && c->subset != 0) return fail(c, NLMC_ERR_UNSUPPORTED, "chain subsets run shared-order philox sweeps only");
     // plan cache hit?
@@ -672,7 +682,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         HIP_TRY(c, c->scratch.reserve(orders, (size_t)n, ell_mode));
     }
 
-    const int nt = sweep_block(n);
+    const int nt = sweep_block_for(n, !stream_mode && f64, !stream_mode && !f64 && c->has_diag);
     // LDS carve-up: spins | flags | uniforms of one sweep (philox) | level offsets (philox) | reduction scratch
     const int lds_flags_off = c->n_pad;
     int cur = c->n_pad * (c->has_flags ? 2 : 1);
@@ -705,7 +715,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
             e0 = next_event(c); e1 = next_event(c); e2 = next_event(c);
             if (!e0 || !e1 || !e2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
             tag_triple(c, 0);
-            HIP_TRY(c, hipEventRecord(e0, c->stream));
+            HIP_TRY(c, hipEventRecord(e0, c->cur));
         }
         if (cached) {
             o0 = (size_t)(sweep0 - c->plan_sweep0) + t0;
@@ -717,7 +727,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
             c->stats_nlev_count = n_orders;
             c->stats_pending = true;
         }
-        if (e1) HIP_TRY(c, hipEventRecord(e1, c->stream));
+        if (e1) HIP_TRY(c, hipEventRecord(e1, c->cur));
 
         SweepArgs a{};
         a.g = c->g;
@@ -759,24 +769,24 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         a.best = (want_min && want_state) ? c->best.p : nullptr;
 #ifdef NLMC_STAMPS
         HIP_TRY(c, c->dbg.reserve((size_t)R * 16 * 8 + 96));
-        HIP_TRY(c, hipMemsetAsync(c->dbg.p, 0, ((size_t)R * 16 * 8 + 96) * sizeof(long long), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->dbg.p, 0, ((size_t)R * 16 * 8 + 96) * sizeof(long long), c->cur));
         a.dbg = c->dbg.p;
 #endif
         a.lds_u_stride = dbuf ? u_bytes : 0;
         a.lds_loff_stride = dbuf ? NLMC_LCAP * 4 : 0;
         a.lds_flags_off = lds_flags_off; a.lds_u_off = lds_u_off; a.lds_loff_off = lds_loff_off; a.lds_red_off = lds_red_off;
         if (stream_mode)
-            hipLaunchKernelGGL(k_sweep_stream, dim3(R), dim3(nt), lds, c->stream, a);
+            hipLaunchKernelGGL(k_sweep_stream, dim3(R), dim3(nt), lds, c->cur, a);
         else if (f64 && c->has_diag)
-            hipLaunchKernelGGL((k_sweep_philox<double, true>), dim3(R), dim3(nt), lds, c->stream, a);
+            hipLaunchKernelGGL((k_sweep_philox<double, true>), dim3(R), dim3(nt), lds, c->cur, a);
         else if (f64)
-            hipLaunchKernelGGL((k_sweep_philox<double, false>), dim3(R), dim3(nt), lds, c->stream, a);
+            hipLaunchKernelGGL((k_sweep_philox<double, false>), dim3(R), dim3(nt), lds, c->cur, a);
         else if (c->has_diag)
-            hipLaunchKernelGGL((k_sweep_philox<float, true>), dim3(R), dim3(nt), lds, c->stream, a);
+            hipLaunchKernelGGL((k_sweep_philox<float, true>), dim3(R), dim3(nt), lds, c->cur, a);
         else
-            hipLaunchKernelGGL((k_sweep_philox<float, false>), dim3(R), dim3(nt), lds, c->stream, a);
+            hipLaunchKernelGGL((k_sweep_philox<float, false>), dim3(R), dim3(nt), lds, c->cur, a);
         HIP_TRY(c, hipGetLastError());
-        if (e2) { HIP_TRY(c, hipEventRecord(e2, c->stream)); c->launches_timed++; }
+        if (e2) { HIP_TRY(c, hipEventRecord(e2, c->cur)); c->launches_timed++; }
         c->launches_sweep++;
         c->launches_total++;
     }
@@ -805,7 +815,7 @@ int rows_to_device(nlmc_ctx *c, void *dst_dev, const void *src_host, int rows)
 int rows_to_host_begin(nlmc_ctx *c, const void *src_dev, int rows)
 {
     c->stage_out.resize((size_t)c->n_pad * rows);
-    HIP_TRY(c, hipMemcpyAsync(c->stage_out.data(), src_dev, c->stage_out.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->stage_out.data(), src_dev, c->stage_out.size(), hipMemcpyDeviceToHost, c->cur));
     return NLMC_OK;
 }
 
@@ -867,6 +877,7 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
     CT(hipSetDevice(device));
     c->device = device;
     c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    c->cur = c->stream;
     c->n = n;
     c->n_pad = (n + 15) / 16 * 16;
     c->nnz = nnz;
@@ -996,6 +1007,9 @@ void nlmc_destroy(nlmc_ctx *c)
     c->dbg.release();
 #endif
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     c->rowptr.release(); c->col.release(); c->val64.release(); c->h64.release(); c->edge32.release(); c->hq.release();
     c->spins.release(); c->best.release(); c->flags.release(); c->efix.release(); c->emin.release(); c->etrace.release();
     c->argmin.release(); c->energy.release(); c->tab.release(); c->ustream.release(); c->etrace_d.release();
@@ -1134,10 +1148,10 @@ int nlmc_energy_of_recorded(nlmc_ctx *c, int first, int count, double *out)
     EnergyArgs a{};
     a.g = c->g; a.spins = c->strace.p + (size_t)first * c->n; a.stride = c->n; a.stride_outer = (int64_t)c->strace_nrec * c->n;
     a.inner = count; a.out = c->etrace_d.p; a.efix = nullptr; a.escale = c->escale;
-    hipLaunchKernelGGL(k_energy, dim3((unsigned)m), dim3(c->n >= 4096 ? 1024 : 256), (size_t)c->n_pad, c->stream, a);
+    hipLaunchKernelGGL(k_energy, dim3((unsigned)m), dim3(c->n >= 4096 ? 1024 : 256), (size_t)c->n_pad, c->cur, a);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(out, c->etrace_d.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out, c->etrace_d.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, c->cur));
+    HIP_TRY(c, hipStreamSynchronize(c->cur));
     return NLMC_OK;
 }
 
@@ -1216,9 +1230,9 @@ int nlmc_sweep_philox(nlmc_ctx *c, int precision, int order_mode, int n_sweeps, 
             }
         if (tab != c->tab_host) {          // (the same table as last time -- every NMC phase of a run -- is not uploaded again)
             HIP_TRY(c, c->tab.reserve(tab.size()));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));         // launches still reading the previous table
-            HIP_TRY(c, hipMemcpyAsync(c->tab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->cur));         // launches still reading the previous table
+            HIP_TRY(c, hipMemcpyAsync(c->tab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, c->cur));
+            HIP_TRY(c, hipStreamSynchronize(c->cur));
             c->tab_host.swap(tab);
         }
         tab_dev = c->tab.p;
@@ -1232,8 +1246,8 @@ int nlmc_sweep_philox(nlmc_ctx *c, int precision, int order_mode, int n_sweeps, 
                 tab[2 * r + 0] = -2.0 * LOG2E * c->beta_list[r];
                 tab[2 * r + 1] = -2.0 * LOG2E * (c->beta_list[r] / c->temp_x);
             }
-            HIP_TRY(c, hipMemcpyAsync(c->pt_tab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->pt_tab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, c->cur));
+            HIP_TRY(c, hipStreamSynchronize(c->cur));
             c->pt_tab_valid = true;
             c->pt_tab_temp_x = c->temp_x;
         }
@@ -1313,7 +1327,14 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     const int n = c->n, T = window;
     const size_t W = (size_t)n_windows;
     P.pstride = fused_pstride(n, c->n_long, T);
-    { int rc = reserve_fused_plan(c, n_windows, T); if (rc) return rc; }
+    if (reserve_fused_plan(c, n_windows, T) != NLMC_OK) {
+        // no room for this many windows: not an error -- nothing is planned, the caller's sweeps take the
+        // sweep-by-sweep path (or it asks again for fewer windows); what was allocated for the attempt is given back
+        (void)hipGetLastError();
+        P.release(); c->fz_glv.release(); c->fz_perm.release();
+        c->err.clear();
+        return NLMC_OK;
+    }
     { int rc = ensure_adjacency(c); if (rc) return rc; }
     FusedLevelizeArgs a{};
     a.g = c->g;
@@ -1832,17 +1853,17 @@ static int lbp_setup(nlmc_ctx *c, int n_problems, const double *epsilon, const d
         HIP_TRY(c, c->lbp_src.reserve(E));
         HIP_TRY(c, c->lbp_rev.reserve(E));
         HIP_TRY(c, c->lbp_flag.reserve(1));
-        HIP_TRY(c, hipMemsetAsync(c->lbp_flag.p, 0, sizeof(int32_t), c->stream));
-        hipLaunchKernelGGL(k_lbp_src, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->rowptr.p, c->lbp_src.p);
+        HIP_TRY(c, hipMemsetAsync(c->lbp_flag.p, 0, sizeof(int32_t), c->cur));
+        hipLaunchKernelGGL(k_lbp_src, dim3((n + 255) / 256), dim3(256), 0, c->cur, n, c->rowptr.p, c->lbp_src.p);
         HIP_TRY(c, hipGetLastError());
         if (nnz > 0) {
-            hipLaunchKernelGGL(k_lbp_rev, dim3((nnz + 255) / 256), dim3(256), 0, c->stream, nnz, c->rowptr.p, c->col.p,
+            hipLaunchKernelGGL(k_lbp_rev, dim3((nnz + 255) / 256), dim3(256), 0, c->cur, nnz, c->rowptr.p, c->col.p,
                                c->lbp_src.p, c->lbp_rev.p, c->lbp_flag.p);
             HIP_TRY(c, hipGetLastError());
         }
         int32_t flag = 0;
-        HIP_TRY(c, hipMemcpyAsync(&flag, c->lbp_flag.p, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&flag, c->lbp_flag.p, sizeof(flag), hipMemcpyDeviceToHost, c->cur));
+        HIP_TRY(c, hipStreamSynchronize(c->cur));
         if (flag) return fail(c, NLMC_ERR_ARG, "LBP needs a structurally symmetric J");
         c->lbp_graph_ready = true;
     }
@@ -1861,15 +1882,15 @@ static int lbp_setup(nlmc_ctx *c, int n_problems, const double *epsilon, const d
     // same epsilon, lambda list and beta: no host synchronisation on that path)
     const std::vector<double> eps_h(epsilon, epsilon + n), lam_h(lambdas, lambdas + n_lambdas);
     if (eps_h != c->lbp_eps_host || lam_h != c->lbp_lams_host) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->lbp_eps.p, eps_h.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->lbp_lams.p, lam_h.data(), sizeof(double) * n_lambdas, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->cur));
+        HIP_TRY(c, hipMemcpyAsync(c->lbp_eps.p, eps_h.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->cur));
+        HIP_TRY(c, hipMemcpyAsync(c->lbp_lams.p, lam_h.data(), sizeof(double) * n_lambdas, hipMemcpyHostToDevice, c->cur));
+        HIP_TRY(c, hipStreamSynchronize(c->cur));
         c->lbp_eps_host = eps_h;
         c->lbp_lams_host = lam_h;
     }
     if (nnz > 0 && (!c->lbp_tJ_valid || c->lbp_tJ_beta != beta)) {
-        hipLaunchKernelGGL(k_lbp_tanhJ, dim3((nnz + 255) / 256), dim3(256), 0, c->stream, nnz, c->val64.p, beta, c->lbp_tJ.p);
+        hipLaunchKernelGGL(k_lbp_tanhJ, dim3((nnz + 255) / 256), dim3(256), 0, c->cur, nnz, c->val64.p, beta, c->lbp_tJ.p);
         HIP_TRY(c, hipGetLastError());
         c->lbp_tJ_valid = true;
         c->lbp_tJ_beta = beta;
@@ -1883,8 +1904,8 @@ static int lbp_launch(nlmc_ctx *c, int n_problems, int n_lambdas, double beta, d
 {
     const int n = c->n, nnz = (int)c->nnz;
     const size_t P = (size_t)n_problems;
-    HIP_TRY(c, hipMemsetAsync(c->lbp_mag.p, 0, sizeof(double) * P * n, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->lbp_out_i.p, 0, sizeof(int32_t) * P * (2 + (size_t)n_lambdas), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->lbp_mag.p, 0, sizeof(double) * P * n, c->cur));
+    HIP_TRY(c, hipMemsetAsync(c->lbp_out_i.p, 0, sizeof(int32_t) * P * (2 + (size_t)n_lambdas), c->cur));
     LbpArgs a{};
     a.n = n; a.nnz = nnz; a.n_lams = n_lambdas; a.max_iter = max_iterations;
     a.rowptr = c->rowptr.p; a.col = c->col.p; a.src = c->lbp_src.p; a.rev = c->lbp_rev.p;
@@ -1906,7 +1927,7 @@ static int lbp_launch(nlmc_ctx *c, int n_problems, int n_lambdas, double beta, d
     a.group = group;
     HIP_TRY(c, c->lbp_bar.reserve(P));
     HIP_TRY(c, c->lbp_part.reserve(P * 2 * (size_t)group * 4));
-    HIP_TRY(c, hipMemsetAsync(c->lbp_bar.p, 0, sizeof(unsigned int) * P, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->lbp_bar.p, 0, sizeof(unsigned int) * P, c->cur));
     a.bar = c->lbp_bar.p; a.part = c->lbp_part.p;
     // small instances: messages in LDS, a thread's edges in registers (k_lbp_lds; same bits)
     const int mpt = (nnz + NLMC_LBP_LDS_THREADS - 1) / NLMC_LBP_LDS_THREADS;
@@ -1920,15 +1941,15 @@ static int lbp_launch(nlmc_ctx *c, int n_problems, int n_lambdas, double beta, d
                                         : reinterpret_cast<const void *>(k_lbp_lds<12, true>);
         { int rc = ensure_lds(c, 17 + variant, kf, lds_small); if (rc) return rc; }
         switch (variant) {
-        case 0: hipLaunchKernelGGL((k_lbp_lds<6, false>), dim3(n_problems), dim3(NLMC_LBP_LDS_THREADS), lds_small, c->stream, a); break;
-        case 1: hipLaunchKernelGGL((k_lbp_lds<6, true>), dim3(n_problems), dim3(NLMC_LBP_LDS_THREADS), lds_small, c->stream, a); break;
-        case 2: hipLaunchKernelGGL((k_lbp_lds<12, false>), dim3(n_problems), dim3(NLMC_LBP_LDS_THREADS), lds_small, c->stream, a); break;
-        default: hipLaunchKernelGGL((k_lbp_lds<12, true>), dim3(n_problems), dim3(NLMC_LBP_LDS_THREADS), lds_small, c->stream, a); break;
+        case 0: hipLaunchKernelGGL((k_lbp_lds<6, false>), dim3(n_problems), dim3(NLMC_LBP_LDS_THREADS), lds_small, c->cur, a); break;
+        case 1: hipLaunchKernelGGL((k_lbp_lds<6, true>), dim3(n_problems), dim3(NLMC_LBP_LDS_THREADS), lds_small, c->cur, a); break;
+        case 2: hipLaunchKernelGGL((k_lbp_lds<12, false>), dim3(n_problems), dim3(NLMC_LBP_LDS_THREADS), lds_small, c->cur, a); break;
+        default: hipLaunchKernelGGL((k_lbp_lds<12, true>), dim3(n_problems), dim3(NLMC_LBP_LDS_THREADS), lds_small, c->cur, a); break;
         }
         HIP_TRY(c, hipGetLastError());
         return NLMC_OK;
     }
-    hipLaunchKernelGGL(k_lbp, dim3(n_problems * group), dim3(NLMC_LBP_THREADS), 0, c->stream, a);
+    hipLaunchKernelGGL(k_lbp, dim3(n_problems * group), dim3(NLMC_LBP_THREADS), 0, c->cur, a);
     HIP_TRY(c, hipGetLastError());
     return NLMC_OK;
 }
@@ -1946,14 +1967,14 @@ int nlmc_lbp_convexified(nlmc_ctx *c, int n_problems, const double *m_star, cons
     const int n = c->n;
     const size_t P = (size_t)n_problems;
     { int rc = lbp_setup(c, n_problems, epsilon, lambdas, n_lambdas, beta, out_mag_all != nullptr); if (rc) return rc; }
-    HIP_TRY(c, hipMemcpyAsync(c->lbp_ms.p, m_star, sizeof(double) * P * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->lbp_ms.p, m_star, sizeof(double) * P * n, hipMemcpyHostToDevice, c->cur));
     { int rc = lbp_launch(c, n_problems, n_lambdas, beta, tolerance, max_iterations, sat, out_mag_all != nullptr); if (rc) return rc; }
     std::vector<int32_t> oi(P * (2 + (size_t)n_lambdas));
-    HIP_TRY(c, hipMemcpyAsync(oi.data(), c->lbp_out_i.p, sizeof(int32_t) * oi.size(), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(out_mag, c->lbp_mag.p, sizeof(double) * P * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(oi.data(), c->lbp_out_i.p, sizeof(int32_t) * oi.size(), hipMemcpyDeviceToHost, c->cur));
+    HIP_TRY(c, hipMemcpyAsync(out_mag, c->lbp_mag.p, sizeof(double) * P * n, hipMemcpyDeviceToHost, c->cur));
     if (out_mag_all)
-        HIP_TRY(c, hipMemcpyAsync(out_mag_all, c->lbp_mag_all.p, sizeof(double) * P * (size_t)n_lambdas * n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpyAsync(out_mag_all, c->lbp_mag_all.p, sizeof(double) * P * (size_t)n_lambdas * n, hipMemcpyDeviceToHost, c->cur));
+    HIP_TRY(c, hipStreamSynchronize(c->cur));
     for (size_t q = 0; q < P; ++q)
         if (oi[P + q] == 2) return fail(c, NLMC_ERR_HIP, "nlmc_lbp_convexified: the workgroups of a problem lost each other (group barrier timed out)");
     std::memcpy(out_n_lambdas, oi.data(), sizeof(int32_t) * P);
@@ -1995,7 +2016,46 @@ int nlmc_select_chains(nlmc_ctx *c, int which)
     if (!c) return NLMC_ERR_ARG;
     if (which < NLMC_CHAINS_ALL || which > NLMC_CHAINS_MARKED) return fail(c, NLMC_ERR_ARG, "nlmc_select_chains: bad selector");
     if (which != NLMC_CHAINS_ALL && !c->slot_mark.p) return fail(c, NLMC_ERR_STATE, "nlmc_select_chains: call nlmc_pt_mark_slots first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    // the subset-aware launches of the marked chains go to the second stream when overlap is on: forked from the main stream
+    // where the first subset of a round is selected (after the chain lists are up to date, before any subset work is
+    // queued), joined again where all chains are selected
+    if (which != NLMC_CHAINS_ALL) {
+        c->subset = which;
+        if (c->cur == c->stream) { int rc = ensure_subset(c); if (rc) return rc; }
+        if (c->overlap && !c->forked) {
+            HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+            c->forked = true;
+        }
+        if (c->overlap && which == NLMC_CHAINS_MARKED && c->cur == c->stream) {
+            HIP_TRY(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+            c->cur = c->aux;
+        } else if (which == NLMC_CHAINS_UNMARKED && c->cur != c->stream) {
+            return fail(c, NLMC_ERR_STATE, "nlmc_select_chains: select all chains between the marked and the unmarked subset of a round");
+        }
+        return NLMC_OK;
+    }
+    if (c->cur != c->stream) {
+        HIP_TRY(c, hipEventRecord(c->ev_join, c->aux));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        c->cur = c->stream;
+    }
+    c->forked = false;
     c->subset = which;
+    return NLMC_OK;
+}
+
+int nlmc_overlap_subsets(nlmc_ctx *c, int on)
+{
+    if (!c) return NLMC_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->cur != c->stream) return fail(c, NLMC_ERR_STATE, "nlmc_overlap_subsets: select all chains first");
+    if (on && !c->aux) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    c->overlap = on != 0;
     return NLMC_OK;
 }
 
@@ -2008,8 +2068,8 @@ int nlmc_get_subset(nlmc_ctx *c, int32_t *out_chains)
     const int R = c->sub_count();
     if (c->subset == 0) { for (int i = 0; i < R; ++i) out_chains[i] = i; return NLMC_OK; }
     { int rc = ensure_subset(c); if (rc) return rc; }
-    HIP_TRY(c, hipMemcpyAsync(out_chains, c->sub_list(), sizeof(int32_t) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out_chains, c->sub_list(), sizeof(int32_t) * (size_t)R, hipMemcpyDeviceToHost, c->cur));
+    HIP_TRY(c, hipStreamSynchronize(c->cur));
     return NLMC_OK;
 }
 
@@ -2027,7 +2087,7 @@ int nlmc_adopt_best(nlmc_ctx *c)
     const int R = c->sub_count();
     if (R == 0) return NLMC_OK;
     { int rc = ensure_subset(c); if (rc) return rc; }
-    hipLaunchKernelGGL(k_adopt_best, dim3(R), dim3(256), 0, c->stream, c->n_pad, c->sub_list(), c->spins.p, c->best.p, c->efix.p, c->emin.p);
+    hipLaunchKernelGGL(k_adopt_best, dim3(R), dim3(256), 0, c->cur, c->n_pad, c->sub_list(), c->spins.p, c->best.p, c->efix.p, c->emin.p);
     HIP_TRY(c, hipGetLastError());
     return NLMC_OK;
 }
@@ -2048,14 +2108,14 @@ int nlmc_backbone_clusters(nlmc_ctx *c, const double *epsilon, const double *lam
     const std::vector<double> thr(thresholds, thresholds + n_thresholds);
     if (thr != c->nmc_thr_host) {
         HIP_TRY(c, c->nmc_thr.reserve((size_t)n_thresholds));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->cur));
         HIP_TRY(c, hipMemcpy(c->nmc_thr.p, thr.data(), sizeof(double) * thr.size(), hipMemcpyHostToDevice));
         c->nmc_thr_host = thr;
     }
-    hipLaunchKernelGGL(k_lbp_seeds, dim3(P), dim3(256), 0, c->stream, c->n, c->n_pad, c->sub_list(), c->spins.p, c->lbp_ms.p);
+    hipLaunchKernelGGL(k_lbp_seeds, dim3(P), dim3(256), 0, c->cur, c->n, c->n_pad, c->sub_list(), c->spins.p, c->lbp_ms.p);
     HIP_TRY(c, hipGetLastError());
     { int rc = lbp_launch(c, P, n_lambdas, beta, tolerance, max_iterations, sat, false); if (rc) return rc; }
-    hipLaunchKernelGGL(k_cluster_mask, dim3(P), dim3(256), (size_t)2 * c->n_pad, c->stream, c->g, c->sub_list(), c->lbp_mag.p,
+    hipLaunchKernelGGL(k_cluster_mask, dim3(P), dim3(256), (size_t)2 * c->n_pad, c->cur, c->g, c->sub_list(), c->lbp_mag.p,
                        c->lbp_out_i.p + P, c->nmc_thr.p, n_thresholds, c->cmask.p, c->nmc_status.p);
     HIP_TRY(c, hipGetLastError());
     return NLMC_OK;
@@ -2101,7 +2161,7 @@ int nlmc_set_phase(nlmc_ctx *c, int kind, double temp_x)
     const int R = c->sub_count();
     if (R > 0) {
         { int rc = ensure_subset(c); if (rc) return rc; }
-        hipLaunchKernelGGL(k_phase_flags, dim3(R), dim3(256), 0, c->stream, c->n_pad, c->sub_list(), c->cmask.p, kind, c->flags.p);
+        hipLaunchKernelGGL(k_phase_flags, dim3(R), dim3(256), 0, c->cur, c->n_pad, c->sub_list(), c->cmask.p, kind, c->flags.p);
         HIP_TRY(c, hipGetLastError());
     }
     c->has_flags = true;

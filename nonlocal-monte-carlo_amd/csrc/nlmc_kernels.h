@@ -595,6 +595,14 @@ struct SweepArgs {
                               // 512 / 1024 = bank-conflict-free addresses for the neighbour gather / the spin's own accesses (wrong results)
 };
 
+// a wave-uniform 64-bit value pinned into scalar registers (a uniform value in a vector register costs 64 lanes, a spilled
+// scalar one lane of a spill register)
+__device__ __forceinline__ long long uniform64(long long v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 // ---- pieces shared by the two sweep kernels ------------------------------------------------------------
 struct ChainCtx {
     long long *st;            // diagnostic build: per-thread stamp sums inside update_spin
@@ -630,9 +638,9 @@ __device__ __forceinline__ void chain_load(const SweepArgs &a, unsigned char *ld
     }
     if (x.tid == 0) { x.red[0] = 0; x.red[1] = 0; }
     x.e_loc = 0;
-    x.E = a.efix[x.c];
-    x.Emin = a.emin ? a.emin[x.c] : 0;
-    x.amin = a.emin ? a.argmin[x.c] : 0;
+    x.E = uniform64(a.efix[x.c]);          // E, Emin, amin: the same value in every thread, kept in scalar registers
+    x.Emin = a.emin ? uniform64(a.emin[x.c]) : 0;
+    x.amin = a.emin ? __builtin_amdgcn_readfirstlane(a.argmin[x.c]) : 0;
     x.per_sweep = (a.etrace != nullptr) || (a.emin != nullptr);
     __syncthreads();
 }
@@ -642,21 +650,20 @@ __device__ __forceinline__ void sweep_epilogue(const SweepArgs &a, ChainCtx &x, 
 {
     const int tg = a.t0 + t;                                 // sweep index inside the call
     const bool rec = a.strace && (tg % a.rec_stride == 0);   // M[:, ::M_skip]  (NMC/nmc.py:390)
+    bool read_spins = rec;                                   // the LDS spins are copied out below (workgroup-uniform)
     if (x.per_sweep) {
         const long long w = wave_sum_i64(x.e_loc);
         x.e_loc = 0;
         if ((x.tid & 63) == 0 && w != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&x.red[0]), (unsigned long long)w);
         __syncthreads();
-        if (x.tid == 0) {
-            x.E += x.red[0];
-            x.red[0] = 0;
-            if (a.etrace) a.etrace[(size_t)x.ob * a.trace_sweeps + tg] = x.E;
-            int better = 0;
-            if (a.emin && x.E < x.Emin) { x.Emin = x.E; x.amin = tg; better = 1; }   // strict <: first argmin (np.argmin)
-            x.red[1] = better;
-        }
-        __syncthreads();
-        if (a.best && x.red[1]) {
+        x.E += uniform64(x.red[0]);              // every thread: the sum stays wave-uniform (no broadcast of the decision)
+        const bool better = a.emin && x.E < x.Emin;                                  // strict <: first argmin (np.argmin)
+        if (better) { x.Emin = x.E; x.amin = tg; }
+        if (x.tid == 0 && a.etrace) a.etrace[(size_t)x.ob * a.trace_sweeps + tg] = x.E;
+        __syncthreads();                         // everybody has read the sum
+        if (x.tid == 0) x.red[0] = 0;            // (next added to at the end of the next sweep, many barriers from here)
+        if (a.best && better) {
+            read_spins = true;
             int4 *dst = reinterpret_cast<int4 *>(a.best + (size_t)x.c * x.n_pad);
             const int4 *src = reinterpret_cast<const int4 *>(x.s);
             for (int i = x.tid; i < x.n_pad / 16; i += x.nt) dst[i] = src[i];
@@ -667,7 +674,7 @@ __device__ __forceinline__ void sweep_epilogue(const SweepArgs &a, ChainCtx &x, 
         int8_t *dst = a.strace + ((size_t)x.ob * n_rec + (size_t)(tg / a.rec_stride)) * x.n;
         for (int i = x.tid; i < x.n; i += x.nt) dst[i] = x.s[i];
     }
-    if (x.per_sweep || rec) __syncthreads();   // LDS spins / red[1] are rewritten next sweep
+    if (read_spins) __syncthreads();           // LDS spins are rewritten next sweep
 }
 
 __device__ __forceinline__ void chain_store(const SweepArgs &a, ChainCtx &x)
@@ -676,7 +683,7 @@ __device__ __forceinline__ void chain_store(const SweepArgs &a, ChainCtx &x)
         const long long w = wave_sum_i64(x.e_loc);
         if ((x.tid & 63) == 0 && w != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&x.red[0]), (unsigned long long)w);
         __syncthreads();
-        if (x.tid == 0) x.E += x.red[0];
+        x.E += uniform64(x.red[0]);
     }
     int4 *dst = reinterpret_cast<int4 *>(a.spins + (size_t)x.c * x.n_pad);
     const int4 *src = reinterpret_cast<const int4 *>(x.s);
@@ -1133,7 +1140,7 @@ __device__ __forceinline__ void run_levels(const SweepArgs &a, ChainCtx &x, cons
 }
 
 template <typename T, bool DIAG>
-__global__ void k_sweep_philox(SweepArgs a)
+__global__ __launch_bounds__(sizeof(T) == 8 ? 512 : DIAG ? 768 : 1024) void k_sweep_philox(SweepArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     ChainCtx x;
@@ -1366,7 +1373,7 @@ struct FusedGenParams { uint32_t gc; int gtid, gnt, nblk, nj, Tn; };
     if (!(NLMC_GEN_DBG_OFF_COND) && (l) > g_w0) {                                                                       \
         g_acc += NLMC_GEN_NSTEP * gp.nj;                                                                                \
         while (g_acc >= g_wlen) { g_acc -= g_wlen; if (g_sidx < NLMC_GEN_NSTEP * gp.nj) NLMC_GEN_STEP(a, gp) }          \
-        if ((l) == g_wend) {                                                                                            \
+        if (__builtin_expect((l) == g_wend, 0)) {                                                                       \
             while (g_sidx < NLMC_GEN_NSTEP * gp.nj) NLMC_GEN_STEP(a, gp)                                                \
             ++g_u; g_slot = g_slot == 2 ? 0 : g_slot + 1; NLMC_GEN_ARM(a, gp)                                           \
         }                                                                                                               \
@@ -1396,11 +1403,13 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
     float cqo0 = cq0, cqo1 = cq1, cqn0 = cq0, cqn1 = cq1;  // coefficients of the older / the newer live sweep
     const int o_row = a.slot_of_chain ? a.slot_of_chain[a.chain_base + o_c] : o_c;
 #define NLMC_OCQ(t, j) ((float)((const_f64o)(uintptr_t)a.tab)[(size_t)o_row * a.tab_cs + (size_t)min((t), a.n_sweeps - 1) * a.tab_ss + (j)] * a.qinv)
+    // (wave-uniform 64-bit values are pinned into scalar registers: a uniform value in a vector register costs 64 lanes, a
+    // spilled scalar one lane)
     if (OUT) {
         o_end = ((const_i32o)(uintptr_t)a.fsend)[0];
-        E_run = a.efix[o_c];
-        E_min = a.emin ? a.emin[o_c] : 0x7FFFFFFFFFFFFFFFll;
-        a_min = a.emin ? a.argmin[o_c] : 0;
+        E_run = uniform64(a.efix[o_c]);
+        E_min = a.emin ? uniform64(a.emin[o_c]) : 0x7FFFFFFFFFFFFFFFll;
+        a_min = a.emin ? __builtin_amdgcn_readfirstlane(a.argmin[o_c]) : 0;
         cqn0 = NLMC_OCQ(1, 0); cqn1 = NLMC_OCQ(1, 1);
     }
     typedef FusedItem<FMT> Item;
@@ -1543,7 +1552,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
     {                                                                                                                   \
         long long *red_ = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);                                       \
         const int slot_ = o_t % 3, tg_ = a.t0 + o_t;                                                                    \
-        E_run += red_[slot_];                                                                                           \
+        E_run += uniform64(red_[slot_]);                                                                                \
         const bool better_ = a.emin && E_run < E_min;        /* strict <: first argmin (np.argmin, NMC/nmc.py:394) */    \
         if (better_) { E_min = E_run; a_min = tg_; }                                                                    \
         if (o_tid == 0) {                                                                                               \
@@ -1591,7 +1600,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             if (GEN) NLMC_GEN(a, gp, lv)                                                    \
             if (hcur) { update(cur); NLMC_FCALL }                                           \
             issue(nxt, (b2) + wv, hnxt NLMC_DBG_NOLOAD);                                    \
-            const bool end_ = OUT && (lv) == o_end;                                         \
+            const bool end_ = OUT && __builtin_expect((lv) == o_end, 0);   /* rare: once per sweep */ \
             if (end_) NLMC_OUT_PRE                                                          \
             NLMC_FW1                                                                        \
             NLMC_DBG_BARRIER                                                                \
@@ -1620,7 +1629,9 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
     }
 }
 
-template <bool DIAG, bool FLAGS, bool OUT = false>
+// FMT is a parameter of the KERNEL (round 3; it was a run-time switch over three inlined copies of every level-loop
+// variant: 12 copies per kernel, whose spilled scalars together took 19 vector registers of the per-sweep-output kernels)
+template <bool DIAG, bool FLAGS, bool OUT, int FMT>
 __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -1685,13 +1696,9 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
     if (wv < a.f_workers) {
         const bool role_long = wv < a.hi_max[0];           // chunks that may hold lane PAIRS (rows longer than 8 entries) come first
         const int variant = (role_long ? 2 : 0) + (is_gen ? 1 : 0);
-#define NLMC_FL(P, G, F) fused_levels<DIAG, FLAGS, P, G, F, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp)
-#define NLMC_FL4(F) switch (variant) { case 0: NLMC_FL(false, false, F); break; case 1: NLMC_FL(false, true, F); break; \
-                                       case 2: NLMC_FL(true, false, F); break; default: NLMC_FL(true, true, F); break; }
-        if (a.fz_fmt == NLMC_FMT_ADDR) NLMC_FL4(NLMC_FMT_ADDR)
-        else if (a.fz_fmt == NLMC_FMT_COMPACT) NLMC_FL4(NLMC_FMT_COMPACT)
-        else NLMC_FL4(NLMC_FMT_WIDE)
-#undef NLMC_FL4
+#define NLMC_FL(P, G) fused_levels<DIAG, FLAGS, P, G, FMT, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp)
+        switch (variant) { case 0: NLMC_FL(false, false); break; case 1: NLMC_FL(false, true); break;
+                           case 2: NLMC_FL(true, false); break; default: NLMC_FL(true, true); break; }
 #undef NLMC_FL
     } else {
         // Waves without schedule items: their share of the thresholds, and they pull the NEXT window's schedule towards
@@ -1706,7 +1713,7 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
         const unsigned warm_lines = a.warm_head ? (unsigned)(((size_t)a.fz_npos_next * 8 + 127) / 128) : 0u;       // head
         const unsigned warm_lines_p = a.warm_head ? (unsigned)(((size_t)a.fz_pstride * 16 + 127) / 128) : 0u;     // lines per plane
         const unsigned warm_used_p = a.warm_head ? (unsigned)(((size_t)a.fz_npos_next * 16 + 127) / 128) : 0u;     // touched lines per plane
-        const unsigned warm_total = warm_lines + (a.fz_fmt == NLMC_FMT_ADDR ? 1u : a.fz_fmt == NLMC_FMT_COMPACT ? 2u : 4u) * warm_used_p;
+        const unsigned warm_total = warm_lines + (FMT == NLMC_FMT_ADDR ? 1u : FMT == NLMC_FMT_COMPACT ? 2u : 4u) * warm_used_p;
         unsigned warm_at = (unsigned)blockIdx.x * (unsigned)hcnt + (unsigned)hid;
         const unsigned warm_step = gridDim.x * (unsigned)hcnt;
         // four touches in flight (a touch of a cold line takes longer than a level: waiting for the previous one every

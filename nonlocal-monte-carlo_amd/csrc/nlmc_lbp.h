@@ -4,7 +4,7 @@
 // stored CSR entry e = (i -> j) of row i carries
 //     w[e]  = u_msgs[j, i]   the message INCOMING to i from j (so a node's total is a contiguous row sum)
 //     hm[e] = h_msgs[i, j]   the cavity field of i without j
-// 1-8 workgroups of 1024 threads per problem (one m_star), see k_lbp; all lambdas of LBP_convexified run inside one launch; Jacobi
+// 1-8 workgroups of NLMC_LBP_THREADS threads per problem (one m_star), see k_lbp (small instances: k_lbp_lds); all lambdas of LBP_convexified run inside one launch; Jacobi
 // iteration with ping-pong message buffers in global memory (L2 resident: 2 * nnz doubles per problem).
 // Arithmetic: fp64 in the reference's operation order, row sums sequential in ascending neighbour index (the
 // reference's `total` uses NumPy's pairwise association and NumPy's own tanh/arctanh, so results agree to rounding,
@@ -12,7 +12,7 @@
 #pragma once
 #include "nlmc_kernels.h"
 
-#define NLMC_LBP_THREADS 1024
+#define NLMC_LBP_THREADS 768     // 12 waves: 170 registers per lane (at 1024 threads the 128-register cap spilled 26 of them)
 
 struct LbpArgs {
     int n, nnz, n_lams, max_iter;

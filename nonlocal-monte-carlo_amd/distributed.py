@@ -154,8 +154,10 @@ class LocalTempering:
         if not marks.any():
             self.nmc = None
             return
+        import os
         for e in self.engs:
             e.mark_slots(marks)
+            e.overlap_subsets(not os.environ.get("NLMC_NO_OVERLAP"))      # plain chains' sweeps beside the NMC chains' work
         self.nmc = dict(phases=list(phases), S=int(sweeps_per_phase), beta=float(global_beta), temp_x=float(temp_x),
                         epsilon=np.asarray(epsilon, dtype=np.float64), lambdas=np.asarray(lambdas, dtype=np.float64),
                         tol=float(tolerance), max_it=int(max_iterations), sat=float(sat),

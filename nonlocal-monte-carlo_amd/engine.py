@@ -178,17 +178,7 @@ class Engine:
                 t1 = min(S, t0 + chunk)
                 outs.append(self.sweep_stream(perm[:, t0:t1], u[:, t0:t1], b if b.ndim == 0 else b[:, t0:t1], record_stride,
                                               want_energy, want_min, want_state))
-            o = {"spins": np.concatenate([p["spins"] for p in outs], axis=1) if record_stride else None,
-                 "energy": np.concatenate([p["energy"] for p in outs], axis=1) if want_energy else None,
-                 "min_energy": None, "argmin": None, "argmin_state": None}
-            if want_min:
-                mins = np.stack([p["min_energy"] for p in outs])           # [chunks, R]
-                first = np.argmin(mins, axis=0)                            # np.argmin: first chunk holding the minimum
-                o["min_energy"] = mins[first, np.arange(R)]
-                o["argmin"] = np.array([outs[first[r]]["argmin"][r] + first[r] * chunk for r in range(R)], dtype=np.int32)
-                if want_state:
-                    o["argmin_state"] = np.stack([outs[first[r]]["argmin_state"][r] for r in range(R)])
-            return o
+            return _stitch_outputs(outs, chunk, record_stride, want_energy, want_min, want_state)
         perm = _abi.as_c(perm, np.int32)
         u = _abi.as_c(u, np.float64)
         tab, cs, ss = _beta_table(beta, R, S)
@@ -216,6 +206,48 @@ class Engine:
                                            max(1, record_stride), _abi.ptr(o["spins"]), _abi.ptr(o["energy"]),
                                            _abi.ptr(o["min_energy"]), _abi.ptr(o["argmin"]),
                                            _abi.ptr(o["argmin_state"])))
+        return o
+
+    FUSED_PLAN_BUDGET = 1 << 30        # bytes of fused-window plan one sweep_philox_windows piece may hold
+
+    def fused_plan_bytes(self, window):
+        return fused_plan_bytes(self.n, int(np.count_nonzero(np.diff(self.inst.indptr) > 8)), window)
+
+    def sweep_philox_windows(self, n_sweeps, seed, sweep0=0, beta=None, window=None, budget_bytes=None, record_stride=0,
+                             want_energy=False, want_min=False, want_state=False, want_recorded_energy=False):
+        """sweep_philox on fused windows planned piece by piece against a memory budget (one planning call for a
+        whole run of 10^4 sweeps takes 23 GB at N = 10^3, 230 GB at N = 10^4): the call is cut into pieces of at most
+        budget_bytes / fused_plan_bytes windows, each planned, swept and dropped; pieces whose plan is refused (instance or
+        window outside what the fused kernels take) run sweep by sweep -- same bits.  Outputs are stitched together exactly
+        as one call would return them (trace, energies, first argmin).  want_recorded_energy: o["energy_recorded"] = fp64
+        energies of the recorded configurations [rows, n_recorded], computed on the device copy of each piece's trace."""
+        S = int(n_sweeps)
+        T = fused_window(S) if window is None else int(window)
+        budget = self.FUSED_PLAN_BUDGET if budget_bytes is None else int(budget_bytes)
+        rec_e = bool(want_recorded_energy and record_stride)
+        if not T or S % T or S == 0:
+            self.fused_last_call = False
+            o = self.sweep_philox(S, seed, sweep0=sweep0, beta=beta, record_stride=record_stride, want_energy=want_energy,
+                                  want_min=want_min, want_state=want_state)
+            if rec_e and S > 0:
+                o["energy_recorded"] = self.energy_of_recorded(o["spins"].shape[1])
+            return o
+        per_piece = sweeps_per_plan_piece(self.fused_plan_bytes(T), S, T, budget, record_stride)
+        b = None if beta is None else np.asarray(beta, dtype=np.float64)
+        outs, fused = [], True
+        for t0 in range(0, S, per_piece):
+            t1 = min(S, t0 + per_piece)
+            if fused:
+                fused = self.plan_philox_fused(sweep0 + t0, (t1 - t0) // T, T, seed) == (t1 - t0) // T     # refused once: stop asking
+            outs.append(self.sweep_philox(t1 - t0, seed, sweep0=sweep0 + t0, beta=b if (b is None or b.ndim < 2) else b[:, t0:t1],
+                                          record_stride=record_stride, want_energy=want_energy, want_min=want_min,
+                                          want_state=want_state))
+            if rec_e:
+                outs[-1]["energy_recorded"] = self.energy_of_recorded(outs[-1]["spins"].shape[1])
+        self.fused_last_call = fused
+        o = outs[0] if len(outs) == 1 else _stitch_outputs(outs, per_piece, record_stride, want_energy, want_min, want_state)
+        if rec_e and len(outs) > 1:
+            o["energy_recorded"] = np.concatenate([p["energy_recorded"] for p in outs], axis=1)
         return o
 
     def plan_philox(self, sweep0, n_sweeps, seed, precision="f32"):
@@ -304,6 +336,10 @@ class Engine:
         currently on "unmarked" / "marked" temperature slots."""
         w = {"all": _abi.CHAINS_ALL, "unmarked": _abi.CHAINS_UNMARKED, "marked": _abi.CHAINS_MARKED}[which]
         self._ck(self._L.nlmc_select_chains(self._ctx, w))
+
+    def overlap_subsets(self, on=True):
+        """Queue the marked subset's work on a second stream beside the unmarked chains' sweeps (nlmc_overlap_subsets)."""
+        self._ck(self._L.nlmc_overlap_subsets(self._ctx, int(bool(on))))
 
     def subset(self):
         out = np.empty(self.rows(), dtype=np.int32)
@@ -439,8 +475,42 @@ def trace_layout(spins, dst_block=None, n_dst_blocks=None, dtype=np.float64, n_t
     return M
 
 
+def _stitch_outputs(outs, chunk, record_stride, want_energy, want_min, want_state):
+    """Outputs of consecutive pieces of one logical sweep call (pieces of `chunk` sweeps) -> what one call would return."""
+    R = outs[0]["spins"].shape[0] if record_stride else (outs[0]["energy"].shape[0] if want_energy else len(outs[0]["min_energy"]))
+    o = {"spins": np.concatenate([p["spins"] for p in outs], axis=1) if record_stride else None,
+         "energy": np.concatenate([p["energy"] for p in outs], axis=1) if want_energy else None,
+         "min_energy": None, "argmin": None, "argmin_state": None}
+    if want_min:
+        mins = np.stack([p["min_energy"] for p in outs])           # [pieces, R]
+        first = np.argmin(mins, axis=0)                            # np.argmin: first piece holding the minimum
+        o["min_energy"] = mins[first, np.arange(R)]
+        o["argmin"] = np.array([outs[first[r]]["argmin"][r] + first[r] * chunk for r in range(R)], dtype=np.int32)
+        if want_state:
+            o["argmin_state"] = np.stack([outs[first[r]]["argmin_state"][r] for r in range(R)])
+    return o
+
+
 def device_count():
     return int(_abi.lib().nlmc_device_count())
+
+
+def fused_plan_bytes(n, n_long, window):
+    """Upper estimate of the device memory one planned window of `window` sweeps takes (head 8 + row planes <= 64 + item ids
+    4 bytes per schedule position, 2 bytes per update of level scratch): what nlmc_plan_philox_fused allocates per window
+    (csrc/nlmc.hip: reserve_fused_plan, fused_pstride).  n_long: rows longer than 8 entries (two positions each)."""
+    pstride = -(-int(window) * (int(n) + int(n_long)) // 64) * 64 + 64 * 1024
+    return pstride * 76 + int(window) * int(n) * 2 + 8192
+
+
+def sweeps_per_plan_piece(bytes_per_window, n_sweeps, window, budget_bytes, record_stride=0):
+    """Sweeps one piece of Engine.sweep_philox_windows covers: as many whole windows as fit the budget (at least one),
+    starting on a recorded sweep when configurations are recorded with a stride."""
+    per_piece = max(1, int(budget_bytes) // int(bytes_per_window)) * int(window)
+    if record_stride > 1:
+        L = int(np.lcm(int(window), int(record_stride)))
+        per_piece = per_piece // L * L or int(n_sweeps)
+    return min(per_piece, int(n_sweeps))
 
 
 def fused_window(n_sweeps, lo=3, hi=64):

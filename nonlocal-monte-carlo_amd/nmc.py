@@ -8,7 +8,6 @@ import numpy as np
 
 from . import hostlogic
 from .base import Common
-from .engine import fused_window
 
 
 class NMC(Common):
@@ -52,8 +51,8 @@ class NMC(Common):
                      max_iterations=100, tolerance=np.finfo(float).eps, all_clusters=None):
         """Throughput extension (not in the reference): `num_restarts` independent NMC runs of run()'s algorithm batched
         in ONE context -- anneal, then per cycle the three phases (NMC/nmc.py:365-433), every phase one launch over all
-        restarts with per-restart cluster flags, the argmin-energy state of each phase handed to the next on the
-        device side of the C-ABI.  Device RNG (philox) whatever `rng` says.  `all_clusters`: one index array used by
+        restarts with per-restart cluster flags, the argmin-energy state of each phase handed to the next.  Device RNG
+        (philox) whatever `rng` says, "f32" arithmetic (24-bit fixed-point couplings).  `all_clusters`: one index array used by
         every restart and cycle (skips the host-side backbone inference), or None to infer clusters per restart and
         cycle like run() does.  Returns (min_energy [R], best_state [R, N] int8, energy_of_phase_minima [R, phases])."""
         norm_factor = np.max(np.abs(self.J))
@@ -75,7 +74,9 @@ class NMC(Common):
             nonlocal sweep0, best_e, best_s
             eng.set_spins(state)
             eng.set_flags(flags, temp_x)
-            o = eng.sweep_philox(n_sweeps, self.seed, sweep0=sweep0, beta=beta_tab, want_min=True, want_state=True)
+            # fused windows planned piece by piece against a memory budget (Engine.sweep_philox_windows; instances / lengths
+            # the fused kernels do not take run sweep by sweep, same bits)
+            o = eng.sweep_philox_windows(n_sweeps, self.seed, sweep0=sweep0, beta=beta_tab, want_min=True, want_state=True)
             sweep0 += n_sweeps
             better = o["min_energy"] < best_e
             best_e = np.where(better, o["min_energy"], best_e)
@@ -83,19 +84,11 @@ class NMC(Common):
             trail.append(o["min_energy"].copy())
             return o["argmin_state"].copy()
 
-        # Fused windows with per-sweep outputs (running minimum + argmin state, a temperature per sweep) for every
-        # launch: the anneal's windows, then ALL phases' windows in one planning call (they depend on the sweep index
-        # only).  Instances / lengths the fused kernels do not take fall back to the sweep-by-sweep schedule.
         if S0 > 0:
-            if fused_window(S0):
-                eng.plan_philox_fused(sweep0, S0 // fused_window(S0), fused_window(S0), self.seed)
             sched = hostlogic.beta_schedule(S0, global_beta, True, 1, 0)
             m = launch(m, S0, np.repeat(sched[None, :], R, axis=0), None)
         m_star = m.copy()
         flat = np.full((R, S), float(global_beta)) if S > 0 else None
-        n_phase_launches = sum(2 + (1 if cyc % full_update_frequency == 0 else 0) for cyc in range(num_NMC_cycles))
-        if S > 0 and fused_window(S):
-            eng.plan_philox_fused(sweep0, n_phase_launches * (S // fused_window(S)), fused_window(S), self.seed)
         for cycle in range(num_NMC_cycles):
             if S == 0:
                 break

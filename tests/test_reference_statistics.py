@@ -137,9 +137,42 @@ def test_engine_min_energies_match_the_reference(product, precision):
     se = np.hypot(m_ref.std(ddof=1) / np.sqrt(len(m_ref)), m_us.std(ddof=1) / np.sqrt(n_restarts))
     z = (m_us.mean() - m_ref.mean()) / se
     assert abs(z) < SIGMAS, f"mean minimum: ours {m_us.mean():.2f} vs reference {m_ref.mean():.2f} ({z:.1f} sigma)"
+    # frequency of the best energy EITHER side has seen (no assumption that the reference's 40 runs found the optimum: if the
+    # device path finds something lower, k_ref is 0 and the two-sided test decides whether that is luck)
     best = min(m_us.min(), m_ref.min())
-    assert best >= -166.0 - 1e-9                               # nobody beats the best energy the reference has seen by luck
-    k_ref, k_us = float((m_ref <= -166.0 + 1e-9).sum()), float((m_us <= -166.0 + 1e-9).sum())
+    k_ref, k_us = float((m_ref <= best + 1e-9).sum()), float((m_us <= best + 1e-9).sum())
     p = (k_ref + k_us) / (len(m_ref) + n_restarts)
     sep = np.sqrt(max(p * (1 - p), 1e-4) * (1 / len(m_ref) + 1 / n_restarts))
     assert abs(k_us / n_restarts - k_ref / len(m_ref)) < SIGMAS * sep
+
+@pytest.mark.gpu
+def test_nmc_run_min_energies_on_gaussian_couplings_match_the_reference(product):
+    """the single-chain device-RNG path (NMC.run: anneal, backbone inference, three phases with argmin hand-offs)
+    runs its dynamics on 24-bit fixed-point couplings for N >= 256; on a Gaussian-coupling instance that is a (stated)
+    approximation, so it is compared with the reference the way two Monte Carlo codes are: the distribution of the minimum
+    energy 40 reference runs reach under a short budget (fixture) against 64 runs of the drop-in with rng="philox"."""
+    import contextlib
+    import io
+    g, csr = _fixture("stats_nmc_run_gsparse256")
+    J = csr.toarray()
+    kw = dict(num_sweeps_initial=int(g["num_sweeps_initial"]), num_sweeps_per_NMC_phase=int(g["num_sweeps_per_NMC_phase"]),
+              num_NMC_cycles=int(g["num_NMC_cycles"]), full_update_frequency=int(g["full_update_frequency"]), M_skip=1,
+              temp_x=float(g["temp_x"]), global_beta=float(g["global_beta"]), lambda_start=float(g["lambda_start"]),
+              lambda_end=float(g["lambda_end"]), lambda_reduction_factor=float(g["lambda_reduction_factor"]),
+              threshold_initial=float(g["threshold_initial"]), threshold_cutoff=float(g["threshold_cutoff"]),
+              max_iterations=int(g["max_iterations"]))
+    mins, lasts = [], []
+    for s in range(64):
+        obj = product.NMC(J.copy(), g["h"].copy(), rng="philox", seed=4000 + s)
+        with contextlib.redirect_stdout(io.StringIO()):
+            M, E, mn = obj.run(**kw)
+        assert M.shape == (csr.n, 3 * kw["num_NMC_cycles"] * kw["num_sweeps_per_NMC_phase"])
+        # the energies handed back are the fp64 energies of the recorded configurations (normalised J, h like the reference)
+        k = int(np.argmin(E))
+        assert abs(E[k] - oracle.energy(oracle.Csr(obj.J), obj.h, M[:, k].astype(np.int8))) < 1e-9 and mn == E.min()
+        mins.append(mn)
+        lasts.append(E[-1])
+    for name, ours, ref in (("minimum", np.array(mins), g["min_energy"]), ("last", np.array(lasts), g["last_energy"])):
+        se = np.hypot(ref.std(ddof=1) / np.sqrt(len(ref)), ours.std(ddof=1) / np.sqrt(len(ours)))
+        z = (ours.mean() - ref.mean()) / se
+        assert abs(z) < SIGMAS, f"{name} energy: ours {ours.mean():.3f} vs reference {ref.mean():.3f} ({z:.1f} sigma)"

@@ -501,10 +501,36 @@ def gen_stats_min_mixed():
          **{k: np.float64(v) for k, v in kw.items()})
 
 
+def gen_stats_nmc():
+    """Minimum energies NMC.run (NMC/nmc.py:442-520: anneal, then cycles of backbone inference + three phases with argmin
+    hand-offs) reaches on a GAUSSIAN-coupling instance of 256 spins under a short budget, 40 independent runs: the yardstick
+    for the single-chain device-RNG path, whose dynamics run on 24-bit fixed-point couplings (no reference-derived
+    fixture covered NMC phases under that arithmetic on non-integer couplings)."""
+    J, h = inst_gauss_sparse(256, 9)
+    kw = dict(num_sweeps_initial=60, num_sweeps_per_NMC_phase=24, num_NMC_cycles=2, full_update_frequency=1, M_skip=1, temp_x=20,
+              global_beta=3.0, lambda_start=3.0, lambda_end=0.05, lambda_reduction_factor=0.8, threshold_initial=0.9999,
+              threshold_cutoff=0.97, max_iterations=100)
+    runs = 40
+    mins, lasts, sizes = np.zeros(runs), np.zeros(runs), []
+    for s in range(runs):
+        obj = ref_nmc.NMC(J.copy(), h.copy())
+        np.random.seed(9100 + s)
+        import matplotlib.pyplot as _plt
+        _plt.close("all")
+        with quiet() as buf:
+            M, E, mn = obj.run(tolerance=np.finfo(float).eps, use_hash_table=False, **kw)
+        mins[s], lasts[s] = mn, E[-1]
+        sizes += [int(m) for m in re.findall(r"cluster size = (\d+)", buf.getvalue())]
+        print(f"[golden] nmc run {s}: min {mn:.4f}", file=sys.__stdout__, flush=True)
+    nf = np.max(np.abs(J))
+    save("stats_nmc_run_gsparse256", **csr_parts(J), h=np.asarray(h).reshape(-1), norm_factor=nf, min_energy=mins, last_energy=lasts,
+         cluster_sizes=np.array(sizes, dtype=np.int64), **{k: np.float64(v) for k, v in kw.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["mcmc", "large", "nmcsub", "lbp", "npt", "icm", "pre", "known", "stats", "statsmin", "statsmix"]
-    table = dict(statsmix=gen_stats_min_mixed, mcmc=gen_mcmc, large=gen_mcmc_large, statsmin=gen_stats_min, nmcsub=gen_nmc_subroutine, lbp=gen_lbp_and_run, npt=gen_npt, icm=gen_icm,
+    which = sys.argv[1:] or ["mcmc", "large", "nmcsub", "lbp", "npt", "icm", "pre", "known", "stats", "statsmin", "statsmix", "statsnmc"]
+    table = dict(statsmix=gen_stats_min_mixed, statsnmc=gen_stats_nmc, mcmc=gen_mcmc, large=gen_mcmc_large, statsmin=gen_stats_min, nmcsub=gen_nmc_subroutine, lbp=gen_lbp_and_run, npt=gen_npt, icm=gen_icm,
                  pre=gen_preprocessor, known=gen_known_answers, stats=gen_stats)
     for w in which:
         table[w]()
