@@ -7,7 +7,8 @@ With N > 1 and no torch.distributed environment this script starts `python -m to
 bench.py ...` itself as a CHILD process (before anything touches the GPU) and exits with the child's code; launched by
 torch.distributed.run it is one rank per GPU over RCCL.
 
-A "step" is ROUNDS_PER_STEP = 64 replica-exchange rounds of NPT; a round is S_SWAP = 10 heat-bath sweeps of every
+A "step" is ROUNDS_PER_STEP = 512 replica-exchange rounds of NPT (64 ms of GPU time: the default 16 steps and the
+driver's --steps 20 both time more than a second); a round is S_SWAP = 10 heat-bath sweeps of every
 replica at its ladder temperature followed by one swap-attempt round.  Workload (SURVEY.md section 8d, config C4 on
 one GPU): synthetic +-J spin glass, N = 10^4 spins, exactly 3N edges (mean degree 6), h = 0; 256 replicas PER GPU on a
 geometric beta ladder 0.05 -> 4 that spans all GPUs (256*N_gpus slots; --strong: 256 replicas in total, 256/N per
@@ -41,7 +42,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 N_SPINS = 10_000
 REPLICAS_PER_GPU = 256
 S_SWAP = 10
-ROUNDS_PER_STEP = 64
+ROUNDS_PER_STEP = 512        # 512 rounds x 0.12 ms: a step is ~64 ms, so that any sensible --steps times >= 1 s
 EVENT_EVERY = int(os.environ.get("NLMC_BENCH_EVENT_EVERY", "8"))   # HIP events around every 8th sweep-kernel launch of the timed region
 PLAN_CHUNK_ROUNDS = 256      # rounds whose schedules are built together (one workgroup per window: fills the chip)
 BETA_MIN, BETA_MAX = 0.05, 4.0
@@ -161,8 +162,8 @@ def self_launch(a, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32, help="timed steps; one step = %d swap rounds" % ROUNDS_PER_STEP)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=16, help="timed steps; one step = %d swap rounds" % ROUNDS_PER_STEP)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--strong", action="store_true", help="256 replicas in total instead of 256 per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f64-leg", action="store_true")
@@ -304,20 +305,26 @@ def main():
             "ms_per_round": dt / tr * 1e3,
             "value_kernel_loop": (upd_launch / (ms_launch * 1e-3)) * world if ms_launch > 0 else None,
             "ms_levelize": tm["ms_levelize"],
-            "ms_sweep_kernels": ms_launch * tm["launches_sweep"],
+            "ms_sweep_kernels": ms_launch * tm["launches_sweep"],      # extrapolated from the launches that had events
             "sweep_launches": tm["launches_sweep"],
             "sweep_launches_with_events": tm["launches_timed"],
+            # contract line: ALGORITHMIC bytes over the launch time measured live with HIP events; `traffic` and
+            # everything derived from it are STATIC figures of the committed PMC passes (counters cannot be read live)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc.get("hbm_bytes_per_launch"),
-                         "traffic_source": pmc.get("source"),
+                         "hbm_measured_frac": (pmc["hbm_bytes_per_launch"] / sec_launch / 1e9 / HBM_PEAK_GBS)
+                         if (pmc.get("hbm_bytes_per_launch") and ms_launch > 0) else None,
+                         "static_from": pmc.get("source"),
+                         "launches_timed": tm["launches_timed"], "launches_total": tm["launches_sweep"],
                          "algorithmic_bytes_per_launch": upd_launch * BYTES_PER_UPDATE,
                          "kernel": "k_sweep_fused<false,false,false>", "us_per_launch": ms_launch * 1e3,
                          "bytes_per_update": BYTES_PER_UPDATE, "updates_per_launch": upd_launch,
-                         "note": "SURVEY 8d algorithmic bytes (63 B per update, no discount for rows shared by chains). "
-                                 "This design keeps spins in LDS and shares one level schedule between all chains of a "
-                                 "launch, so HBM carries only `traffic`; the bounds that bind are roofline_l2 and "
-                                 "roofline_issue below (DESIGN.md section 5)"},
+                         "note": "frac = SURVEY 8d algorithmic bytes (63 B per update, no discount for rows shared by chains) over "
+                                 "the HBM peak: > 1 because this design does not move those bytes (spins live in LDS, one "
+                                 "level schedule serves all chains of a launch); hbm_measured_frac = PMC traffic over the "
+                                 "same launch time, the physical HBM utilisation; the kernel is bound by the dependent "
+                                 "chain of a level, see roofline_l2 / roofline_issue (DESIGN.md section 5)"},
             # every workgroup (= chain = CU) streams the whole window schedule through its L1 from its XCD's L2
             "roofline_l2": {"bound": "l2", "unit": "GB/s", "peak": L2_PEAK_GBS,
                             "achieved": upd_launch * sched_bytes / sec_launch / 1e9 if ms_launch > 0 else 0.0,
@@ -335,7 +342,7 @@ def main():
                                      "valu_lane_insts_per_update": lane_insts / upd_launch,
                                      "valu_lane_insts_per_schedule_position": lane_insts / upd_launch / positions_per_update,
                                      "lds_bank_conflict_frac": pmc.get("lds_bank_conflict_frac"),
-                                     "wait_any_frac": pmc.get("wait_any_frac"), "source": pmc.get("source")}
+                                     "wait_any_frac": pmc.get("wait_any_frac"), "static_from": pmc.get("source")}
         if world == 1 and not a.no_f64_leg:
             f = run_leg("f64", 1, 0)
             ms64 = f["tm"]["ms_sweep"] / max(1, f["tm"]["launches_timed"])

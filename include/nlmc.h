@@ -139,6 +139,11 @@ int nlmc_plan_philox_fused(nlmc_ctx *ctx, uint32_t sweep0, int n_windows, int wi
  * most that size then allocates nothing).  Drops the current fused plan. */
 int nlmc_plan_reserve_fused(nlmc_ctx *ctx, int n_windows, int window);
 
+/* Diagnostic: the level list of planned window `window` of the selected plan slot, as chunk offsets (a chunk = 64 schedule
+ * positions = one wave's items of one level): level l holds chunks [out[l], out[l+1]); out_n_levels levels (0: the window got
+ * no fused schedule).  capacity = entries of the caller's array (>= levels + 1; 1025 always suffices). */
+int nlmc_plan_get_levels(nlmc_ctx *ctx, int window, int32_t *out_level_chunk_offsets, int32_t capacity, int32_t *out_n_levels);
+
 /* Replica exchange (NPT/npt.py:602-683).  Chains are grouped into ladders of ladder_len consecutive global
  * chain ids; slot r of a ladder runs at beta_list[r].  Accepted swaps exchange the beta slots of two chains
  * (label exchange) -- equivalent to the reference's exchange of the two N-blocks of m_start (NPT/npt.py:677-678). */

@@ -75,7 +75,7 @@ struct nlmc_ctx {
     DevBuf<int32_t> argmin;
     DevBuf<double> energy, tab, ustream, etrace_d;
     DevBuf<uint32_t> keys;
-    DevBuf<int8_t> strace, cfg;
+    DevBuf<int8_t> strace, cfg, snap_g;
     int strace_nrec = 0;          // recorded configurations per chain held in strace by the last sweep call (0: none)
     int strace_rows = 0;          // chains (rows) of that trace: the subset the call ran on
     // chain subsets (nlmc_pt_mark_slots / nlmc_select_chains): sweeps, hand-offs and backbone inference of a call act on
@@ -435,7 +435,10 @@ int run_fused(nlmc_ctx *c, int slot, int w, uint32_t sweep0, uint64_t seed, cons
     const nlmc_ctx::FusedPlan &P = c->fz[slot];
     const int R = c->sub_count(), n = c->n, T = P.T;
     const size_t PS = (size_t)P.pstride;
-    const FusedLds L = fused_lds(c->n, c->n_pad, c->has_flags, outs, P.fmt == NLMC_FMT_ADDR);
+    // per-sweep outputs: three snapshot slots in LDS when they fit beside the threshold tables, in global memory otherwise
+    const bool snap_lds = outs && fused_lds(c->n, c->n_pad, c->has_flags, true, P.fmt == NLMC_FMT_ADDR).total <= (size_t)150 * 1024;
+    const FusedLds L = fused_lds(c->n, c->n_pad, c->has_flags, snap_lds, P.fmt == NLMC_FMT_ADDR);
+    if (outs && !snap_lds) HIP_TRY(c, c->snap_g.reserve((size_t)R * (3 * (size_t)c->n_pad + 16)));
     const int variant = (outs ? 4 : 0) + (c->has_diag ? 2 : 0) + (c->has_flags ? 1 : 0);
     const void *kfun = fused_kernel(c->has_diag, c->has_flags, outs, P.fmt);
     { int rc = ensure_lds(c, 24 + variant * 3 + P.fmt, kfun, L.total); if (rc) return rc; }
@@ -500,6 +503,7 @@ int run_fused(nlmc_ctx *c, int slot, int w, uint32_t sweep0, uint64_t seed, cons
     a.lds_neg_off = L.neg_off;
     a.lds_flags_off = L.flags_off; a.lds_u_off = L.u_off; a.lds_u_stride = L.u_bytes; a.lds_red_off = L.red_off;
     a.lds_snap_off = L.snap_off;
+    a.snap_g = (outs && !snap_lds) ? c->snap_g.p : nullptr;
 #ifdef NLMC_STAMPS
     HIP_TRY(c, c->dbg.reserve((size_t)R * 16 * 8 + 96));
     HIP_TRY(c, hipMemsetAsync(c->dbg.p, 0, ((size_t)R * 16 * 8 + 96) * sizeof(long long), c->cur));
@@ -637,9 +641,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
             }
             return NLMC_OK;
         }
-        if (!getenv("NLMC_NO_FUSED_OUT") &&
-            fused_lds(c->n, c->n_pad, c->has_flags, true, P.fmt == NLMC_FMT_ADDR).total <= (size_t)150 * 1024)
-            fused_out = true;
+        if (!getenv("NLMC_NO_FUSED_OUT")) fused_out = true;     // (snapshots in LDS or, for large n, in a global ring: run_fused)
     }
     if (o.out_energy) HIP_TRY(c, c->etrace.reserve((size_t)R * n_sweeps));
     if (rec) HIP_TRY(c, c->strace.reserve((size_t)R * n_rec * n));
@@ -1013,7 +1015,7 @@ void nlmc_destroy(nlmc_ctx *c)
     c->rowptr.release(); c->col.release(); c->val64.release(); c->h64.release(); c->edge32.release(); c->hq.release();
     c->spins.release(); c->best.release(); c->flags.release(); c->efix.release(); c->emin.release(); c->etrace.release();
     c->argmin.release(); c->energy.release(); c->tab.release(); c->ustream.release(); c->etrace_d.release();
-    c->keys.release(); c->strace.release(); c->cfg.release(); c->scratch.release(); c->plan.release();
+    c->keys.release(); c->strace.release(); c->cfg.release(); c->snap_g.release(); c->scratch.release(); c->plan.release();
     c->slot_mark.release(); c->sub_list_buf.release(); c->cmask.release(); c->nmc_status.release(); c->nmc_thr.release();
     c->fz_glv.release(); c->fz_perm.release(); c->fz_adj.release(); c->fz_stats.release(); c->fz[0].release(); c->fz[1].release();
     c->lbp_src.release(); c->lbp_rev.release(); c->lbp_flag.release(); c->lbp_out_i.release(); c->lbp_tJ.release();
@@ -1384,6 +1386,21 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     P.valid = true;
     P.sweep0 = sweep0; P.windows = n_windows; P.T = T; P.seed = seed;
     if (out_planned) *out_planned = ok;
+    return NLMC_OK;
+}
+
+int nlmc_plan_get_levels(nlmc_ctx *c, int window, int32_t *out_level_chunk_offsets, int32_t capacity, int32_t *out_n_levels)
+{
+    if (!c || !out_level_chunk_offsets || !out_n_levels) return fail(c, NLMC_ERR_ARG, "nlmc_plan_get_levels: NULL argument");
+    const nlmc_ctx::FusedPlan &P = c->fz[c->fz_slot];
+    if (!P.valid || window < 0 || window >= P.windows) return fail(c, NLMC_ERR_STATE, "nlmc_plan_get_levels: no such planned window in the selected slot");
+    const int nl = P.nlev_host[(size_t)window];
+    *out_n_levels = nl;
+    if (capacity < nl + 1) return fail(c, NLMC_ERR_ARG, "nlmc_plan_get_levels: capacity < levels + 1");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(out_level_chunk_offsets, P.loff.p + (size_t)window * (NLMC_LCAP + 1), sizeof(int32_t) * (size_t)(nl + 1),
+                              hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return NLMC_OK;
 }
 

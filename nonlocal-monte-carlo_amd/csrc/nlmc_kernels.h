@@ -591,6 +591,8 @@ struct SweepArgs {
     int lds_neg_off;          // NLMC_FMT_ADDR: LDS offset of the negated copy of the spins (n_pad + 16); 0: none
     int lds_send_off;
     int lds_snap_off;         // k_sweep_fused<.., OUT>: three snapshot slots of n_pad bytes
+    int8_t *snap_g;           // ... or, when they do not fit in LDS beside the threshold tables (n > ~9000): the same three slots
+                              // per block in global memory, [blocks][3 n_pad + 16]; nullptr: LDS
     int dbg_flags;            // -DNLMC_DEBUG_KNOBS builds only (NLMC_DBG_FLAGS): 1 = no threshold production, 2 = no updates, 4 = no item loads,
                               // 512 / 1024 = bank-conflict-free addresses for the neighbour gather / the spin's own accesses (wrong results)
 };
@@ -1402,6 +1404,10 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
     int a_min = 0;
     float cqo0 = cq0, cqo1 = cq1, cqn0 = cq0, cqn1 = cq1;  // coefficients of the older / the newer live sweep
     const int o_row = a.slot_of_chain ? a.slot_of_chain[a.chain_base + o_c] : o_c;
+    // Snapshot ring in global memory (wave-uniform pointer): every update stores its new spin there (a scattered byte store,
+    // fire and forget); at the end of a sweep every storing wave drains its stores before the level's barrier, and the copy
+    // to `best` / the recorded trace reads the ring past the CU's vector L1 (lines of the slot's previous use may linger there).
+    int8_t *const snapg = (OUT && a.snap_g) ? a.snap_g + (size_t)o_b * (3 * (size_t)o_npad + 16) : nullptr;
 #define NLMC_OCQ(t, j) ((float)((const_f64o)(uintptr_t)a.tab)[(size_t)o_row * a.tab_cs + (size_t)min((t), a.n_sweeps - 1) * a.tab_ss + (j)] * a.qinv)
     // (wave-uniform 64-bit values are pinned into scalar registers: a uniform value in a vector register costs 64 lanes, a
     // spilled scalar one lane)
@@ -1536,7 +1542,8 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             e_new += Xt * (long long)(cv - cvo);
             *(lds_i8w)(uintptr_t)ka = (int8_t)sn;
             if (FMT == NLMC_FMT_ADDR) *(lds_i8w)(uintptr_t)(ka + v_neg_off) = (int8_t)-sn;
-            *(lds_i8w)(uintptr_t)(tw + (unsigned)a.lds_snap_off) = (int8_t)sn;      // snapshot slot of the update's sweep
+            if (snapg) snapg[tw] = (int8_t)sn;                                      // snapshot slot of the update's sweep:
+            else *(lds_i8w)(uintptr_t)(tw + (unsigned)a.lds_snap_off) = (int8_t)sn; // global ring (large n) or LDS
         }
     };
     // End of the older live sweep: before the level's barrier every wave adds its share to the sweep's LDS accumulator
@@ -1544,6 +1551,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
     // local variables: lambdas that capture this much state end up in scratch memory.
 #define NLMC_OUT_PRE                                                                                                    \
     {                                                                                                                   \
+        if (snapg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       /* this wave's snapshot stores have landed */     \
         const long long w_ = wave_sum_i64(e_loc);                                                                       \
         long long *red_ = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);                                       \
         if (lane == 0 && w_ != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&red_[o_t % 3]), (unsigned long long)w_); \
@@ -1559,16 +1567,20 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             red_[(o_t + 2) % 3] = 0;                          /* read a sweep ago, next used two sweeps from now */      \
             if (a.etrace) a.etrace[(size_t)o_b * a.trace_sweeps + tg_] = E_run;                                         \
         }                                                                                                               \
-        const unsigned char *snap_ = lds_raw + a.lds_snap_off + (size_t)slot_ * o_npad;                                 \
+        const unsigned char *snap_ = snapg ? reinterpret_cast<const unsigned char *>(snapg) + (size_t)slot_ * o_npad              \
+                                           : lds_raw + a.lds_snap_off + (size_t)slot_ * o_npad;                         \
         if (better_ && a.best) {                                                                                        \
             int4 *dst_ = reinterpret_cast<int4 *>(a.best + (size_t)o_c * o_npad);                                       \
             const int4 *src_ = reinterpret_cast<const int4 *>(snap_);                                                   \
-            for (int i_ = o_tid; i_ < o_npad / 16; i_ += a.f_workers * 64) dst_[i_] = src_[i_];                         \
+            if (snapg) for (int i_ = o_tid; i_ < o_npad / 16; i_ += a.f_workers * 64)                                  \
+                reinterpret_cast<nlmc_i4 *>(dst_)[i_] = __builtin_nontemporal_load(&reinterpret_cast<const nlmc_i4 *>(src_)[i_]);   \
+            else for (int i_ = o_tid; i_ < o_npad / 16; i_ += a.f_workers * 64) dst_[i_] = src_[i_];                    \
         }                                                                                                               \
         if (a.strace && tg_ % a.rec_stride == 0) {            /* M[:, ::M_skip]  (NMC/nmc.py:390) */                     \
             const int n_rec_ = (a.trace_sweeps + a.rec_stride - 1) / a.rec_stride;                                      \
             int8_t *dst_ = a.strace + ((size_t)o_b * n_rec_ + (size_t)(tg_ / a.rec_stride)) * a.g.n;                   \
-            for (int i_ = o_tid; i_ < a.g.n; i_ += a.f_workers * 64) dst_[i_] = (int8_t)snap_[i_];                      \
+            if (snapg) for (int i_ = o_tid; i_ < a.g.n; i_ += a.f_workers * 64) dst_[i_] = (int8_t)__builtin_nontemporal_load(&snap_[i_]); \
+            else for (int i_ = o_tid; i_ < a.g.n; i_ += a.f_workers * 64) dst_[i_] = (int8_t)snap_[i_];                 \
         }                                                                                                               \
         e_loc = e_new; e_new = 0;                                                                                       \
         ++o_t;                                                                                                          \

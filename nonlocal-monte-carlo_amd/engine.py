@@ -266,6 +266,13 @@ class Engine:
         """Fused-window plans live in two slots (include/nlmc.h: nlmc_plan_slot); planning calls write to the selected one."""
         self._ck(self._L.nlmc_plan_slot(self._ctx, int(slot)))
 
+    def plan_levels(self, window):
+        """Chunks (64 schedule positions) per level of a planned fused window of the selected plan slot (diagnostic)."""
+        off = np.zeros(1025, dtype=np.int32)
+        nl = ctypes.c_int32(0)
+        self._ck(self._L.nlmc_plan_get_levels(self._ctx, int(window), _abi.ptr(off), 1025, ctypes.byref(nl)))
+        return np.diff(off[:nl.value + 1])
+
     def plan_reserve_fused(self, n_windows, window):
         """Allocate the fused-window plan buffers for up to n_windows windows (no schedule is built)."""
         self._ck(self._L.nlmc_plan_reserve_fused(self._ctx, int(n_windows), int(window)))

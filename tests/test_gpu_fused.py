@@ -102,7 +102,7 @@ def test_fused_with_swaps_and_sharded_contexts(product):
 
 def test_fused_plan_declines_what_it_cannot_run(product, monkeypatch):
     """Tiny instance (n < 256), window of 2: nothing planned, calls take the plain path; per-chain orders and f64
-    ignore a fused plan; calls with per-sweep outputs run on it unless the three snapshot slots do not fit in LDS."""
+    ignore a fused plan; calls with per-sweep outputs run on it (snapshot slots in LDS, or in a global ring for large n)."""
     J, h = make_instance(200, seed=3)
     with product.Engine(J, h, 2) as eng:
         assert eng.plan_philox_fused(0, 4, 10, SEED) == 0
@@ -129,15 +129,15 @@ def test_fused_plan_declines_what_it_cannot_run(product, monkeypatch):
         eng.set_spins(init_spins(2, N))
         eng.sweep_philox(T, SEED, sweep0=0, beta=1.0, order="per_chain")                        # not what was planned
         assert eng.last_schedule_stats()["orders"] == 2 * T
-    N = 10000                                                                                   # snapshots do not fit
+    N = 10000                      # the snapshot slots do not fit in LDS: they live in a global ring, the call stays fused
     J, h = make_instance(N, seed=32)
     with product.Engine(J, h, 2) as eng:
         assert eng.plan_philox_fused(0, 1, T, SEED) == 1
         eng.set_spins(init_spins(2, N))
         eng.sweep_philox(T, SEED, sweep0=0, beta=1.0, want_min=True)
-        lv_out = eng.last_schedule_stats()["levels"]
+        lv_out = eng.last_schedule_stats()
         eng.sweep_philox(T, SEED, sweep0=0, beta=1.0)
-        assert eng.last_schedule_stats()["levels"] < lv_out
+        assert eng.last_schedule_stats() == lv_out and lv_out["orders"] == T
 
 
 @pytest.mark.parametrize("N", [300, 1000, 1600, 3000, 5000])
@@ -162,7 +162,7 @@ def test_fused_small_workgroups(product, N):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["pmj", "gauss_flags", "anneal"])
+@pytest.mark.parametrize("case", ["pmj", "gauss_flags", "anneal", "pmj_10000_flags", "gauss_10000"])
 def test_fused_windows_with_per_sweep_outputs_equal_the_sweep_by_sweep_kernel(product, case, monkeypatch):
     """Calls that want the energy trace, the running minimum + argmin state (NMC/nmc.py:386-395) or recorded
     configurations, or that anneal (one temperature per sweep, NMC/nmc.py:56-69), run on the fused windows too
@@ -170,7 +170,10 @@ def test_fused_windows_with_per_sweep_outputs_equal_the_sweep_by_sweep_kernel(pr
     call, with phase flags, and the tracked state must carry on correctly into the next call."""
     from helpers import make_instance, init_spins
     N, R, T, W = 700, 5, 6, 4
-    gauss = case == "gauss_flags"
+    big = "10000" in case                 # n = 10^4: the snapshot slots do not fit in LDS beside the threshold tables and live in
+    if big:                               # a global ring (VERDICT r2 #6: argmin hand-off at C4 / C5 size on fused windows)
+        N, R, T, W = 10000, 3, 5, 2
+    gauss = case.startswith("gauss")
     J, h = make_instance(N, seed=41, with_h=gauss, gaussian=gauss)
     m0 = init_spins(R, N)
     S = T * W
@@ -179,7 +182,7 @@ def test_fused_windows_with_per_sweep_outputs_equal_the_sweep_by_sweep_kernel(pr
     else:
         beta = np.repeat(np.geomspace(0.3, 2.5, R)[:, None], S, axis=1)
     flags = None
-    if gauss:
+    if case in ("gauss_flags", "pmj_10000_flags"):
         rng = np.random.default_rng(3)
         flags = rng.choice([0, 0, 0, 1, 2, 3], size=(R, N)).astype(np.uint8)
 
