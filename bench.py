@@ -267,9 +267,11 @@ def main():
         e_end = st.eng.energy()
         sched = st.eng.last_schedule_stats()
         chunks = st._planner.chunks_planned if getattr(st, "_planner", None) is not None else 0
+        coll = ("rccl ncclAllGather issued by libnlmc_hip.so on the kernels' stream" if st.lib_collective else
+                "torch.distributed all_gather_into_tensor" if st.collective else None)
         st.close()
         return {"dt": dt, "tm": tm, "rounds": tr, "count": count, "e_start": e_start, "e_end": e_end, "sched": sched,
-                "chunks": chunks}
+                "chunks": chunks, "collective": coll}
 
     r = run_leg("f32", a.steps, a.warmup)
 
@@ -299,6 +301,8 @@ def main():
                        "replicas_total": G, "sweeps_per_round": S_SWAP, "rounds_per_step": ROUNDS_PER_STEP,
                        "swap_pairs_per_round": n_pairs, "beta_ladder": [BETA_MIN, BETA_MAX], "rng": "philox4x32-10",
                        "order": "one permutation per sweep", "plan_chunk_rounds": PLAN_CHUNK_ROUNDS},
+            "collective": r["collective"],         # the one collective of a round (None: a single process, nothing to gather)
+            "ranks_seen": world,
             "plan_in_timed_region": True,
             "plan_chunks_in_timed_region": r["chunks"],
             "rounds_timed": tr,

@@ -163,6 +163,20 @@ int nlmc_pt_swap_philox(nlmc_ctx *ctx, uint32_t round, uint64_t seed, int n_pair
  * NPT.run(device_ids=...): no device-to-device path is assumed between them). */
 int nlmc_pt_swap_philox_host(nlmc_ctx *ctx, uint32_t round, uint64_t seed, int n_pairs, const double *energies_all_host,
                              int32_t *out_pairs, uint8_t *out_accepted);
+/* Replica-sharded ladders, one process per GPU (NPT/npt.py:616-640 hands one task per replica to a process pool): the ONE
+ * collective of a round -- an all-gather of every rank's chain energies -- issued BY THE LIBRARY with RCCL on the stream its
+ * kernels run on (librccl is bound at run time; the copy the process already holds is reused).  With a communicator in place
+ * the sweep kernels write their chains' energies straight into this rank's block of the gathered vector.
+ *   nlmc_comm_unique_id   rank 0 creates the id (128 bytes) and hands it to the others over whatever channel the launcher
+ *                         has (torch.distributed broadcast in distributed.ShardedTempering)
+ *   nlmc_comm_init        every rank; the context must own block `rank` of `world` equal blocks of chains
+ *   nlmc_pt_swap_philox_collective   all-gather + the device-decided swap round of nlmc_pt_swap_philox on the gathered
+ *                         energies (identical decision on every rank).  refresh_energies != 0: publish the tracked energies
+ *                         first (needed when the states changed other than through a sweep call since the last round). */
+int nlmc_comm_unique_id(uint8_t *out_id /*[128]*/);
+int nlmc_comm_init(nlmc_ctx *ctx, const uint8_t *id /*[128]*/, int world, int rank);
+int nlmc_pt_swap_philox_collective(nlmc_ctx *ctx, uint32_t round, uint64_t seed, int n_pairs, int refresh_energies,
+                                   int32_t *out_pairs, uint8_t *out_accepted);
 /* Optional: the pair selection depends on the RNG only, so the selections of rounds [round0, round0+n_rounds) can be
  * computed ahead of time (one wave per round and ladder).  Later nlmc_pt_swap_philox calls in that range with the same
  * seed and n_pairs are left with the parallel acceptance test.  Results are identical with or without a plan. */

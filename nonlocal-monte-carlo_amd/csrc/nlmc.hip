@@ -6,6 +6,8 @@
 #include "nlmc_nmc.h"
 #include "nlmc_host.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -190,6 +192,9 @@ struct nlmc_ctx {
     bool stats_pending = false;
     const int32_t *stats_nlev_ptr = nullptr;
     int64_t stats_nlev_count = 0;
+
+    void *comm = nullptr;              // RCCL communicator of the sharded tempering (nlmc_comm_init): the per-round all-gather of
+    int comm_world = 0, comm_rank = 0; // the energies is issued by the library on the kernels' own stream
 
     std::string err;
     CsrDev g{};
@@ -800,6 +805,41 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
 
 namespace {
 
+// ---- RCCL, bound at run time (dlopen): a process that never shards a ladder over GPUs needs no librccl -----------------
+// The library the process already holds (PyTorch ships one under the same soname) is reused.
+struct Rccl {
+    typedef struct { char internal[128]; } UniqueId;                      // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
+    int (*GetUniqueId)(UniqueId *) = nullptr;
+    int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool tried = false, ok = false;
+    std::string why;
+};
+Rccl g_rccl;
+
+bool rccl_load()
+{
+    Rccl &r = g_rccl;
+    if (r.tried) return r.ok;
+    r.tried = true;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { r.why = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?"); return false; }
+    r.GetUniqueId = reinterpret_cast<int (*)(Rccl::UniqueId *)>(dlsym(h, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<int (*)(void **, int, Rccl::UniqueId, int)>(dlsym(h, "ncclCommInitRank"));
+    r.AllGather = reinterpret_cast<int (*)(const void *, void *, size_t, int, void *, hipStream_t)>(dlsym(h, "ncclAllGather"));
+    r.CommDestroy = reinterpret_cast<int (*)(void *)>(dlsym(h, "ncclCommDestroy"));
+    r.GetErrorString = reinterpret_cast<const char *(*)(int)>(dlsym(h, "ncclGetErrorString"));
+    r.ok = r.GetUniqueId && r.CommInitRank && r.AllGather && r.CommDestroy;
+    if (!r.ok) r.why = "librccl.so.1 lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy";
+    return r.ok;
+}
+
+std::string rccl_err(int rc) { return g_rccl.GetErrorString ? std::string(g_rccl.GetErrorString(rc)) : ("ncclResult " + std::to_string(rc)); }
+
 int rows_to_device(nlmc_ctx *c, void *dst_dev, const void *src_host, int rows)
 {
     const size_t n = (size_t)c->n, np = (size_t)c->n_pad;
@@ -1008,6 +1048,7 @@ void nlmc_destroy(nlmc_ctx *c)
     }
     c->dbg.release();
 #endif
+    if (c->comm && g_rccl.ok) (void)g_rccl.CommDestroy(c->comm);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1638,6 +1679,56 @@ int nlmc_pt_swap_philox_host(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_p
     HIP_TRY(c, hipMemcpyAsync(c->pt_energies_all.p, energies_all_host, sizeof(double) * (size_t)c->n_chains_global,
                               hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));      // the caller's buffer may go away after the call
+    return nlmc_pt_swap_philox(c, round, seed, n_pairs, c->pt_energies_all.p, out_pairs, out_accepted);
+}
+
+// ---- replica-sharded ladders: the ONE collective of a round, issued by the library on the kernels' stream -----------------
+int nlmc_comm_unique_id(uint8_t *out_id)
+{
+    if (!out_id) return fail(nullptr, NLMC_ERR_ARG, "nlmc_comm_unique_id: NULL argument");
+    if (!rccl_load()) return fail(nullptr, NLMC_ERR_UNSUPPORTED, g_rccl.why);
+    Rccl::UniqueId id;
+    const int rc = g_rccl.GetUniqueId(&id);
+    if (rc != 0) return fail(nullptr, NLMC_ERR_HIP, "ncclGetUniqueId: " + rccl_err(rc));
+    std::memcpy(out_id, id.internal, sizeof(id.internal));
+    return NLMC_OK;
+}
+
+int nlmc_comm_init(nlmc_ctx *c, const uint8_t *id, int world, int rank)
+{
+    if (!c || !id || world < 1 || rank < 0 || rank >= world) return fail(c, NLMC_ERR_ARG, "nlmc_comm_init: bad argument");
+    if (c->n_chains * world != c->n_chains_global || c->chain_base != rank * c->n_chains)
+        return fail(c, NLMC_ERR_ARG, "nlmc_comm_init: the context must own block `rank` of `world` equal blocks of chains");
+    if (!rccl_load()) return fail(c, NLMC_ERR_UNSUPPORTED, g_rccl.why);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->comm) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    Rccl::UniqueId uid;
+    std::memcpy(uid.internal, id, sizeof(uid.internal));
+    const int rc = g_rccl.CommInitRank(&c->comm, world, uid, rank);
+    if (rc != 0) { c->comm = nullptr; return fail(c, NLMC_ERR_HIP, "ncclCommInitRank: " + rccl_err(rc)); }
+    c->comm_world = world; c->comm_rank = rank;
+    HIP_TRY(c, c->pt_energies_all.reserve((size_t)c->n_chains_global));
+    HIP_TRY(c, hipMemsetAsync(c->pt_energies_all.p, 0, sizeof(double) * (size_t)c->n_chains_global, c->stream));
+    // the sweep kernels store their chains' tracked energies straight into this rank's block of the gathered vector
+    c->energy_sink = c->pt_energies_all.p + c->chain_base;
+    return NLMC_OK;
+}
+
+int nlmc_pt_swap_philox_collective(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs, int refresh_energies,
+                                   int32_t *out_pairs, uint8_t *out_accepted)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (!c->comm) return fail(c, NLMC_ERR_STATE, "nlmc_pt_swap_philox_collective: call nlmc_comm_init first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    double *block = c->pt_energies_all.p + c->chain_base;
+    if (refresh_energies || c->energy_sink != block) {        // (no sweep since the last state change wrote the block)
+        hipLaunchKernelGGL(k_efix_to_double, dim3((c->n_chains + 255) / 256), dim3(256), 0, c->stream, c->efix.p, block, c->n_chains, c->escale);
+        HIP_TRY(c, hipGetLastError());
+    }
+    // in-place all-gather (send = this rank's block of the receive buffer), on the stream the sweep and swap kernels use:
+    // stream order is the only synchronisation a round needs
+    const int rc = g_rccl.AllGather(block, c->pt_energies_all.p, (size_t)c->n_chains, /*ncclDouble*/ 8, c->comm, c->stream);
+    if (rc != 0) return fail(c, NLMC_ERR_HIP, "ncclAllGather: " + rccl_err(rc));
     return nlmc_pt_swap_philox(c, round, seed, n_pairs, c->pt_energies_all.p, out_pairs, out_accepted);
 }
 

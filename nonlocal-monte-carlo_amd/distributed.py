@@ -8,6 +8,8 @@ the (tiny) slot table -- swaps are label exchanges, no configuration ever crosse
 number is a pure function of (seed, global chain id, sweep, spin), the trajectory is bit-identical for any number
 of ranks.
 """
+import os
+
 import numpy as np
 
 from .engine import Engine, RoundPlanner
@@ -42,7 +44,19 @@ class ShardedTempering:
         self.sweeps_done = 0
         self.rounds_done = 0
         self.collective = dist is not None          # also with a single rank: the launcher path stays exercised
-        if self.collective:
+        self.lib_collective = False
+        if self.collective and hasattr(self.eng, "comm_init") and dist.get_backend() == "nccl" and self.n_pairs > 0 \
+                and not os.environ.get("NLMC_TORCH_COLLECTIVE"):
+            # The all-gather of a round is issued by the LIBRARY (ncclAllGather from libnlmc_hip.so on the stream its kernels
+            # run on: no hand-over between c10d's collective stream and the kernels' stream, ~10 us per round); its
+            # communicator's unique id travels through the process group that is already up.
+            uid = torch.zeros(128, dtype=torch.uint8, device=device)
+            if self.rank == 0:
+                uid.copy_(torch.from_numpy(self.eng.comm_unique_id()))
+            dist.broadcast(uid, 0)
+            self.eng.comm_init(uid.cpu().numpy(), self.world, self.rank)
+            self.lib_collective = True
+        elif self.collective:
             self.e_local = torch.empty(self.count, dtype=torch.float64, device=device)
             self.e_all = torch.empty(self.G, dtype=torch.float64, device=device)
             # the sweep kernels write their chains' energies straight into the all-gather's send buffer
@@ -86,7 +100,10 @@ class ShardedTempering:
         self.sweeps_done += n_sweeps
         log = None
         if self.n_pairs > 0:
-            if self.collective:
+            if self.lib_collective:
+                log = self.eng.pt_swap_philox_collective(self.rounds_done, self.seed, self.n_pairs, refresh_energies=n_sweeps == 0,
+                                                         want_log=want_log)
+            elif self.collective:
                 if not self._sink or n_sweeps == 0:
                     self.eng.energy_dev(self.e_local.data_ptr())       # tracked energies -> device/host buffer
                 self.dist.all_gather_into_tensor(self.e_all, self.e_local)   # the ONE collective of the round
@@ -102,8 +119,9 @@ class ShardedTempering:
         loc = self.eng.get_spins()
         if not self.collective:
             return loc
-        t = self.torch.from_numpy(loc.astype(np.int8)).to(self.e_all.device)
-        out = self.torch.empty((self.G, loc.shape[1]), dtype=self.torch.int8, device=self.e_all.device)
+        dev = self.torch.device("cuda", self.torch.cuda.current_device()) if self.lib_collective else self.e_all.device
+        t = self.torch.from_numpy(loc.astype(np.int8)).to(dev)
+        out = self.torch.empty((self.G, loc.shape[1]), dtype=self.torch.int8, device=dev)
         self.dist.all_gather_into_tensor(out, t)
         return out.cpu().numpy()
 
@@ -154,7 +172,6 @@ class LocalTempering:
         if not marks.any():
             self.nmc = None
             return
-        import os
         for e in self.engs:
             e.mark_slots(marks)
             e.overlap_subsets(not os.environ.get("NLMC_NO_OVERLAP"))      # plain chains' sweeps beside the NMC chains' work

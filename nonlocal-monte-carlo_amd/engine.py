@@ -314,6 +314,25 @@ class Engine:
                                                   _abi.ptr(pairs), _abi.ptr(acc)))
         return pairs, acc
 
+    # -- sharded ladders: the per-round all-gather issued by the library (include/nlmc.h: nlmc_comm_init) -------------
+    @staticmethod
+    def comm_unique_id():
+        out = np.zeros(128, dtype=np.uint8)
+        _abi.check(_abi.lib().nlmc_comm_unique_id(_abi.ptr(out)), None)
+        return out
+
+    def comm_init(self, unique_id, world, rank):
+        uid = _abi.as_c(unique_id, np.uint8).reshape(128)
+        self._ck(self._L.nlmc_comm_init(self._ctx, _abi.ptr(uid), int(world), int(rank)))
+
+    def pt_swap_philox_collective(self, round_idx, seed, n_pairs, refresh_energies=False, want_log=False):
+        nl = self.n_chains_global // self.ladder_len
+        pairs = np.empty((nl, n_pairs, 2), np.int32) if want_log else None
+        acc = np.empty((nl, n_pairs), np.uint8) if want_log else None
+        self._ck(self._L.nlmc_pt_swap_philox_collective(self._ctx, int(round_idx), int(seed), int(n_pairs), int(bool(refresh_energies)),
+                                                        _abi.ptr(pairs), _abi.ptr(acc)))
+        return pairs, acc
+
     def pt_plan(self, round0, n_rounds, seed, n_pairs):
         self._ck(self._L.nlmc_pt_plan(self._ctx, int(round0), int(n_rounds), int(seed), int(n_pairs)))
 

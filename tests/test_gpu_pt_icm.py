@@ -199,3 +199,39 @@ def test_energy_sink_is_written_by_the_sweep_kernels(product):
         eng.sweep_philox(T, 9, sweep0=2 * T, beta=None)
         assert np.array_equal(buf.read(R), before)                        # switched off
         buf.free()
+
+
+def test_library_issued_all_gather_one_rank_communicator(product):
+    """The per-round all-gather of a sharded ladder is issued by the library itself (RCCL bound at run time, communicator from
+    nlmc_comm_init) on the kernels' stream.  A one-rank communicator rehearses the whole path on one GPU: sweeps write their
+    energies into the gathered vector, ncclAllGather in place, the swap kernel reads it -- same decisions as the
+    single-context round, also when the states changed outside a sweep call (refresh_energies)."""
+    J, h = make_instance(200, seed=12, with_h=True)
+    L, nl, n_pairs = 8, 2, 3
+    G = L * nl
+    betas = np.geomspace(0.2, 3.0, L)
+    with product.Engine(J, h, G) as a, product.Engine(J, h, G) as b:
+        for e in (a, b):
+            e.set_spins(init_spins(G, 200))
+            e.pt_init(betas)
+        try:
+            a.comm_init(product.Engine.comm_unique_id(), 1, 0)
+        except NotImplementedError as ex:                      # no librccl on this box
+            pytest.skip(str(ex))
+        for rnd in range(5):
+            for e in (a, b):
+                e.sweep_philox(4, 91, sweep0=4 * rnd, beta=None)
+            pa, aa = a.pt_swap_philox_collective(rnd, 91, n_pairs, want_log=True)
+            pb, ab = b.pt_swap_philox(rnd, 91, n_pairs)
+            assert np.array_equal(pa, pb) and np.array_equal(aa, ab) and np.array_equal(a.pt_slots(), b.pt_slots())
+        s = init_spins(G, 200, base=77)
+        for e in (a, b):
+            e.set_spins(s)                                     # states replaced behind the sweep kernels' back
+        pa, aa = a.pt_swap_philox_collective(9, 91, n_pairs, refresh_energies=True, want_log=True)
+        pb, ab = b.pt_swap_philox(9, 91, n_pairs)
+        assert np.array_equal(pa, pb) and np.array_equal(aa, ab) and np.array_equal(a.pt_slots(), b.pt_slots())
+    # a context that does not own an equal block of the chains is refused
+    with product.Engine(J, h, 4, chain_base=0, n_chains_global=16) as c:
+        c.pt_init(betas)
+        with pytest.raises(ValueError):
+            c.comm_init(product.Engine.comm_unique_id(), 2, 1)
