@@ -65,7 +65,7 @@ struct nlmc_ctx {
     bool has_diag = false;
     bool has_zero_vals = false;   // a stored entry is 0.0 (or underflows to 0 in fp32)
     size_t lds_opt[48] = {};      // dynamic-LDS opt-in already granted, one slot per kernel: 0 k_levelize, 1 k_icm_components,
-                                  // 2..7 sweep-by-sweep kernels, 8..15 k_sweep_fused variants, 16 k_levelize_fused, 17..20 k_lbp_lds, 24..47 k_sweep_fused variants
+                                  // 2..7 sweep-by-sweep kernels, 8..15 k_sweep_fused variants, 16 k_levelize_fused, 17..20 k_lbp_lds, 21 k_icm_round, 24..47 k_sweep_fused variants
 
     DevBuf<int32_t> rowptr, col;
     DevBuf<double> val64, h64;
@@ -1809,6 +1809,33 @@ static int icm_launch_components(nlmc_ctx *c, const int32_t *pairs_dev, int n_pa
     return NLMC_OK;
 }
 
+// components + pick + move + incremental energies of a batch of pairs in one launch (k_icm_round)
+static int icm_launch_round(nlmc_ctx *c, const int32_t *pairs_dev, int n_pairs, uint32_t round, uint64_t seed, int katz,
+                            int pair_R = 0, int pair_K = 0)
+{
+    HIP_TRY(c, c->icm_info.reserve((size_t)n_pairs * 2));
+    IcmRoundArgs a{};
+    a.g = c->g; a.spins = c->spins.p; a.pairs = pairs_dev; a.info = c->icm_info.p;
+    a.pair_R = pair_R; a.pair_K = pair_K; a.chain_of_slot = c->chain_of_slot.p;
+    if (!c->has_zero_vals && c->n <= 65535) {
+        int rc = ensure_adjacency(c);
+        if (rc) return rc;
+        a.adj = reinterpret_cast<const uint4 *>(c->fz_adj.p);
+    }
+    a.round = round; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.katz = katz; a.chain_base = c->chain_base;
+    a.efix = c->efix.p; a.energy_sink = c->energy_sink; a.eshift = c->escale - c->qs; a.escale = c->escale;
+    size_t cur = (size_t)c->n * 4;
+    a.lds_cand_off = (int)cur; cur += (((size_t)c->n + 7) & ~(size_t)7) * 2;
+    cur = (cur + 15) & ~(size_t)15;
+    a.lds_sa_off = (int)cur; cur += (size_t)c->n_pad;
+    a.lds_sb_off = (int)cur; cur += (size_t)c->n_pad;
+    const size_t lds = cur + 16;
+    { int rc = ensure_lds(c, 21, reinterpret_cast<const void *>(k_icm_round), lds); if (rc) return rc; }
+    hipLaunchKernelGGL(k_icm_round, dim3(n_pairs), dim3(c->n >= 4096 ? 1024 : 256), lds, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    return NLMC_OK;
+}
+
 static int icm_check_pair(nlmc_ctx *c, int a, int b)
 {
     if (a < 0 || b < 0 || a >= c->n_chains || b >= c->n_chains || a == b) return fail(c, NLMC_ERR_ARG, "icm: bad chain pair");
@@ -1900,11 +1927,9 @@ int nlmc_icm_round_philox(nlmc_ctx *c, const int32_t *pairs, int n_pairs, uint32
     HIP_TRY(c, c->icm_pairs.reserve((size_t)n_pairs * 2));
     HIP_TRY(c, hipMemcpyAsync(c->icm_pairs.p, pairs, sizeof(int32_t) * 2 * n_pairs, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    int rc = icm_launch_components(c, c->icm_pairs.p, n_pairs);
-    if (rc) return rc;
-    rc = icm_apply(c, n_pairs, nullptr, 0, round, seed, katzgraber, 1);
-    if (rc) return rc;
-    rc = launch_energy_self(c, nullptr);
+    // the tracked energies must be the energies of the current states in the fixed-point model: true after sweeps and
+    // moves of this kind; a caller that overwrote the states gets them re-synchronised by nlmc_set_spins / nlmc_energy
+    int rc = icm_launch_round(c, c->icm_pairs.p, n_pairs, round, seed, katzgraber);
     if (rc) return rc;
     if (out_info) {
         HIP_TRY(c, hipMemcpyAsync(out_info, c->icm_info.p, sizeof(int32_t) * 2 * n_pairs, hipMemcpyDeviceToHost, c->stream));
@@ -1926,17 +1951,18 @@ int nlmc_icm_round_ladders(nlmc_ctx *c, uint32_t round, uint64_t seed, int katzg
     if (out_n_pairs) *out_n_pairs = n_pairs;
     if (n_pairs == 0) return NLMC_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, c->icm_pairs.reserve((size_t)n_pairs * 2));
-    hipLaunchKernelGGL(k_icm_pair_ladders, dim3((R * K + 63) / 64), dim3(64), 0, c->stream, R, K, round, (uint32_t)seed,
-                       (uint32_t)(seed >> 32), c->chain_of_slot.p, c->icm_pairs.p);
-    HIP_TRY(c, hipGetLastError());
-    int rc = icm_launch_components(c, c->icm_pairs.p, n_pairs);
-    if (rc) return rc;
-    rc = icm_apply(c, n_pairs, nullptr, 0, round, seed, katzgraber, 1);
-    if (rc) return rc;
-    // (an incremental update of the tracked energies inside the move -- only the bonds that leave the cluster -- was
-    // measured: the row walk of one giant cluster, 41 us, costs more than recomputing all energies, 30 us)
-    rc = launch_energy_self(c, nullptr);
+    const int nt_round = c->n >= 4096 ? 1024 : 256;
+    const bool pair_in_kernel = K <= nt_round;          // the pairing (a sort of K Philox keys per slot) is made by the move kernel itself
+    if (!pair_in_kernel) {
+        HIP_TRY(c, c->icm_pairs.reserve((size_t)n_pairs * 2));
+        hipLaunchKernelGGL(k_icm_pair_ladders, dim3((R * K + 63) / 64), dim3(64), 0, c->stream, R, K, round, (uint32_t)seed,
+                           (uint32_t)(seed >> 32), c->chain_of_slot.p, c->icm_pairs.p);
+        HIP_TRY(c, hipGetLastError());
+    }
+    // one launch: components, pick, move, incremental fixed-point energies (k_icm_round; round 2's separate row walk of the
+    // cluster ran one thread per cluster spin from a cold kernel: 41 us -- inside the components workgroup, with both
+    // states in LDS, it is a few us)
+    int rc = icm_launch_round(c, pair_in_kernel ? nullptr : c->icm_pairs.p, n_pairs, round, seed, katzgraber, R, K);
     if (rc) return rc;
     if (out_info) {
         HIP_TRY(c, hipMemcpyAsync(out_info, c->icm_info.p, sizeof(int32_t) * 2 * n_pairs, hipMemcpyDeviceToHost, c->stream));

@@ -241,6 +241,220 @@ __global__ void k_icm_components(IcmArgs a)
     if (tid == 0) { a.info[2 * p] = converged ? nroots : -1; a.info[2 * p + 1] = 0; }
 }
 
+// ---- one fused kernel per batch of device-decided moves (round 3) ---------------------------------------------------
+// Components, pick, move and the energy bookkeeping of one pair in ONE workgroup: the labels never leave LDS, both
+// configurations are staged in LDS, and the tracked energies of the two chains are updated INCREMENTALLY in the fixed-point
+// model of the sweep kernels (exact integers: dE = 2 sum_{i in C} s_i (sum_{j not in C} Jq_ij s_j + hq_i) for the exchanged
+// cluster C -- only bonds that leave the cluster count --, dE = 2 hq.s for the global flip of the Katzgraber variant):
+// no k_energy pass over all chains afterwards.  Round 2 ran k_icm_components (57 us) + k_icm_move (12 us) + k_energy over
+// all 256 chains (30 us) per APT round at N = 10^4.
+struct IcmRoundArgs {
+    CsrDev g;
+    int8_t *spins;            // [n_chains][n_pad]
+    const int32_t *pairs;     // [n_pairs][2] local chain ids, or nullptr: the Houdayer pairing of the APT round is made here --
+    int pair_R, pair_K;       // block p pairs the ladders ranked 2i, 2i+1 among the K ladders of slot r = p / (K/2), i = p % (K/2),
+    const int32_t *chain_of_slot;   // ranks by the keys philox(j, round, r, ICM_PAIR) (k_icm_pair_ladders' law, NPT/apt_ICM.py:216-222)
+    int32_t *info;            // [n_pairs][2]  {n_components (-1: hook rounds did not converge), picked size}
+    const uint4 *adj;         // 16-bit adjacency table or nullptr (see IcmArgs)
+    uint32_t round, seed_lo, seed_hi;
+    int katz, chain_base;
+    long long *efix;          // [n_chains] tracked energies, units 2^-escale
+    double *energy_sink;      // [n_chains] or nullptr
+    int eshift, escale;       // escale - qs
+    int lds_cand_off, lds_sa_off, lds_sb_off;
+};
+
+__global__ __launch_bounds__(1024) void k_icm_round(IcmRoundArgs a)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    int32_t *lab = reinterpret_cast<int32_t *>(lds_raw);
+    uint16_t *cand = reinterpret_cast<uint16_t *>(lds_raw + a.lds_cand_off);
+    int8_t *sa = reinterpret_cast<int8_t *>(lds_raw + a.lds_sa_off), *sb = reinterpret_cast<int8_t *>(lds_raw + a.lds_sb_off);
+    __shared__ int nroots, ncand, sh_root, sh_size;
+    __shared__ int sh_scan[17];
+    __shared__ long long sh_dE[2];
+    const int n = a.g.n, n_pad = a.g.n_pad, tid = threadIdx.x, nt = blockDim.x, p = blockIdx.x;
+    __shared__ int sh_pair[2];
+    if (!a.pairs) {                        // pairing on the fly (pair_K <= blockDim.x: checked by the host)
+        const int half = a.pair_K / 2, r = p / half, i = p % half;
+        if (tid < a.pair_K) {
+            const uint32_t kj = philox4x32_10((uint32_t)tid, a.round, (uint32_t)r, 6u /*NLMC_TAG_ICM_PAIR*/, a.seed_lo, a.seed_hi).x;
+            int rank = 0;
+            for (int q = 0; q < a.pair_K; ++q) {
+                if (q == tid) continue;
+                const uint32_t kq = philox4x32_10((uint32_t)q, a.round, (uint32_t)r, 6u, a.seed_lo, a.seed_hi).x;
+                rank += (kq < kj) || (kq == kj && q < tid);
+            }
+            if (rank == 2 * i || rank == 2 * i + 1) sh_pair[rank & 1] = a.chain_of_slot[(size_t)tid * a.pair_R + r];
+        }
+        __syncthreads();
+    }
+    const int ca = a.pairs ? a.pairs[2 * p] : sh_pair[0], cb = a.pairs ? a.pairs[2 * p + 1] : sh_pair[1];
+    int8_t *ga = a.spins + (size_t)ca * n_pad, *gb = a.spins + (size_t)cb * n_pad;
+    if (tid == 0) { nroots = 0; ncand = 0; sh_size = 0; sh_dE[0] = 0; sh_dE[1] = 0; sh_root = -1; }
+    for (int i = tid; i < n_pad / 16; i += nt) {
+        reinterpret_cast<int4 *>(sa)[i] = reinterpret_cast<const int4 *>(ga)[i];
+        reinterpret_cast<int4 *>(sb)[i] = reinterpret_cast<const int4 *>(gb)[i];
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += nt) {
+        const bool d = (int)sa[k] * (int)sb[k] == -1;
+        lab[k] = d ? k : INT_MAX;
+        if (d) cand[atomicAdd(&ncand, 1)] = (uint16_t)k;
+    }
+    __syncthreads();
+    const int nc = ncand;
+    bool converged = false;                // (workgroup-uniform)
+    for (int it = 0; it <= n; ++it) {
+        int changed = 0;
+        if (a.adj) {
+            // neighbour lists of the NEXT candidate of this thread are in flight while the current one is hooked (two 16-byte
+            // loads + the row bounds per candidate were a dependent global round trip each before)
+            int idx = tid, k = 0, rs = 0, deg = 0;
+            uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+            if (idx < nc) { k = (int)cand[idx]; a0 = a.adj[2 * k]; a1 = a.adj[2 * k + 1]; rs = a.g.rowptr[k]; deg = a.g.rowptr[k + 1] - rs; }
+            while (idx < nc) {
+                const int idn = idx + nt;
+                int kn = 0, rsn = 0, degn = 0;
+                uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0;
+                if (idn < nc) { kn = (int)cand[idn]; b0 = a.adj[2 * kn]; b1 = a.adj[2 * kn + 1]; rsn = a.g.rowptr[kn]; degn = a.g.rowptr[kn + 1] - rsn; }
+                int rk = icm_find(lab, k);
+                auto hook = [&](int j) {
+                    if (j == k || lab[j] == INT_MAX) return;
+                    const int rj = icm_find(lab, j);
+                    if (rj < rk) { atomicMin(&lab[rk], rj); rk = rj; changed = 1; }
+                    else if (rk < rj) { atomicMin(&lab[rj], rk); changed = 1; }
+                };
+                const uint32_t aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int q = 0; q < NLMC_FZ_ADJ; ++q) hook((int)((aw[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu));
+                for (int e = rs + NLMC_FZ_ADJ; e < rs + deg; ++e) hook(a.g.col[e]);
+                idx = idn; k = kn; rs = rsn; deg = degn; a0 = b0; a1 = b1;
+            }
+        } else {
+            for (int idx = tid; idx < nc; idx += nt) {
+                const int k = (int)cand[idx];
+                int rk;
+                auto hook = [&](int j) {
+                    if (j == k || lab[j] == INT_MAX) return;
+                    const int rj = icm_find(lab, j);
+                    if (rj < rk) { atomicMin(&lab[rk], rj); rk = rj; changed = 1; }
+                    else if (rk < rj) { atomicMin(&lab[rj], rk); changed = 1; }
+                };
+                const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
+                EdgeQ ed[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ed[q] = a.g.edge32[rs + q];
+                rk = icm_find(lab, k);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q < deg && (ed[q].q != 0 || a.g.val64[rs + q] != 0.0)) hook(ed[q].col);
+                for (int e = rs + 8; e < rs + deg; ++e) {
+                    const EdgeQ t = a.g.edge32[e];
+                    if (t.q != 0 || a.g.val64[e] != 0.0) hook(t.col);
+                }
+            }
+        }
+        if (!__syncthreads_or(changed)) { converged = true; break; }
+    }
+    // final labels (every candidate points at its root), number of components
+    int cnt = 0;
+    for (int idx = tid; idx < nc; idx += nt) {
+        const int k = (int)cand[idx];
+        const int l = icm_find(lab, k);
+        cnt += (l == k);
+    }
+    if (cnt) atomicAdd(&nroots, cnt);
+    __syncthreads();
+    for (int idx = tid; idx < nc; idx += nt) { const int k = (int)cand[idx]; lab[k] = icm_find(lab, k); }
+    __syncthreads();
+    const int ncomp = converged ? nroots : -1;
+    if (ncomp <= 0) {                       // nothing to move (identical or opposite... no disagreement), or not converged
+        if (tid == 0) { a.info[2 * p] = ncomp; a.info[2 * p + 1] = 0; }
+        return;
+    }
+    // pick component number floor(r ncomp / 2^32) in ascending-label order (NPT/apt_ICM.py:232-233)
+    const uint32_t r = philox4x32_10((uint32_t)(a.chain_base + ca), a.round, (uint32_t)(a.chain_base + cb), NLMC_TAG_ICM, a.seed_lo, a.seed_hi).x;
+    const int pick = (int)(((unsigned long long)r * (unsigned long long)ncomp) >> 32);
+    const int chunk = (n + nt - 1) / nt;
+    const int b = min(tid * chunk, n), e = min(b + chunk, n);
+    int mine = 0;
+    for (int k = b; k < e; ++k) mine += (lab[k] == k);
+    const int lane = tid & 63, wv = tid >> 6;
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+    if (lane == 63) sh_scan[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += sh_scan[w];
+    const int before = base + incl - mine;
+    if (pick >= before && pick < before + mine) {
+        int seen = before;
+        for (int k = b; k < e; ++k)
+            if (lab[k] == k) { if (seen == pick) { sh_root = k; break; } ++seen; }
+    }
+    __syncthreads();
+    const int root = sh_root;
+    int csz = 0;
+    for (int idx = tid; idx < nc; idx += nt) csz += (lab[(int)cand[idx]] == root);
+    if (csz) atomicAdd(&sh_size, csz);
+    __syncthreads();
+    const int size = sh_size;
+    long long dEa = 0, dEb = 0;
+    if (a.katz && size > n / 2) {
+        // state_1 = -state_1 (NPT/apt_ICM.py:236-237): the coupling term is even in s, the field term changes sign
+        for (int k = tid; k < n; k += nt) { dEa += 2ll * (long long)a.g.hq[k] * (long long)sa[k]; ga[k] = (int8_t)(-sa[k]); }
+    } else {
+        // exchange the cluster between the two states (both flip on it: they disagree there)
+        for (int idx = tid; idx < nc; idx += nt) {
+            const int k = (int)cand[idx];
+            if (lab[k] != root) continue;
+            const int rs = a.g.rowptr[k], re = a.g.rowptr[k + 1];
+            long long fa = a.g.hq[k], fb = fa;
+            EdgeQ ed[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ed[q] = a.g.edge32[rs + q];     // unconditional (padded array): eight loads in flight
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (rs + q < re && lab[ed[q].col] != root) {            // bonds inside the cluster (and the diagonal) keep their energy
+                    fa += (long long)ed[q].q * (long long)sa[ed[q].col];
+                    fb += (long long)ed[q].q * (long long)sb[ed[q].col];
+                }
+            }
+            for (int q = rs + 8; q < re; ++q) {
+                const EdgeQ t = a.g.edge32[q];
+                if (lab[t.col] == root) continue;
+                fa += (long long)t.q * (long long)sa[t.col];
+                fb += (long long)t.q * (long long)sb[t.col];
+            }
+            dEa += 2ll * (long long)sa[k] * fa;
+            dEb += 2ll * (long long)sb[k] * fb;
+            ga[k] = sb[k];
+            gb[k] = sa[k];
+        }
+    }
+    dEa = wave_sum_i64(dEa);
+    dEb = wave_sum_i64(dEb);
+    if (lane == 0) {
+        if (dEa) atomicAdd(reinterpret_cast<unsigned long long *>(&sh_dE[0]), (unsigned long long)dEa);
+        if (dEb) atomicAdd(reinterpret_cast<unsigned long long *>(&sh_dE[1]), (unsigned long long)dEb);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const long long ea = a.efix[ca] + sh_dE[0] * (1ll << a.eshift), eb = a.efix[cb] + sh_dE[1] * (1ll << a.eshift);
+        a.efix[ca] = ea;
+        a.efix[cb] = eb;
+        if (a.energy_sink) {
+            const double inv = __longlong_as_double((long long)(1023 - a.escale) << 52);
+            a.energy_sink[ca] = (double)ea * inv;
+            a.energy_sink[cb] = (double)eb * inv;
+        }
+        a.info[2 * p] = ncomp;
+        a.info[2 * p + 1] = size;
+    }
+}
+
 // Houdayer pairing on the device (NPT/apt_ICM.py:216-222): for every temperature slot r the K ladders (sub-replicas)
 // are shuffled -- order = sort of the keys philox(j, round, r, ICM_PAIR) -- and paired (sh[0], sh[1]), (sh[2], sh[3]), ...;
 // a pair is written as the two LOCAL chains that currently hold slot r in those ladders.

@@ -9,6 +9,7 @@ number is a pure function of (seed, global chain id, sweep, spin), the trajector
 of ranks.
 """
 import os
+import sys
 
 import numpy as np
 
@@ -50,13 +51,18 @@ class ShardedTempering:
             # The all-gather of a round is issued by the LIBRARY (ncclAllGather from libnlmc_hip.so on the stream its kernels
             # run on: no hand-over between c10d's collective stream and the kernels' stream, ~10 us per round); its
             # communicator's unique id travels through the process group that is already up.
-            uid = torch.zeros(128, dtype=torch.uint8, device=device)
+            uid = torch.zeros(129, dtype=torch.uint8, device=device)       # [128] = 1: rank 0 could create an id
             if self.rank == 0:
-                uid.copy_(torch.from_numpy(self.eng.comm_unique_id()))
+                try:
+                    uid[:128].copy_(torch.from_numpy(self.eng.comm_unique_id()))
+                    uid[128] = 1
+                except (NotImplementedError, RuntimeError) as ex:          # no usable librccl: every rank takes the c10d path
+                    print(f"[nlmc] library-issued all-gather unavailable ({ex}); using torch.distributed", file=sys.stderr)
             dist.broadcast(uid, 0)
-            self.eng.comm_init(uid.cpu().numpy(), self.world, self.rank)
-            self.lib_collective = True
-        elif self.collective:
+            if int(uid[128].item()) == 1:
+                self.eng.comm_init(uid[:128].cpu().numpy(), self.world, self.rank)
+                self.lib_collective = True
+        if self.collective and not self.lib_collective:
             self.e_local = torch.empty(self.count, dtype=torch.float64, device=device)
             self.e_all = torch.empty(self.G, dtype=torch.float64, device=device)
             # the sweep kernels write their chains' energies straight into the all-gather's send buffer

@@ -81,7 +81,7 @@ def c5():
     G = R * K
     eng = P.Engine(J, h, G)
     eng.set_spins(init_spins(G, N)); eng.pt_init(np.geomspace(0.05, 4.0, R))
-    planner = P.engine.RoundPlanner(eng, 0, rounds + 1, S, 5); planner._plan(0, True); eng.pt_plan(0, rounds + 1, 5, 10)
+    planner = P.engine.RoundPlanner(eng, 0, rounds + 1, S, 5, budget_bytes=8 << 30); planner._plan(0, True); eng.pt_plan(0, rounds + 1, 5, 10)
     def one(r):
         planner.sweep(r)
         eng.icm_round_ladders(r, 5, True)
