@@ -18,6 +18,8 @@ python3 "$REPO/scripts/summarize_prof.py" "$TAG" "$OUT/stats" "$OUT/fetch" "$OUT
 # secondary kernels: backbone inference (k_lbp) and the APT + iso-cluster round (C5)
 timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/lbp" -o s -- python3 $REPO/scripts/lbp_throughput.py > "$OUT/lbp.log" 2>&1
 timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c5" -o s -- python3 $REPO/scripts/c5_only.py > "$OUT/c5.log" 2>&1
+RESTARTS=8 timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c3nmc" -o s -- python3 $REPO/scripts/npt_nmc_throughput.py > "$OUT/c3nmc.log" 2>&1
+cp "$OUT/c3nmc/s_kernel_stats.csv" "$REPO/profiles/${TAG}_c3nmc_kernel_stats.csv"
 cp "$OUT/lbp/s_kernel_stats.csv" "$REPO/profiles/${TAG}_lbp_kernel_stats.csv"
 cp "$OUT/c5/s_kernel_stats.csv" "$REPO/profiles/${TAG}_c5_kernel_stats.csv"
 cp "$REPO"/profiles/${TAG}_* "$REPO"/profiles/current_sweep_pmc.json "$OUT"/

@@ -47,7 +47,7 @@ def main():
     hbm = int(round((2.0 * fs[1] + ws[1]) * 1024))
     with open(os.path.join(out, f"{tag}_sweep_hbm_traffic_pmc.csv"), "w") as g:
         g.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE  and (separate pass)  --pmc WRITE_SIZE  -- python3 bench.py "
-                "--steps 4 --warmup 1 --no-cpu-baseline --no-f64-leg\n"
+                "--steps 1 --warmup 1 --no-cpu-baseline --no-f64-leg\n"
                 f"# per launch of {kname} (256 chains x 1e4 spins x 10 sweeps); counter unit = KiB\n"
                 "# gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of wide coalesced reads -> "
                 "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024\n"
@@ -56,7 +56,7 @@ def main():
                 f"# hbm_bytes_per_launch,{hbm}\n# algorithmic_bytes_per_launch,{256 * 10_000 * 10 * 63}\n")
     if sq_dirs:
         with open(os.path.join(out, f"{tag}_sweep_pmc_summary.csv"), "w") as g:
-            g.write("# rocprofv3 --kernel-trace --pmc <counters, one pass per line group> -- python3 bench.py --steps 4 "
+            g.write("# rocprofv3 --kernel-trace --pmc <counters, one pass per line group> -- python3 bench.py --steps 1 "
                     f"--warmup 1 --no-cpu-baseline --no-f64-leg\n# {kname}, per launch (256 chains x 1e4 spins x 10 sweeps)\n"
                     "counter,mean_per_launch\n")
             for d in sq_dirs:
