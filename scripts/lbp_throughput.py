@@ -28,9 +28,10 @@ for N in (1000, 10000):
         eng.lbp_convexified(ms[:1], eps, lams, 2.5, EPS, 100, 1.0)          # graph build + warm-up
         for B in (1, 4, 64, 256):
             mb = np.concatenate([ms] * (B // 4)) if B >= 4 else ms[:1]
-            t = time.perf_counter()
-            o = eng.lbp_convexified(mb, eps, lams, 2.5, EPS, 100, float(np.tanh(19.06)) - EPS)
-            dt = time.perf_counter() - t
+            for rep in range(2):                     # (second call: buffers of this batch size exist)
+                t = time.perf_counter()
+                o = eng.lbp_convexified(mb, eps, lams, 2.5, EPS, 100, float(np.tanh(19.06)) - EPS)
+                dt = time.perf_counter() - t
             iters = int((o["iters"][0][:o["n_lambdas"][0]] + 1).sum())
             print(f"N={N} problems={B}: device {dt*1e3:.2f} ms ({dt/B*1e3:.3f} ms/problem, {iters} BP iterations in problem 0, "
                   f"{o['n_lambdas'][0]} lambdas); host 1 problem {t_host*1e3:.1f} ms ({len(hm)} lambdas)", flush=True)
