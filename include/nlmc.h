@@ -234,6 +234,8 @@ int nlmc_backbone_clusters(nlmc_ctx *ctx, const double *epsilon /*[n]*/, const d
                            double tolerance, int max_iterations, double sat, const double *thresholds, int n_thresholds);
 int nlmc_backbone_check(nlmc_ctx *ctx);
 int nlmc_get_cluster_mask(nlmc_ctx *ctx, uint8_t *out /*[n_chains][n]*/);
+/* Caller-provided backbones instead of an inference (NMC_subroutine's `all_clusters` argument, NPT/npt.py:357-359): 1 = in a cluster. */
+int nlmc_set_cluster_mask(nlmc_ctx *ctx, const uint8_t *mask /*[n_chains][n]*/);
 int nlmc_set_phase(nlmc_ctx *ctx, int kind, double temp_x);
 /* Fused-window plans live in two slots; nlmc_plan_philox_fused / nlmc_plan_reserve_fused write to the selected one, sweep
  * calls use whichever slot covers their sweeps (a round sweeps its plain chains on windows of num_sweeps_MCMC_per_swap and

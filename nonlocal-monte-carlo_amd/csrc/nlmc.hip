@@ -2034,7 +2034,7 @@ static int lbp_setup(nlmc_ctx *c, int n_problems, const double *epsilon, const d
 
 // the batched lambda loop on the seeds in lbp_ms (stream-ordered, no synchronisation)
 static int lbp_launch(nlmc_ctx *c, int n_problems, int n_lambdas, double beta, double tolerance, int max_iterations, double sat,
-                      bool want_all)
+                      bool want_all, bool single_workgroup = false)
 {
     const int n = c->n, nnz = (int)c->nnz;
     const size_t P = (size_t)n_problems;
@@ -2058,7 +2058,9 @@ static int lbp_launch(nlmc_ctx *c, int n_problems, int n_lambdas, double beta, d
     int group = 1;
     while (group < 8 && (long long)n_problems * group * 2 <= std::min(32, cus) && n / (group * 2) >= 1024) group *= 2;
     if (const char *e = getenv("NLMC_LBP_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 8 && (long long)n_problems * v <= cus) group = v; }
+    if (single_workgroup) group = 1;
     a.group = group;
+    if (const char *e = getenv("NLMC_LBP_POLL_BUDGET")) a.poll_budget = atoi(e);      // (test knob: provoke the timeout path)
     HIP_TRY(c, c->lbp_bar.reserve(P));
     HIP_TRY(c, c->lbp_part.reserve(P * 2 * (size_t)group * 4));
     HIP_TRY(c, hipMemsetAsync(c->lbp_bar.p, 0, sizeof(unsigned int) * P, c->cur));
@@ -2109,6 +2111,20 @@ int nlmc_lbp_convexified(nlmc_ctx *c, int n_problems, const double *m_star, cons
     if (out_mag_all)
         HIP_TRY(c, hipMemcpyAsync(out_mag_all, c->lbp_mag_all.p, sizeof(double) * P * (size_t)n_lambdas * n, hipMemcpyDeviceToHost, c->cur));
     HIP_TRY(c, hipStreamSynchronize(c->cur));
+    bool lost = false;
+    for (size_t q = 0; q < P; ++q) lost = lost || oi[P + q] == 2;
+    if (lost) {
+        // The workgroups that share a problem poll each other with a bounded budget; they only find each other when all of
+        // them are resident, which another context on the same GPU can prevent.  Once more with ONE workgroup per
+        // problem -- slower, no barrier between workgroups, same bits -- before giving up.
+        HIP_TRY(c, hipMemcpyAsync(c->lbp_ms.p, m_star, sizeof(double) * P * n, hipMemcpyHostToDevice, c->cur));
+        { int rc = lbp_launch(c, n_problems, n_lambdas, beta, tolerance, max_iterations, sat, out_mag_all != nullptr, true); if (rc) return rc; }
+        HIP_TRY(c, hipMemcpyAsync(oi.data(), c->lbp_out_i.p, sizeof(int32_t) * oi.size(), hipMemcpyDeviceToHost, c->cur));
+        HIP_TRY(c, hipMemcpyAsync(out_mag, c->lbp_mag.p, sizeof(double) * P * n, hipMemcpyDeviceToHost, c->cur));
+        if (out_mag_all)
+            HIP_TRY(c, hipMemcpyAsync(out_mag_all, c->lbp_mag_all.p, sizeof(double) * P * (size_t)n_lambdas * n, hipMemcpyDeviceToHost, c->cur));
+        HIP_TRY(c, hipStreamSynchronize(c->cur));
+    }
     for (size_t q = 0; q < P; ++q)
         if (oi[P + q] == 2) return fail(c, NLMC_ERR_HIP, "nlmc_lbp_convexified: the workgroups of a problem lost each other (group barrier timed out)");
     std::memcpy(out_n_lambdas, oi.data(), sizeof(int32_t) * P);
@@ -2238,7 +2254,10 @@ int nlmc_backbone_clusters(nlmc_ctx *c, const double *epsilon, const double *lam
     { int rc = ensure_subset(c); if (rc) return rc; }
     { int rc = lbp_setup(c, P, epsilon, lambdas, n_lambdas, beta, false); if (rc) return rc; }
     HIP_TRY(c, c->cmask.reserve((size_t)c->n_chains * c->n_pad));
-    HIP_TRY(c, c->nmc_status.reserve(1));
+    if (!c->nmc_status.p) {
+        HIP_TRY(c, c->nmc_status.reserve(1));
+        HIP_TRY(c, hipMemsetAsync(c->nmc_status.p, 0, sizeof(int32_t), c->cur));
+    }
     const std::vector<double> thr(thresholds, thresholds + n_thresholds);
     if (thr != c->nmc_thr_host) {
         HIP_TRY(c, c->nmc_thr.reserve((size_t)n_thresholds));
@@ -2281,6 +2300,20 @@ int nlmc_get_cluster_mask(nlmc_ctx *c, uint8_t *out)
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     rows_to_host_finish(c, out, c->n_chains);
+    return NLMC_OK;
+}
+
+int nlmc_set_cluster_mask(nlmc_ctx *c, const uint8_t *mask)
+{
+    if (!c || !mask) return fail(c, NLMC_ERR_ARG, "nlmc_set_cluster_mask: NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->n_chains == 0) return NLMC_OK;
+    HIP_TRY(c, c->cmask.reserve((size_t)c->n_chains * c->n_pad));
+    for (size_t i = 0; i < (size_t)c->n_chains * c->n; ++i)
+        if (mask[i] > 1) return fail(c, NLMC_ERR_ARG, "nlmc_set_cluster_mask: entries must be 0 or 1");
+    int rc = rows_to_device(c, c->cmask.p, mask, c->n_chains);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return NLMC_OK;
 }
 

@@ -36,6 +36,7 @@ struct LbpArgs {
     int group;
     unsigned int *bar;          // [P] arrival counters (zeroed before the launch)
     double *part;               // [P][2][group][4] partial maxima of the convergence test, double-buffered
+    int poll_budget;            // polls a workgroup spends waiting for its group (0: the default, ~4M)
 };
 
 __global__ void k_lbp_src(int n, const int32_t *rowptr, int32_t *src)
@@ -245,7 +246,7 @@ __device__ __forceinline__ double lbp_wave_max(double v)
 // counter and polls it with relaxed agent-scope loads, then every thread acquires (invalidates its CU's L1).  The
 // launch keeps problems * group <= number of CUs, so all workgroups are resident; the poll is BOUNDED all the same --
 // on a timeout the problem is flagged (status 2) and its workgroups leave.  Returns false on timeout.
-__device__ __forceinline__ bool lbp_group_barrier(unsigned int *counter, unsigned int target, int tid)
+__device__ __forceinline__ bool lbp_group_barrier(unsigned int *counter, unsigned int target, int tid, int poll_budget)
 {
     __shared__ int ok;
     __threadfence();                                            // release (agent): write back this thread's stores
@@ -253,7 +254,7 @@ __device__ __forceinline__ bool lbp_group_barrier(unsigned int *counter, unsigne
     __syncthreads();
     if (tid == 0) {
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int budget = 1 << 22;
+        int budget = poll_budget > 0 ? poll_budget : 1 << 22;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && --budget > 0)
             __builtin_amdgcn_s_sleep(2);
         ok = budget > 0;
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(NLMC_LBP_THREADS) void k_lbp(LbpArgs a)
         hm[e] = 0.0;
     }
     for (int i = i0 + tid; i < i1; i += NLMC_LBP_THREADS) tot[i] = 0.0;
-    if (G > 1) dead = !lbp_group_barrier(a.bar + p, ++seq * (unsigned)G, tid);
+    if (G > 1) dead = !lbp_group_barrier(a.bar + p, ++seq * (unsigned)G, tid, a.poll_budget);
     else __syncthreads();
 
     int n_done = 0, status = 0;
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(NLMC_LBP_THREADS) void k_lbp(LbpArgs a)
             }
             if (G > 1) {
                 const unsigned int slot = seq & 1u;
-                if (!lbp_group_barrier(a.bar + p, ++seq * (unsigned)G, tid)) { dead = true; break; }
+                if (!lbp_group_barrier(a.bar + p, ++seq * (unsigned)G, tid, a.poll_budget)) { dead = true; break; }
                 if (tid < 4) {
                     double m = 0.0;
                     for (int k = 0; k < G; ++k) m = fmax(m, a.part[(((size_t)p * 2 + slot) * G + k) * 4 + tid]);

@@ -393,6 +393,10 @@ class Engine:
         self._ck(self._L.nlmc_get_cluster_mask(self._ctx, _abi.ptr(out)))
         return out
 
+    def set_cluster_mask(self, mask):
+        m = _abi.as_c(np.asarray(mask).astype(bool), np.uint8).reshape(self.n_chains, self.n)
+        self._ck(self._L.nlmc_set_cluster_mask(self._ctx, _abi.ptr(m)))
+
     def set_phase(self, kind, temp_x=1.0):
         k = {"ALL": _abi.PHASE_ALL, "C": _abi.PHASE_BACKBONE_HOT, "NC": _abi.PHASE_BACKBONE_FROZEN}[kind]
         self._ck(self._L.nlmc_set_phase(self._ctx, k, float(temp_x)))

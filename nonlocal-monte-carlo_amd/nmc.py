@@ -62,9 +62,77 @@ class NMC(Common):
         R, N = int(num_restarts), inst.n
         S0, S = int(num_sweeps_initial), int(num_sweeps_per_NMC_phase)
         eng = self._cache.engine(self.J, self.h, R)
+        m = np.sign(2 * np.random.default_rng(self.seed).random((R, N)) - 1).astype(np.int8)
+        args = (lambda_start, lambda_end, lambda_reduction_factor, threshold_initial, threshold_cutoff, max_iterations, tolerance)
+        if full_update_frequency == 1:
+            return self._run_restarts_device(eng, inst, m, S0, S, num_NMC_cycles, temp_x, global_beta, all_clusters, *args)
+        return self._run_restarts_host(eng, inst, m, S0, S, num_NMC_cycles, full_update_frequency, temp_x, global_beta,
+                                       all_clusters, *args)
+
+    def _run_restarts_device(self, eng, inst, m, S0, S, num_NMC_cycles, temp_x, global_beta, all_clusters, lambda_start,
+                             lambda_end, lambda_reduction_factor, threshold_initial, threshold_cutoff, max_iterations, tolerance):
+        """Every cycle ends with a plain phase (full_update_frequency == 1), so the state a cycle's backbone inference is seeded
+        with (m_star, NMC/nmc.py:368-373,433) is the state its first phase starts from: the hand-offs, the inference seeds, the
+        cluster masks and the phase flags all stay on the device (include/nlmc.h: nlmc_adopt_best, nlmc_backbone_clusters,
+        nlmc_set_phase); per launch only the minima and argmin states come back for the run's own best-of bookkeeping."""
+        from .lbp import lambda_list, _SAT, EPS as _EPS
+        R, N = m.shape
+        sweep0 = self._sweep_counter
+        best_e, best_s, trail = np.full(R, np.inf), m.copy(), []
+        eng.select("all")
+        eng.set_spins(m)
+        eng.set_flags(None)
+
+        def launch(n_sweeps, beta):
+            nonlocal sweep0, best_e
+            o = eng.sweep_philox_windows(n_sweeps, self.seed, sweep0=sweep0, beta=beta, want_min=True, want_state=True)
+            sweep0 += n_sweeps
+            better = o["min_energy"] < best_e
+            best_e = np.where(better, o["min_energy"], best_e)
+            best_s[better] = o["argmin_state"][better]
+            trail.append(o["min_energy"].copy())
+            eng.adopt_best()                     # the next launch starts from the argmin column (NMC/nmc.py:394-395)
+            eng.energy()                         # ... with its fp64 energy as the tracked one (what set_spins did per launch)
+
+        if S0 > 0:
+            sched = hostlogic.beta_schedule(S0, global_beta, True, 1, 0)
+            launch(S0, np.repeat(sched[None, :], R, axis=0))
+        if S > 0 and num_NMC_cycles > 0:
+            if all_clusters is None:
+                lams = lambda_list(lambda_start, lambda_end, lambda_reduction_factor)
+                if not lams:
+                    raise TypeError("bad operand type for abs(): 'NoneType'")
+                thr, t = [float(threshold_initial)], threshold_initial - 0.01
+                while t > threshold_cutoff:
+                    thr.append(float(t))
+                    t -= 0.01
+                epsilon = self._graph(inst).epsilon(inst.h)
+            else:
+                mask = np.zeros((R, N), dtype=np.uint8)
+                mask[:, np.asarray(all_clusters, dtype=int)] = 1
+                eng.set_cluster_mask(mask)
+            try:
+                for cycle in range(num_NMC_cycles):
+                    if all_clusters is None:
+                        eng.backbone_clusters(epsilon, lams, global_beta, tolerance, max_iterations, _SAT - _EPS, thr)
+                    for kind in ("C", "NC", "ALL"):
+                        eng.set_phase(kind, temp_x)
+                        launch(S, float(global_beta))
+                eng.backbone_check()
+            finally:
+                eng.set_flags(None)
+        self._sweep_counter = sweep0
+        # the running minima were tracked in the fixed-point model; report the fp64 energies of the kept states
+        return eng.energy_of(best_s), best_s, np.stack(trail, axis=1) if trail else np.zeros((R, 0))
+
+    def _run_restarts_host(self, eng, inst, m, S0, S, num_NMC_cycles, full_update_frequency, temp_x, global_beta, all_clusters,
+                           lambda_start, lambda_end, lambda_reduction_factor, threshold_initial, threshold_cutoff, max_iterations,
+                           tolerance):
+        """Cycles without a plain phase keep an older m_star for the inference than the state the phases continue from: the
+        hand-offs go through the host (state and flags uploaded per launch)."""
+        R, N = m.shape
         graph = self._graph(inst) if all_clusters is None else None
         epsilon = graph.epsilon(inst.h) if all_clusters is None else None
-        m = np.sign(2 * np.random.default_rng(self.seed).random((R, N)) - 1).astype(np.int8)
         sweep0 = self._sweep_counter
         best_e = np.full(R, np.inf)
         best_s = m.copy()

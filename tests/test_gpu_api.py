@@ -336,6 +336,31 @@ def test_nmc_run_restarts_batched(product):
         assert np.allclose(trail[c], mins, rtol=0, atol=1e-9)
 
 
+def test_nmc_run_restarts_device_hand_offs_equal_the_host_managed_path(product):
+    """run_restarts with inferred backbones: the device-resident cycle (inference seeded from the chains' states, cluster masks,
+    phase flags and argmin hand-offs on the device) gives the bits of the host-managed one (states and flags uploaded per launch,
+    clusters grown on the host from the same marginals)."""
+    import contextlib
+    import io
+    from helpers import make_instance
+    N, R = 600, 5
+    J, h = make_instance(N, seed=23)
+    kw = dict(temp_x=20, global_beta=3.0, lambda_start=3.0, lambda_end=0.05, lambda_reduction_factor=0.8,
+              threshold_initial=0.9999, threshold_cutoff=0.97, max_iterations=100, tolerance=np.finfo(float).eps)
+    a = product.NMC(J, h, rng="philox", seed=77)
+    ea, sa, ta = a.run_restarts(R, num_sweeps_initial=20, num_sweeps_per_NMC_phase=12, num_NMC_cycles=3, **kw)
+    b = product.NMC(J, h, rng="philox", seed=77)
+    inst = b._cache.instance(b.J, b.h)
+    eng = b._cache.engine(b.J, b.h, R)
+    m = np.sign(2 * np.random.default_rng(77).random((R, N)) - 1).astype(np.int8)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eb, sb, tb = b._run_restarts_host(eng, inst, m, 20, 12, 3, 1, kw["temp_x"], kw["global_beta"], None, kw["lambda_start"],
+                                          kw["lambda_end"], kw["lambda_reduction_factor"], kw["threshold_initial"],
+                                          kw["threshold_cutoff"], kw["max_iterations"], kw["tolerance"])
+    assert ta.shape == (R, 1 + 3 * 3)
+    assert np.array_equal(ta, tb) and np.array_equal(sa, sb) and np.array_equal(ea, eb)
+
+
 def test_chimera2048_known_answer_and_search(product):
     """Real-instance sanity of SURVEY.md section 8(d): Chimera-2048 droplet instance 001 (data file + the first line of
     groundstates_otn2d.txt).  (i) the listed ground state evaluates to the listed energy (file prints 6 decimals);

@@ -174,3 +174,24 @@ def test_lds_resident_kernel_equals_the_global_memory_kernel(product, N, P, monk
         m = int(a["n_lambdas"][q])
         assert np.array_equal(a["iters"][q, :m], b["iters"][q, :m])
         assert np.array_equal(a["mag_all"][q, :m], b["mag_all"][q, :m])
+
+
+def test_group_barrier_timeout_falls_back_to_one_workgroup_per_problem(product, monkeypatch):
+    """the workgroups that share one inference poll each other with a bounded budget and give up when they are
+    not all resident (another context on the GPU); the call then runs once more with one workgroup per problem instead of
+    failing.  Provoked here with a poll budget of ONE poll; the result must equal the undisturbed call bit for bit."""
+    N = 9000
+    J, h = make_instance(N, seed=5)
+    inst = product.Instance(J, h)
+    graph = product.lbp.EdgeGraph(inst)
+    eps = graph.epsilon(inst.h)
+    ms = low_energy_states(J, h, 1, seed=2, sweeps=40).astype(np.float64)
+    lams = product.lbp.lambda_list(3.0, 0.5, 0.7)
+    sat = float(np.tanh(19.06)) - EPS
+    with product.Engine(inst, None, 1) as eng:
+        monkeypatch.setenv("NLMC_LBP_GROUP", "4")
+        a = eng.lbp_convexified(ms, eps, lams, 2.5, EPS, 60, sat)
+        monkeypatch.setenv("NLMC_LBP_POLL_BUDGET", "1")
+        b = eng.lbp_convexified(ms, eps, lams, 2.5, EPS, 60, sat)
+    assert a["status"][0] == 0 and b["status"][0] == 0
+    assert np.array_equal(a["mag"], b["mag"]) and np.array_equal(a["n_lambdas"], b["n_lambdas"])
