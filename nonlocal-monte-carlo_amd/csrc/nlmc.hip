@@ -2065,24 +2065,16 @@ static int lbp_launch(nlmc_ctx *c, int n_problems, int n_lambdas, double beta, d
     HIP_TRY(c, c->lbp_part.reserve(P * 2 * (size_t)group * 4));
     HIP_TRY(c, hipMemsetAsync(c->lbp_bar.p, 0, sizeof(unsigned int) * P, c->cur));
     a.bar = c->lbp_bar.p; a.part = c->lbp_part.p;
-    // small instances: messages in LDS, a thread's edges in registers (k_lbp_lds; same bits)
-    const int mpt = (nnz + NLMC_LBP_LDS_THREADS - 1) / NLMC_LBP_LDS_THREADS;
-    if (group == 1 && n <= 4 * NLMC_LBP_LDS_THREADS && mpt <= 12 && !getenv("NLMC_LBP_GLOBAL")) {
-        const int mpt_v = mpt <= 6 ? 6 : 12;
-        const size_t lds_small = ((size_t)2 * (mpt_v * NLMC_LBP_LDS_THREADS + 1) + 4 * NLMC_LBP_LDS_THREADS + 1 + 64) * sizeof(double);
-        const int variant = (mpt_v / 6 - 1) * 2 + (c->has_diag ? 1 : 0);
-        const void *kf = variant == 0 ? reinterpret_cast<const void *>(k_lbp_lds<6, false>)
-                         : variant == 1 ? reinterpret_cast<const void *>(k_lbp_lds<6, true>)
-                         : variant == 2 ? reinterpret_cast<const void *>(k_lbp_lds<12, false>)
-                                        : reinterpret_cast<const void *>(k_lbp_lds<12, true>);
-        { int rc = ensure_lds(c, 17 + variant, kf, lds_small); if (rc) return rc; }
-        switch (variant) {
-        case 0: hipLaunchKernelGGL((k_lbp_lds<6, false>), dim3(n_problems), dim3(NLMC_LBP_LDS_THREADS), lds_small, c->cur, a); break;
-        case 1: hipLaunchKernelGGL((k_lbp_lds<6, true>), dim3(n_problems), dim3(NLMC_LBP_LDS_THREADS), lds_small, c->cur, a); break;
-        case 2: hipLaunchKernelGGL((k_lbp_lds<12, false>), dim3(n_problems), dim3(NLMC_LBP_LDS_THREADS), lds_small, c->cur, a); break;
-        default: hipLaunchKernelGGL((k_lbp_lds<12, true>), dim3(n_problems), dim3(NLMC_LBP_LDS_THREADS), lds_small, c->cur, a); break;
-        }
-        HIP_TRY(c, hipGetLastError());
+    // small instances: messages in LDS, a thread's edges in registers (k_lbp_lds; same bits): 8 waves x 12 edges per thread, two
+    // messages in lock step (16 waves x 6 edges x one message were measured too: 8.4 instead of 8.8 us per iteration, with 30
+    // registers per lane spilled at the 128-register cap -- not kept)
+    if (group == 1 && n <= 2048 && nnz <= 6144 && !getenv("NLMC_LBP_GLOBAL")) {
+        const size_t lds_small = ((size_t)2 * (6144 + 1) + 2048 + 1 + 64) * sizeof(double);
+        const void *kf = c->has_diag ? reinterpret_cast<const void *>(k_lbp_lds<512, 12, 4, true, 2>)
+                                     : reinterpret_cast<const void *>(k_lbp_lds<512, 12, 4, false, 2>);
+        { int rc = ensure_lds(c, 17 + (c->has_diag ? 1 : 0), kf, lds_small); if (rc) return rc; }
+        void *kargs[] = {&a};
+        HIP_TRY(c, hipLaunchKernel(kf, dim3(n_problems), dim3(512), kargs, lds_small, c->cur));
         return NLMC_OK;
     }
     hipLaunchKernelGGL(k_lbp, dim3(n_problems * group), dim3(NLMC_LBP_THREADS), 0, c->cur, a);

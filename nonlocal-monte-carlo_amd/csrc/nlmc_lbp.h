@@ -389,20 +389,22 @@ __global__ __launch_bounds__(NLMC_LBP_THREADS) void k_lbp(LbpArgs a)
 // messages -> ONE barrier (the convergence maxima go through a 16-lane butterfly that every wave repeats, so the decision
 // is uniform without a broadcast).  Same operations in the same order as k_lbp: results are bit-identical
 // (tests/test_gpu_lbp.py).
-// 512 threads (2 waves per SIMD, 256 registers per lane): with 1024 the 128-register cap spilled ~100 registers per lane.
 // No per-lane predicates in the loop (a bool per edge is a 64-bit scalar mask each: 56 scalar registers, which pushed the
 // polynomial coefficients out of the scalar file): edge slots past nnz are harmless dummies (source = a node slot that
 // always holds 0, tanh(beta J) = 0, reads from message slots that stay 0, writes to a scratch slot: their message is
 // exactly 0 and every maximum they feed is 0), node slots past n likewise; diagonal entries only in the HAS_DIAG variant.
-#define NLMC_LBP_LDS_THREADS 512
-#ifndef NLMC_LBP_ILV
-#define NLMC_LBP_ILV 2            // message computations the scheduler may interleave
-#endif
-template <int MPT, bool HAS_DIAG>
-__global__ __launch_bounds__(NLMC_LBP_LDS_THREADS) void k_lbp_lds(LbpArgs a)
+// NT threads, MPT edges and NPT nodes per thread (NT MPT = 6144 edge slots, NT NPT = 2048 node slots), ILP message
+// computations in lock step per wave.  Instantiated as 8 waves x 12 edges x 2 (246 registers, no scratch).  The fp64 pipe alone
+// would prefer more streams (scripts/probes/fp64_issue_probe.hip: wave-FMAs per 100 counter ticks and CU -- 8 waves x 1 / 2 / 4
+// chains: 123 / 135 / 178, 16 waves x 1 / 2 / 4: 246 / 270 / 355), but 16 waves x 6 edges x 1 gained 5 % only (8.4 vs 8.8 us per
+// iteration, 30 registers per lane spilled): an iteration is fp64 issue AND four 8-byte LDS accesses per message (three of them
+// random) AND two barriers.
+template <int NT, int MPT, int NPT, bool HAS_DIAG, int ILP>
+__global__ __launch_bounds__(NT) void k_lbp_lds(LbpArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    constexpr int NT = NLMC_LBP_LDS_THREADS, NPT = 4, NW = NT / 64, ESLOTS = MPT * NT;
+    constexpr int NW = NT / 64, ESLOTS = MPT * NT;
+    static_assert(ESLOTS < 65536 && NPT * NT < 65536, "source / reverse slot are packed into 16 bits each");
     static_assert(NW <= 16, "red rows hold 16 waves");
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = a.n, nnz = a.nnz;
@@ -412,8 +414,10 @@ __global__ __launch_bounds__(NLMC_LBP_LDS_THREADS) void k_lbp_lds(LbpArgs a)
     const double *ms = a.m_star + (size_t)p * n;
 
     // this thread's edges
-    int e_src[MPT], e_rev[MPT];
+    unsigned e_sr[MPT];                 // source node slot | reverse message slot << 16
     double e_tJ[MPT], e_hm[MPT];
+#define E_SRC(k) (int)(e_sr[k] & 0xFFFFu)
+#define E_REV(k) (int)(e_sr[k] >> 16)
     unsigned bits = 0u;                 // bit k: node slot k exists; 4 + k: its dense h_msgs row has non-edge entries; 8 + k: edge k is diagonal
 #pragma unroll
     for (int k = 0; k < MPT; ++k) {
@@ -421,8 +425,7 @@ __global__ __launch_bounds__(NLMC_LBP_LDS_THREADS) void k_lbp_lds(LbpArgs a)
         const bool on = e < nnz;
         const int ec = on ? e : 0;
         const int si = a.src[ec], ri = a.rev[ec];
-        e_src[k] = on ? si : NPT * NT;
-        e_rev[k] = on ? ri : ESLOTS;
+        e_sr[k] = on ? ((unsigned)si | ((unsigned)ri << 16)) : ((unsigned)(NPT * NT) | ((unsigned)ESLOTS << 16));
         e_tJ[k] = on ? a.tJ[ec] : 0.0;
         e_hm[k] = 0.0;
         if (HAS_DIAG && on && a.col[ec] == si) bits |= 1u << (8 + k);
@@ -484,39 +487,46 @@ __global__ __launch_bounds__(NLMC_LBP_LDS_THREADS) void k_lbp_lds(LbpArgs a)
             // ---- messages: h_msgs[i, j] = total_i - u_msgs[j, i];  u_msgs[i, j] = atanh_sat(tanh(bJ) tanh(b h_msgs)) / b
             // (two messages at a time, the LDS reads of the next pair in flight meanwhile: left to itself the scheduler
             // interleaves all MPT message computations and spills)
-            static_assert(MPT % 2 == 0, "messages are processed in pairs");
-            double t_n[2] = {tot[e_src[0]], tot[e_src[1]]}, w_n[2] = {wc[tid], wc[tid + NT]}, u_n[2] = {wc[e_rev[0]], wc[e_rev[1]]};
+            static_assert(MPT % ILP == 0 && (ILP == 1 || ILP == 2), "messages are processed one or two at a time");
+            double t_n[ILP], w_n[ILP], u_n[ILP];
 #pragma unroll
-            for (int k = 0; k < MPT; k += 2) {
-                const double t_i[2] = {t_n[0], t_n[1]}, w_e[2] = {w_n[0], w_n[1]}, u_o[2] = {u_n[0], u_n[1]};
-                if (k + 2 < MPT) {
+            for (int j = 0; j < ILP; ++j) { t_n[j] = tot[E_SRC(j)]; w_n[j] = wc[tid + j * NT]; u_n[j] = wc[E_REV(j)]; }
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int kn = k + 2 + j < MPT ? k + 2 + j : 0;
-                        t_n[j] = tot[e_src[kn]];
+            for (int k = 0; k < MPT; k += ILP) {
+                double t_i[ILP], w_e[ILP], u_o[ILP], h_new[ILP], u_new[ILP];
+#pragma unroll
+                for (int j = 0; j < ILP; ++j) { t_i[j] = t_n[j]; w_e[j] = w_n[j]; u_o[j] = u_n[j]; }
+                if (k + ILP < MPT) {                 // the LDS reads of the next message(s) are in flight meanwhile
+#pragma unroll
+                    for (int j = 0; j < ILP; ++j) {
+                        const int kn = k + ILP + j < MPT ? k + ILP + j : 0;
+                        t_n[j] = tot[E_SRC(kn)];
                         w_n[j] = wc[tid + kn * NT];
-                        u_n[j] = wc[e_rev[kn]];
+                        u_n[j] = wc[E_REV(kn)];
                     }
                 }
-                LbpD2 h_new{t_i[0] - w_e[0], t_i[1] - w_e[1]};
-                if (HAS_DIAG) {
-                    h_new.a = (bits & (1u << (8 + k))) ? 0.0 : h_new.a;
-                    h_new.b = (bits & (1u << (9 + k))) ? 0.0 : h_new.b;
+#pragma unroll
+                for (int j = 0; j < ILP; ++j) {
+                    h_new[j] = t_i[j] - w_e[j];
+                    if (HAS_DIAG) h_new[j] = (bits & (1u << (8 + k + j))) ? 0.0 : h_new[j];
                 }
-                const LbpD2 u_new = lbp_message2(LbpD2{e_tJ[k], e_tJ[k + 1]}, LbpD2{a.beta * h_new.a, a.beta * h_new.b}, a.sat, a.usat, a.inv_beta);
-                const double h_old0 = e_hm[k], h_old1 = e_hm[k + 1];
-                e_hm[k] = h_new.a; e_hm[k + 1] = h_new.b;
-                wn[e_rev[k]] = u_new.a;
-                wn[e_rev[k + 1]] = u_new.b;
-                dh_n = fmax(dh_n, fabs(h_new.a - h_old0));
-                dh_d = fmax(dh_d, fabs(h_new.a) + fabs(h_old0));
-                du_n = fmax(du_n, fabs(u_new.a - u_o[0]));
-                du_d = fmax(du_d, fabs(u_new.a) + fabs(u_o[0]));
-                dh_n = fmax(dh_n, fabs(h_new.b - h_old1));
-                dh_d = fmax(dh_d, fabs(h_new.b) + fabs(h_old1));
-                du_n = fmax(du_n, fabs(u_new.b - u_o[1]));
-                du_d = fmax(du_d, fabs(u_new.b) + fabs(u_o[1]));
-                __builtin_amdgcn_sched_barrier(0);
+                if (ILP == 2) {
+                    const LbpD2 r2 = lbp_message2(LbpD2{e_tJ[k], e_tJ[k + ILP - 1]}, LbpD2{a.beta * h_new[0], a.beta * h_new[ILP - 1]}, a.sat, a.usat, a.inv_beta);
+                    u_new[0] = r2.a; u_new[ILP - 1] = r2.b;
+                } else {
+                    u_new[0] = lbp_message(e_tJ[k], a.beta * h_new[0], a.sat, a.usat, a.inv_beta);
+                }
+#pragma unroll
+                for (int j = 0; j < ILP; ++j) {
+                    const double h_old = e_hm[k + j];
+                    e_hm[k + j] = h_new[j];
+                    wn[E_REV(k + j)] = u_new[j];
+                    dh_n = fmax(dh_n, fabs(h_new[j] - h_old));
+                    dh_d = fmax(dh_d, fabs(h_new[j]) + fabs(h_old));
+                    du_n = fmax(du_n, fabs(u_new[j] - u_o[j]));
+                    du_d = fmax(du_d, fabs(u_new[j]) + fabs(u_o[j]));
+                }
+                __builtin_amdgcn_sched_barrier(0);   // (left to itself the scheduler hoists the loads of all MPT messages and spills)
             }
             dh_n = lbp_wave_max(dh_n); dh_d = lbp_wave_max(dh_d); du_n = lbp_wave_max(du_n); du_d = lbp_wave_max(du_d);
             if (lane == 0) { red[0 * 16 + wv] = dh_n; red[1 * 16 + wv] = dh_d; red[2 * 16 + wv] = du_n; red[3 * 16 + wv] = du_d; }
@@ -551,4 +561,6 @@ __global__ __launch_bounds__(NLMC_LBP_LDS_THREADS) void k_lbp_lds(LbpArgs a)
         __syncthreads();               // red / the message buffers are rewritten by the next lambda's first iteration
     }
     if (tid == 0) { a.out_nlam[p] = n_done; a.out_status[p] = status; }
+#undef E_SRC
+#undef E_REV
 }
