@@ -298,6 +298,11 @@ int nlmc_find_clusters(int n, const int32_t *rowptr, const int32_t *colidx, cons
 int nlmc_trace_layout(const int8_t *src, int64_t n_blocks, int64_t n_sweeps, int64_t n, const int32_t *dst_block,
                       const int32_t *dst_col, int64_t n_dst_blocks, int64_t row_len, void *dst, int elem_bytes, int n_threads);
 
+/* Host routine: writes one zero byte into every 4 KB page of a freshly allocated buffer from n_threads threads (<= 0: one per
+ * core, at most 32) -- the first-touch page faults of the reference-shaped float64 M (205 MB at the C4 shape: 14 of the 47 ms of
+ * an NPT.run call) are taken while the GPU is still sweeping instead of after it. */
+int nlmc_host_prefault(void *ptr, int64_t bytes, int n_threads);
+
 /* Timing of the most recent sweep call, measured with HIP events on the context's stream -- zero unless event timing
  * was switched on with nlmc_timing_reset (the plain product path records no events). */
 int nlmc_last_timing(nlmc_ctx *ctx, float *ms_levelize, float *ms_sweep, int32_t *launches_sweep);

@@ -30,7 +30,7 @@ EXPORTS = [
     "nlmc_lbp_convexified", "nlmc_find_clusters", "nlmc_trace_layout", "nlmc_energy_of_recorded",
     "nlmc_last_timing", "nlmc_timing_reset", "nlmc_timing_total", "nlmc_last_schedule_stats",
     "nlmc_pt_mark_slots", "nlmc_select_chains", "nlmc_subset_count", "nlmc_get_subset", "nlmc_track_minimum", "nlmc_adopt_best",
-    "nlmc_backbone_clusters", "nlmc_backbone_check", "nlmc_get_cluster_mask", "nlmc_set_phase", "nlmc_plan_slot", "nlmc_overlap_subsets", "nlmc_plan_get_levels", "nlmc_comm_unique_id", "nlmc_comm_init", "nlmc_pt_swap_philox_collective", "nlmc_set_cluster_mask",
+    "nlmc_backbone_clusters", "nlmc_backbone_check", "nlmc_get_cluster_mask", "nlmc_set_phase", "nlmc_plan_slot", "nlmc_overlap_subsets", "nlmc_plan_get_levels", "nlmc_comm_unique_id", "nlmc_comm_init", "nlmc_pt_swap_philox_collective", "nlmc_set_cluster_mask", "nlmc_host_prefault",
 ]
 
 
@@ -135,6 +135,8 @@ def lib():
     L.nlmc_energy_of_recorded.argtypes = [_vp, _i, _i, _vp]
     L.nlmc_trace_layout.restype = _i
     L.nlmc_trace_layout.argtypes = [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i, _i]
+    L.nlmc_host_prefault.restype = _i
+    L.nlmc_host_prefault.argtypes = [_vp, _i64, _i]
     L.nlmc_last_timing.restype = _i
     L.nlmc_last_timing.argtypes = [_vp, _vp, _vp, _vp]
     L.nlmc_timing_reset.restype = _i

@@ -2349,6 +2349,23 @@ int nlmc_find_clusters(int n, const int32_t *rowptr, const int32_t *colidx, cons
     return NLMC_OK;
 }
 
+int nlmc_host_prefault(void *ptr, int64_t bytes, int n_threads)
+{
+    if (!ptr || bytes < 0) return fail(nullptr, NLMC_ERR_ARG, "nlmc_host_prefault: bad argument");
+    if (n_threads <= 0) n_threads = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const int64_t page = 4096, pages = (bytes + page - 1) / page;
+    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(n_threads, pages / 256 + 1));
+    auto part = [&](int64_t p0, int64_t p1) {
+        volatile unsigned char *b = static_cast<volatile unsigned char *>(ptr);
+        for (int64_t q = p0; q < p1; ++q) b[q * page] = 0;
+    };
+    if (nt == 1) { part(0, pages); return NLMC_OK; }
+    std::vector<std::thread> th;
+    for (int64_t i = 0; i < nt; ++i) th.emplace_back(part, pages * i / nt, pages * (i + 1) / nt);
+    for (auto &t : th) t.join();
+    return NLMC_OK;
+}
+
 int nlmc_trace_layout(const int8_t *src, int64_t n_blocks, int64_t n_sweeps, int64_t n, const int32_t *dst_block,
                       const int32_t *dst_col, int64_t n_dst_blocks, int64_t row_len, void *dst, int elem_bytes, int n_threads)
 {

@@ -521,6 +521,16 @@ def _stitch_outputs(outs, chunk, record_stride, want_energy, want_min, want_stat
     return o
 
 
+def prefault_async(arr, n_threads=0):
+    """Touch every page of a freshly allocated array from a background thread (nlmc_host_prefault; the call releases the GIL).
+    Returns the thread: join() it before the array is filled."""
+    import threading
+    a = arr
+    t = threading.Thread(target=lambda: _abi.lib().nlmc_host_prefault(_abi.ptr(a), int(a.nbytes), int(n_threads)), daemon=True)
+    t.start()
+    return t
+
+
 def device_count():
     return int(_abi.lib().nlmc_device_count())
 

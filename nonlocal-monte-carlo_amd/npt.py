@@ -21,7 +21,7 @@ import numpy as np
 
 from . import hostlogic
 from .base import Common
-from .engine import Engine, trace_layout
+from .engine import Engine, prefault_async, trace_layout
 
 
 class NPT(Common):
@@ -299,6 +299,12 @@ class NPT(Common):
                 thr.append(float(t))
                 t -= 0.01
         lt = LocalTempering(inst, beta_list, G, self.seed, self.num_swapping_pairs, devs)
+        M_buf = M_touch = None
+        if return_trace == "float64" and R * N * S * 8 >= (32 << 20):
+            # the reference-shaped float64 M of the return value: allocated now, its pages faulted in by a background thread
+            # while the GPU sweeps (first touch of 205 MB at the C4 shape cost 14 of 47 ms after the run)
+            M_buf = np.empty((R * N, S), dtype=np.float64)
+            M_touch = prefault_async(M_buf)
         try:
             if nmc:
                 lt.configure_nmc(self.doNMC, phases, S_nmc, nmc["global_beta"], nmc["temp_x"], self._graph(inst).epsilon(inst.h),
@@ -353,8 +359,10 @@ class NPT(Common):
             M = None
             if return_trace is not None:
                 dt = np.float64 if return_trace == "float64" else np.int8
+                if M_touch is not None:
+                    M_touch.join()
                 if last is not None:                     # restart 0 is the one returned in the reference's shape:
-                    M = trace_layout(last[:R], slots_last[:R], R, dt)    # block r = the replica at temperature slot r
+                    M = trace_layout(last[:R], slots_last[:R], R, dt, out=M_buf)   # block r = the replica at temperature slot r
                 else:
                     M = np.zeros((R * N, S), dtype=dt)
             if self.num_swapping_pairs > 0 and rounds > 0:

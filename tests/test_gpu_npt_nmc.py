@@ -200,3 +200,32 @@ def test_min_energies_with_nmc_slots_match_the_reference(product):
     se = np.hypot(m_ref.std(ddof=1) / np.sqrt(len(m_ref)), m_us.std(ddof=1) / np.sqrt(n_restarts))
     z = (m_us.mean() - m_ref.mean()) / se
     assert abs(z) < 4.5, f"mean minimum: ours {m_us.mean():.2f} vs reference {m_ref.mean():.2f} ({z:.1f} sigma)"
+
+
+def test_npt_with_nmc_replicas_on_chimera128_against_the_known_ground_state(product):
+    """Known answer that ships with the reference (NMC/examples/Chimera_droplet_instances/chimera128_spinglass_power: instance 001
+    and the first line of groundstates_otn2d.txt).  The device-resident NPT with NMC_task on its two coldest slots (16 slots, 16
+    restarts, 2*10^4 sweeps) must end within 1 % of the listed ground-state energy and never below it; the plain ladder of the
+    same shape reads out the ground state itself (the NMC slots end every round on a short plain phase after heating their
+    backbone, so their read-out energies sit above a plain replica's -- in the reference too, stats_minenergy_pmj96_mixed)."""
+    import os
+    from conftest import GOLDEN
+    d = os.path.join(GOLDEN, "instances")
+    W, h = product.instances.txt_to_A_droplet(os.path.join(d, "chimera128__001.txt"))
+    tok = open(os.path.join(d, "chimera128__groundstate_001.txt")).read().split()
+    e_gs = float(tok[2])
+    J = -W                                                       # NMC/examples/chimera_example.py: J = -W, h = -h
+    hh = -np.asarray(h, dtype=np.float64).reshape(-1)
+    nf = abs(J).max()
+    R = 16
+    best = {}
+    for n_nmc in (2, 0):
+        obj = product.NPT(J, hh, rng="philox", seed=8)
+        with contextlib.redirect_stdout(io.StringIO()):
+            obj.run(np.geomspace(0.3, 20.0, R), R, [False] * (R - n_nmc) + [True] * n_nmc, num_sweeps_MCMC=20000,
+                    num_sweeps_read=20000, num_swap_attempts=400, num_swapping_pairs=R // 3, num_cycles=1, global_beta=10.0,
+                    temp_x=20, lambda_start=3.0, lambda_end=0.05, lambda_reduction_factor=0.8, num_restarts=16, return_trace=None)
+        best[n_nmc] = obj.restart_energies.min() * nf             # run() normalises by max|J| (NPT/npt.py:588-590)
+        assert best[n_nmc] >= e_gs - 1e-3, (n_nmc, best[n_nmc], e_gs)
+    assert best[2] <= e_gs * (1 - 0.01), (best, e_gs)
+    assert abs(best[0] - e_gs) < 1e-3, (best, e_gs)
