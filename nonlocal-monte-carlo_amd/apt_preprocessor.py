@@ -96,7 +96,8 @@ class APT_preprocessor(SweepMixin):
                 if numpy_mode:
                     o = eng.sweep_stream(perm, u, float(beta[-1]), want_energy=True)
                 else:
-                    o = eng.sweep_philox(S, self.seed, sweep0=self._sweep_counter, beta=float(beta[-1]), want_energy=True)
+                    # fused windows with the per-sweep energy trace where the instance qualifies (same bits as sweep by sweep)
+                    o = eng.sweep_philox_windows(S, self.seed, sweep0=self._sweep_counter, beta=float(beta[-1]), want_energy=True)
                     self._sweep_counter += S
                 Energy = o["energy"][:, S - num_sweeps_read:] if num_sweeps_read else np.zeros((R, 0))
                 saved_state[:, :] = eng.get_spins()

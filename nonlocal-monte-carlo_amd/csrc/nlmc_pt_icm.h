@@ -304,59 +304,58 @@ __global__ __launch_bounds__(1024) void k_icm_round(IcmRoundArgs a)
     }
     __syncthreads();
     const int nc = ncand;
-    bool converged = false;                // (workgroup-uniform)
-    for (int it = 0; it <= n; ++it) {
-        int changed = 0;
-        if (a.adj) {
-            // neighbour lists of the NEXT candidate of this thread are in flight while the current one is hooked (two 16-byte
-            // loads + the row bounds per candidate were a dependent global round trip each before)
-            int idx = tid, k = 0, rs = 0, deg = 0;
-            uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
-            if (idx < nc) { k = (int)cand[idx]; a0 = a.adj[2 * k]; a1 = a.adj[2 * k + 1]; rs = a.g.rowptr[k]; deg = a.g.rowptr[k + 1] - rs; }
-            while (idx < nc) {
-                const int idn = idx + nt;
-                int kn = 0, rsn = 0, degn = 0;
-                uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0;
-                if (idn < nc) { kn = (int)cand[idn]; b0 = a.adj[2 * kn]; b1 = a.adj[2 * kn + 1]; rsn = a.g.rowptr[kn]; degn = a.g.rowptr[kn + 1] - rsn; }
-                int rk = icm_find(lab, k);
-                auto hook = [&](int j) {
-                    if (j == k || lab[j] == INT_MAX) return;
-                    const int rj = icm_find(lab, j);
-                    if (rj < rk) { atomicMin(&lab[rk], rj); rk = rj; changed = 1; }
-                    else if (rk < rj) { atomicMin(&lab[rj], rk); changed = 1; }
-                };
-                const uint32_t aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    // ONE pass over the edges of the disagreement sub-graph (round 3; it was "hook, then repeat until nothing changes": ~5 rounds
+    // over all candidates).  Every edge (k, j) is merged to completion where it is met: find both roots, hook the LARGER root
+    // under the smaller one with a compare-and-swap that only succeeds while the larger one still IS a root, and on failure
+    // (somebody else hooked it first) look the roots up again -- the loop ends when both ends share a root, so no edge is ever
+    // left for a later round.  Roots only ever move to smaller indices: the final root of a component is its smallest member
+    // (the order find_disagreement_clusters lists the clusters in, NPT/apt_ICM.py:120-141).  Each edge is taken from its
+    // larger end only.
+    const bool converged = true;
+    auto merge = [&](int k, int j) {
+        if (j >= k || lab[j] == INT_MAX) return;           // (j == k: the padding of the adjacency table / the diagonal)
+        int ra = icm_find(lab, k), rb = icm_find(lab, j);
+        while (ra != rb) {
+            if (ra < rb) { const int t = ra; ra = rb; rb = t; }            // ra > rb
+            const int old = atomicCAS(&lab[ra], ra, rb);
+            if (old == ra) break;                                          // ra was a root and now hangs under rb
+            ra = icm_find(lab, old);
+            rb = icm_find(lab, rb);
+        }
+    };
+    if (a.adj) {
+        // neighbour lists of the NEXT candidate of this thread are in flight while the current one is merged
+        int idx = tid, k = 0, rs = 0, deg = 0;
+        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+        if (idx < nc) { k = (int)cand[idx]; a0 = a.adj[2 * k]; a1 = a.adj[2 * k + 1]; rs = a.g.rowptr[k]; deg = a.g.rowptr[k + 1] - rs; }
+        while (idx < nc) {
+            const int idn = idx + nt;
+            int kn = 0, rsn = 0, degn = 0;
+            uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0;
+            if (idn < nc) { kn = (int)cand[idn]; b0 = a.adj[2 * kn]; b1 = a.adj[2 * kn + 1]; rsn = a.g.rowptr[kn]; degn = a.g.rowptr[kn + 1] - rsn; }
+            const uint32_t aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-                for (int q = 0; q < NLMC_FZ_ADJ; ++q) hook((int)((aw[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu));
-                for (int e = rs + NLMC_FZ_ADJ; e < rs + deg; ++e) hook(a.g.col[e]);
-                idx = idn; k = kn; rs = rsn; deg = degn; a0 = b0; a1 = b1;
-            }
-        } else {
-            for (int idx = tid; idx < nc; idx += nt) {
-                const int k = (int)cand[idx];
-                int rk;
-                auto hook = [&](int j) {
-                    if (j == k || lab[j] == INT_MAX) return;
-                    const int rj = icm_find(lab, j);
-                    if (rj < rk) { atomicMin(&lab[rk], rj); rk = rj; changed = 1; }
-                    else if (rk < rj) { atomicMin(&lab[rj], rk); changed = 1; }
-                };
-                const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
-                EdgeQ ed[8];
+            for (int q = 0; q < NLMC_FZ_ADJ; ++q) merge(k, (int)((aw[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu));
+            for (int e = rs + NLMC_FZ_ADJ; e < rs + deg; ++e) merge(k, a.g.col[e]);
+            idx = idn; k = kn; rs = rsn; deg = degn; a0 = b0; a1 = b1;
+        }
+    } else {
+        for (int idx = tid; idx < nc; idx += nt) {
+            const int k = (int)cand[idx];
+            const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
+            EdgeQ ed[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) ed[q] = a.g.edge32[rs + q];
-                rk = icm_find(lab, k);
+            for (int q = 0; q < 8; ++q) ed[q] = a.g.edge32[rs + q];
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (q < deg && (ed[q].q != 0 || a.g.val64[rs + q] != 0.0)) hook(ed[q].col);
-                for (int e = rs + 8; e < rs + deg; ++e) {
-                    const EdgeQ t = a.g.edge32[e];
-                    if (t.q != 0 || a.g.val64[e] != 0.0) hook(t.col);
-                }
+            for (int q = 0; q < 8; ++q)
+                if (q < deg && (ed[q].q != 0 || a.g.val64[rs + q] != 0.0)) merge(k, ed[q].col);
+            for (int e = rs + 8; e < rs + deg; ++e) {
+                const EdgeQ t = a.g.edge32[e];
+                if (t.q != 0 || a.g.val64[e] != 0.0) merge(k, t.col);
             }
         }
-        if (!__syncthreads_or(changed)) { converged = true; break; }
     }
+    __syncthreads();
     // final labels (every candidate points at its root), number of components
     int cnt = 0;
     for (int idx = tid; idx < nc; idx += nt) {

@@ -457,3 +457,26 @@ def test_apt_icm_device_resident_read_out(product, k_read):
     assert M8.dtype == np.int8 and np.array_equal(M8, M) and np.array_equal(E8, E)
     _, Mn, En = go(None)
     assert Mn is None and np.array_equal(En, E)
+
+
+def test_apt_preprocessor_philox_mode_on_fused_windows(product, tmp_path, monkeypatch):
+    """APT_preprocessor(rng="philox"): all chains of a rung in one batched call on fused windows with the per-sweep energy trace;
+    the ladder it builds equals the one built sweep by sweep (same bits), is reproducible from the seed, and climbs."""
+    from helpers import make_instance
+    J, h = make_instance(400, seed=9, with_h=True)
+    monkeypatch.chdir(tmp_path)
+
+    def go(seed):
+        obj = product.APT_preprocessor(J.copy(), h.reshape(-1, 1).copy(), rng="philox", seed=seed)
+        with quiet():
+            return obj.run(num_sweeps_MCMC=60, num_sweeps_read=30, num_rng=12, beta_start=0.3, alpha=1.25, sigma_E_val=1000,
+                           beta_max=3.0, use_hash_table=0, num_cores=1)
+    b1, s1 = go(5)
+    b2, s2 = go(5)
+    assert b1 == b2 and s1 == s2 and len(b1) >= 4 and all(y > x for x, y in zip(b1, b1[1:]))
+    monkeypatch.setenv("NLMC_NO_FUSED", "1")
+    b3, s3 = go(5)
+    assert b3 == b1 and s3 == s1
+    monkeypatch.delenv("NLMC_NO_FUSED")
+    b4, _ = go(6)
+    assert b4 != b1
