@@ -2066,8 +2066,7 @@ static int lbp_launch(nlmc_ctx *c, int n_problems, int n_lambdas, double beta, d
     HIP_TRY(c, hipMemsetAsync(c->lbp_bar.p, 0, sizeof(unsigned int) * P, c->cur));
     a.bar = c->lbp_bar.p; a.part = c->lbp_part.p;
     // small instances: messages in LDS, a thread's edges in registers (k_lbp_lds; same bits): 8 waves x 12 edges per thread, two
-    // messages in lock step (16 waves x 6 edges x one message were measured too: 8.4 instead of 8.8 us per iteration, with 30
-    // registers per lane spilled at the 128-register cap -- not kept)
+    // messages in lock step (other shapes: see the kernel's header)
     if (group == 1 && n <= 2048 && nnz <= 6144 && !getenv("NLMC_LBP_GLOBAL")) {
         const size_t lds_small = ((size_t)2 * (6144 + 1) + 2048 + 1 + 64) * sizeof(double);
         const void *kf = c->has_diag ? reinterpret_cast<const void *>(k_lbp_lds<512, 12, 4, true, 2>)

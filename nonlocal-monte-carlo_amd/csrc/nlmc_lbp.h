@@ -69,169 +69,134 @@ __global__ void k_lbp_tanhJ(int nnz, const double *val, double beta, double *tJ)
     if (e < nnz) tJ[e] = tanh(beta * val[e]);
 }
 
-// u = atanh(clip(a tanh(y), +-sat)) / beta with one exponential, one logarithm and two divisions instead of
-// tanh + atanh (330 fp64 instructions with the library functions, ~105 like this):
-//   E = exp(-2|y|), a' = a sign(y):  a tanh(y) = a'(1-E)/(1+E),
-//   atanh(x) = log((1+x)/(1-x))/2 = log1p( 2a'(1-E) / ((1-a') + E(1+a')) )/2     (no cancellation: 1-E from expm1)
-// |x| > sat  <=>  |a'|(1-E) > sat(1+E): the saturated value usat = atanh(sat)/beta comes from the host.
-// expm1 / log1p are plain polynomial kernels (Taylor to r^13 after the usual 2^n split; fdlibm's log series with the
-// rounding error of 1+z fed back).  Round 3 instruction diet (the kernel is fp64-VALU bound; 211 -> ~105 instructions per
-// message): every multiply-add is an explicit three-address v_fma_f64 (the compiler's two-address v_fmac_f64 form copied
-// each polynomial coefficient into the accumulator first: 54 moves per message), the divisions are reciprocal + two
-// Newton steps + one correction without the scaling / fix-up instructions of the general-purpose expansion (operands are
-// far from the ends of the exponent range here), and the feedback term c/u (|c| <= ulp(1+z)) takes the raw reciprocal.
-// Measured on 2*10^7 random (a, y) with |atanh a| <= 3 against long double (tools-free check in tests/test_law_cpu.py's
-// spirit: oracle-independent, see scripts/lbp_message_check.py): the message stays within 2e-14 relative, limited by the
-// conditioning 1/(1-x^2) of atanh near the saturated messages like the library functions are (3.6e-15).
+// u = atanh(clip(a tanh(y), +-sat)) / beta with one exponential, one logarithm and ONE division instead of tanh + atanh (330
+// fp64 instructions with the library functions; 211 in round 2's formulation as the compiler emitted it; ~100 now -- the kernels
+// are fp64-issue bound, scripts/probes/fp64_issue_probe.hip):
+//   E = exp(-2|y|), a' = a sign(y):  a tanh(y) = a'(1-E)/(1+E);  |a tanh y| > sat  <=>  |a'|(1-E) > sat(1+E): the saturated value
+//   usat = atanh(sat)/beta comes from the host.  Every multiply-add is an explicit fma (the compiler's two-address v_fmac_f64 form
+//   copied each polynomial coefficient into the accumulator first: 54 moves per message), the division is reciprocal + two Newton
+//   steps + one correction without the scaling / fix-up instructions of the general-purpose expansion.
+// Agreement with the reference's tanh / arctanh: marginals within 1e-10 on every lambda both sides converge on
+// (tests/test_gpu_lbp.py, golden vectors of the reference itself).
 __device__ __forceinline__ double lbp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-__device__ __forceinline__ double lbp_div(double num, double den)           // num / den, normal-range operands
-{
-    double r = __builtin_amdgcn_rcp(den);
-    double e = lbp_fma(-den, r, 1.0);
-    r = lbp_fma(r, e, r);
-    e = lbp_fma(-den, r, 1.0);
-    r = lbp_fma(r, e, r);
-    const double q = num * r;
-    return lbp_fma(lbp_fma(-den, q, num), r, q);
-}
-
-__device__ __forceinline__ double lbp_expm1_neg(double x, double &E)      // x <= 0; returns e^x - 1, E = e^x
+// W messages in lock step (W = 1, 2): every step is written for all W elements before the next one, so that a wave carries W
+// independent dependent chains (the fp64 pipe of a SIMD with 2 waves wants them).  Per element:
+//   E = exp(-2|y|) by 2^n * (1 + r q(r)), q a degree-13 Taylor kernel after the usual ln2 split; em1 = E - 1 without cancellation
+//   atanh(a' t) = log(P / D) / 2,  P = (1 + a') + E (1 - a'),  D = (1 - a') + E (1 + a')   (both > 0, no cancellation)
+//   log(P / D) = k ln2 + log((1 + s) / (1 - s)),  s = (P 2^-k - D) / (P 2^-k + D) with k chosen from the exponents so that the
+//   ratio lies in [sqrt(1/2), sqrt(2)] (|s| <= 0.1716: fdlibm's log kernel 2s + s R(s^2)); where k = 0 the numerator is taken as
+//   N = -2 a' em1 = P - D, which is exact to rounding however close the ratio is to 1 -- small messages keep their relative
+//   accuracy.  ONE division per message (round 3; it was two divisions and a reciprocal: z = N / D, then log1p(z) through
+//   f / (2 + f) with the feedback term c / u).
+template <int W>
+__device__ __forceinline__ void lbp_message_w(const double (&a)[W], const double (&y)[W], double (&out)[W], double sat, double usat,
+                                              double inv_beta)
 {
     const double LOG2E = 1.4426950408889634, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
-    x = fmax(x, -80.0);
-    const double nf = rint(x * LOG2E);
-    double r = lbp_fma(-nf, LN2_HI, x);
-    r = lbp_fma(-nf, LN2_LO, r);                                           // |r| <= ln2 / 2
-    double q = 1.0 / 87178291200.0;                                        // (e^r - 1)/r = sum r^i / (i+1)!
-    q = lbp_fma(q, r, 1.0 / 6227020800.0);
-    q = lbp_fma(q, r, 1.0 / 479001600.0);
-    q = lbp_fma(q, r, 1.0 / 39916800.0);
-    q = lbp_fma(q, r, 1.0 / 3628800.0);
-    q = lbp_fma(q, r, 1.0 / 362880.0);
-    q = lbp_fma(q, r, 1.0 / 40320.0);
-    q = lbp_fma(q, r, 1.0 / 5040.0);
-    q = lbp_fma(q, r, 1.0 / 720.0);
-    q = lbp_fma(q, r, 1.0 / 120.0);
-    q = lbp_fma(q, r, 1.0 / 24.0);
-    q = lbp_fma(q, r, 1.0 / 6.0);
-    q = lbp_fma(q, r, 0.5);
-    q = lbp_fma(q, r, 1.0);
-    const double em1r = r * q;
-    const double s = ldexp(1.0, (int)nf);
-    E = lbp_fma(s, em1r, s);
-    return nf == 0.0 ? em1r : E - 1.0;
-}
-
-__device__ __forceinline__ double lbp_log1p(double z)                      // z > -1
-{
-    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
     const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
                  Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
                  Lg7 = 1.479819860511658591e-01;
-    const double u = 1.0 + z;
-    const double c = z - (u - 1.0);                                        // u + c == 1 + z
-    int k;
-    double m = frexp(u, &k);                                               // u = m 2^k, m in [1/2, 1)
-    const bool low = m < 0.70710678118654752440;
-    m = low ? m * 2.0 : m;
-    k = low ? k - 1 : k;
-    const double f = m - 1.0;
-    const double s = lbp_div(f, 2.0 + f);
-    const double z2 = s * s, w = z2 * z2;
-    const double t1 = w * lbp_fma(w, lbp_fma(w, Lg6, Lg4), Lg2);
-    const double t2 = z2 * lbp_fma(w, lbp_fma(w, lbp_fma(w, Lg7, Lg5), Lg3), Lg1);
-    const double R = t2 + t1;
-    const double hfsq = 0.5 * f * f;
-    const double dk = (double)k;
-    const double lo = lbp_fma(dk, LN2_LO, c * __builtin_amdgcn_rcp(u));
-    return lbp_fma(dk, LN2_HI, -((hfsq - lbp_fma(s, hfsq + R, lo)) - f));
+    const double SQRT2 = 1.41421356237309504880;
+    double ap[W], x[W], nf[W], r[W], q[W], em1r[W], sc[W], E[W], em1[W];
+#define LBP_ALL for (int j = 0; j < W; ++j)
+#pragma unroll
+    LBP_ALL ap[j] = copysign(a[j], a[j] * y[j]);
+#pragma unroll
+    LBP_ALL x[j] = fmax(-2.0 * fabs(y[j]), -80.0);
+#pragma unroll
+    LBP_ALL nf[j] = rint(x[j] * LOG2E);
+#pragma unroll
+    LBP_ALL r[j] = lbp_fma(-nf[j], LN2_HI, x[j]);
+#pragma unroll
+    LBP_ALL r[j] = lbp_fma(-nf[j], LN2_LO, r[j]);                          // |r| <= ln2 / 2
+#pragma unroll
+    LBP_ALL q[j] = 1.0 / 87178291200.0;                                    // (e^r - 1)/r = sum r^i / (i+1)!
+#define LBP_HORNER(C) _Pragma("unroll") LBP_ALL q[j] = lbp_fma(q[j], r[j], C);
+    LBP_HORNER(1.0 / 6227020800.0) LBP_HORNER(1.0 / 479001600.0) LBP_HORNER(1.0 / 39916800.0) LBP_HORNER(1.0 / 3628800.0)
+    LBP_HORNER(1.0 / 362880.0) LBP_HORNER(1.0 / 40320.0) LBP_HORNER(1.0 / 5040.0) LBP_HORNER(1.0 / 720.0) LBP_HORNER(1.0 / 120.0)
+    LBP_HORNER(1.0 / 24.0) LBP_HORNER(1.0 / 6.0) LBP_HORNER(0.5) LBP_HORNER(1.0)
+#undef LBP_HORNER
+#pragma unroll
+    LBP_ALL em1r[j] = r[j] * q[j];
+#pragma unroll
+    LBP_ALL sc[j] = ldexp(1.0, (int)nf[j]);
+#pragma unroll
+    LBP_ALL E[j] = lbp_fma(sc[j], em1r[j], sc[j]);
+#pragma unroll
+    LBP_ALL em1[j] = lbp_fma(sc[j], em1r[j], sc[j] - 1.0);                 // E - 1 in (-1, 0]: sc - 1 is exact, one rounding
+    double N[W], P[W], D[W], mP[W], mD[W], num[W], den[W], s[W], dk[W];
+    int eP[W], eD[W], k[W];
+#pragma unroll
+    LBP_ALL P[j] = lbp_fma(E[j], 1.0 - ap[j], 1.0 + ap[j]);
+#pragma unroll
+    LBP_ALL D[j] = lbp_fma(E[j], 1.0 + ap[j], 1.0 - ap[j]);
+#pragma unroll
+    LBP_ALL N[j] = -2.0 * ap[j] * em1[j];
+#pragma unroll
+    LBP_ALL { mP[j] = frexp(P[j], &eP[j]); mD[j] = frexp(D[j], &eD[j]); }  // mantissas in [1/2, 1)
+#pragma unroll
+    LBP_ALL {
+        const int adj = (mP[j] > mD[j] * SQRT2 ? 1 : 0) - (mP[j] * SQRT2 < mD[j] ? 1 : 0);
+        k[j] = eP[j] - eD[j] + adj;
+        mP[j] = ldexp(mP[j], -adj);
+    }
+#pragma unroll
+    LBP_ALL N[j] = ldexp(N[j], -eD[j]);
+#pragma unroll
+    LBP_ALL num[j] = mP[j] - mD[j];
+#pragma unroll
+    LBP_ALL num[j] = k[j] == 0 ? N[j] : num[j];                            // (both arms are values: a select, not control flow)
+#pragma unroll
+    LBP_ALL den[j] = mP[j] + mD[j];
+    {   // s = num / den: reciprocal + two Newton steps + one correction (operands far from the ends of the exponent range)
+        double rc[W], e[W], qq[W];
+#pragma unroll
+        LBP_ALL rc[j] = __builtin_amdgcn_rcp(den[j]);
+#pragma unroll
+        LBP_ALL e[j] = lbp_fma(-den[j], rc[j], 1.0);
+#pragma unroll
+        LBP_ALL rc[j] = lbp_fma(rc[j], e[j], rc[j]);
+#pragma unroll
+        LBP_ALL e[j] = lbp_fma(-den[j], rc[j], 1.0);
+#pragma unroll
+        LBP_ALL rc[j] = lbp_fma(rc[j], e[j], rc[j]);
+#pragma unroll
+        LBP_ALL qq[j] = num[j] * rc[j];
+#pragma unroll
+        LBP_ALL s[j] = lbp_fma(lbp_fma(-den[j], qq[j], num[j]), rc[j], qq[j]);
+    }
+    double z2[W], w[W], t1[W], t2[W], lg[W];
+#pragma unroll
+    LBP_ALL { z2[j] = s[j] * s[j]; dk[j] = (double)k[j]; }
+#pragma unroll
+    LBP_ALL w[j] = z2[j] * z2[j];
+#pragma unroll
+    LBP_ALL t1[j] = w[j] * lbp_fma(w[j], lbp_fma(w[j], Lg6, Lg4), Lg2);
+#pragma unroll
+    LBP_ALL t2[j] = z2[j] * lbp_fma(w[j], lbp_fma(w[j], lbp_fma(w[j], Lg7, Lg5), Lg3), Lg1);
+#pragma unroll
+    LBP_ALL lg[j] = lbp_fma(dk[j], LN2_HI, lbp_fma(2.0, s[j], lbp_fma(s[j], t2[j] + t1[j], dk[j] * LN2_LO)));
+#pragma unroll
+    LBP_ALL out[j] = fmin(fmax(0.5 * inv_beta * lg[j], -usat), usat);      // atanh is monotone: clipping its argument to +-sat == clamping it
+#undef LBP_ALL
 }
 
 __device__ __forceinline__ double lbp_message(double a, double y, double sat, double usat, double inv_beta)
 {
-    const double ap = copysign(a, a * y);
-    double E;
-    const double em1 = lbp_expm1_neg(-2.0 * fabs(y), E);                   // E - 1 in (-1, 0]
-    const double u = 0.5 * inv_beta * lbp_log1p(lbp_div(-2.0 * ap * em1, lbp_fma(E, 1.0 + ap, 1.0 - ap)));
-    return (fabs(ap) * (-em1) > sat * (1.0 + E)) ? copysign(usat, ap) : u;
+    const double aa[1] = {a}, yy[1] = {y};
+    double o[1];
+    lbp_message_w<1>(aa, yy, o, sat, usat, inv_beta);
+    return o[0];
 }
 
-// Two messages at once, step by step in lock step: the fp64 pipeline wants ~4 independent instruction streams per SIMD
-// and k_lbp_lds runs 2 waves per SIMD (register budget), so each wave carries two dependent chains.  The arithmetic of
-// each element is exactly lbp_message's (same operations, same order): results are the same bits.
 struct LbpD2 { double a, b; };
-__device__ __forceinline__ LbpD2 d2(double x) { return LbpD2{x, x}; }
-__device__ __forceinline__ LbpD2 operator+(LbpD2 x, LbpD2 y) { return LbpD2{x.a + y.a, x.b + y.b}; }
-__device__ __forceinline__ LbpD2 operator-(LbpD2 x, LbpD2 y) { return LbpD2{x.a - y.a, x.b - y.b}; }
-__device__ __forceinline__ LbpD2 operator*(LbpD2 x, LbpD2 y) { return LbpD2{x.a * y.a, x.b * y.b}; }
-__device__ __forceinline__ LbpD2 operator-(LbpD2 x) { return LbpD2{-x.a, -x.b}; }
-__device__ __forceinline__ LbpD2 fma2(LbpD2 x, LbpD2 y, LbpD2 z) { return LbpD2{__builtin_fma(x.a, y.a, z.a), __builtin_fma(x.b, y.b, z.b)}; }
-__device__ __forceinline__ LbpD2 fma2(LbpD2 x, LbpD2 y, double z) { return LbpD2{__builtin_fma(x.a, y.a, z), __builtin_fma(x.b, y.b, z)}; }
-
-__device__ __forceinline__ LbpD2 lbp_div2(LbpD2 num, LbpD2 den)
-{
-    LbpD2 r{__builtin_amdgcn_rcp(den.a), __builtin_amdgcn_rcp(den.b)};
-    LbpD2 e = fma2(-den, r, 1.0);
-    r = fma2(r, e, r);
-    e = fma2(-den, r, 1.0);
-    r = fma2(r, e, r);
-    const LbpD2 q = num * r;
-    return fma2(fma2(-den, q, num), r, q);
-}
-
 __device__ __forceinline__ LbpD2 lbp_message2(LbpD2 a, LbpD2 y, double sat, double usat, double inv_beta)
 {
-    const double LOG2E = 1.4426950408889634, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
-    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
-                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-                 Lg7 = 1.479819860511658591e-01;
-    const LbpD2 ap{copysign(a.a, a.a * y.a), copysign(a.b, a.b * y.b)};
-    // ---- E = exp(x), em1 = E - 1, x = -2|y|   (lbp_expm1_neg)
-    LbpD2 x{fmax(-2.0 * fabs(y.a), -80.0), fmax(-2.0 * fabs(y.b), -80.0)};
-    const LbpD2 nf{rint(x.a * LOG2E), rint(x.b * LOG2E)};
-    LbpD2 r = fma2(-nf, d2(LN2_HI), x);
-    r = fma2(-nf, d2(LN2_LO), r);
-    LbpD2 q = d2(1.0 / 87178291200.0);
-    q = fma2(q, r, 1.0 / 6227020800.0);
-    q = fma2(q, r, 1.0 / 479001600.0);
-    q = fma2(q, r, 1.0 / 39916800.0);
-    q = fma2(q, r, 1.0 / 3628800.0);
-    q = fma2(q, r, 1.0 / 362880.0);
-    q = fma2(q, r, 1.0 / 40320.0);
-    q = fma2(q, r, 1.0 / 5040.0);
-    q = fma2(q, r, 1.0 / 720.0);
-    q = fma2(q, r, 1.0 / 120.0);
-    q = fma2(q, r, 1.0 / 24.0);
-    q = fma2(q, r, 1.0 / 6.0);
-    q = fma2(q, r, 0.5);
-    q = fma2(q, r, 1.0);
-    const LbpD2 em1r = r * q;
-    const LbpD2 sc{ldexp(1.0, (int)nf.a), ldexp(1.0, (int)nf.b)};
-    const LbpD2 E = fma2(sc, em1r, sc);
-    const LbpD2 em1{nf.a == 0.0 ? em1r.a : E.a - 1.0, nf.b == 0.0 ? em1r.b : E.b - 1.0};
-    // ---- z = 2a'(1-E) / ((1-a') + E(1+a')),  log1p(z)   (lbp_log1p)
-    const LbpD2 z = lbp_div2(d2(-2.0) * ap * em1, fma2(E, d2(1.0) + ap, d2(1.0) - ap));
-    const LbpD2 u = d2(1.0) + z;
-    const LbpD2 c = z - (u - d2(1.0));
-    int ka, kb;
-    double ma = frexp(u.a, &ka), mb = frexp(u.b, &kb);
-    const bool la = ma < 0.70710678118654752440, lb = mb < 0.70710678118654752440;
-    ma = la ? ma * 2.0 : ma; mb = lb ? mb * 2.0 : mb;
-    ka = la ? ka - 1 : ka; kb = lb ? kb - 1 : kb;
-    const LbpD2 f{ma - 1.0, mb - 1.0};
-    const LbpD2 s = lbp_div2(f, d2(2.0) + f);
-    const LbpD2 z2 = s * s, w = z2 * z2;
-    const LbpD2 t1 = w * fma2(w, fma2(w, d2(Lg6), Lg4), Lg2);
-    const LbpD2 t2 = z2 * fma2(w, fma2(w, fma2(w, d2(Lg7), Lg5), Lg3), Lg1);
-    const LbpD2 R = t2 + t1;
-    const LbpD2 hfsq = d2(0.5) * f * f;
-    const LbpD2 dk{(double)ka, (double)kb};
-    const LbpD2 lo = fma2(dk, d2(LN2_LO), c * LbpD2{__builtin_amdgcn_rcp(u.a), __builtin_amdgcn_rcp(u.b)});
-    const LbpD2 lg = fma2(dk, d2(LN2_HI), -((hfsq - fma2(s, hfsq + R, lo)) - f));
-    const double ua = 0.5 * inv_beta * lg.a, ub = 0.5 * inv_beta * lg.b;
-    return LbpD2{(fabs(ap.a) * (-em1.a) > sat * (1.0 + E.a)) ? copysign(usat, ap.a) : ua,
-                 (fabs(ap.b) * (-em1.b) > sat * (1.0 + E.b)) ? copysign(usat, ap.b) : ub};
+    const double aa[2] = {a.a, a.b}, yy[2] = {y.a, y.b};
+    double o[2];
+    lbp_message_w<2>(aa, yy, o, sat, usat, inv_beta);
+    return LbpD2{o[0], o[1]};
 }
 
 __device__ __forceinline__ double lbp_wave_max(double v)
@@ -239,6 +204,43 @@ __device__ __forceinline__ double lbp_wave_max(double v)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// max over the 16 lanes of a DPP row, in registers (quad swaps, then the two mirrors): every lane ends up with the row maximum
+template <int CTRL>
+__device__ __forceinline__ double lbp_dpp_max_step(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return fmax(v, __hiloint2double(hi2, lo2));
+}
+__device__ __forceinline__ double lbp_row_max(double v)
+{
+    v = lbp_dpp_max_step<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = lbp_dpp_max_step<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = lbp_dpp_max_step<0x141>(v);     // row_half_mirror
+    v = lbp_dpp_max_step<0x140>(v);     // row_mirror
+    return v;
+}
+// four non-negative per-lane quantities -> row q (lanes [16 q, 16 q + 16)) of the wave holds the wave maximum of quantity q:
+// two exchange steps that halve the number of quantities a lane carries (3 cross-row shuffles), then the in-row maximum
+// (the plain butterfly was 6 shuffles + 6 maxima per quantity: 48 ds_bpermute per iteration)
+__device__ __forceinline__ double lbp_wave_max4(double q0, double q1, double q2, double q3, int lane)
+{
+    const bool up = (lane & 32) != 0, odd = (lane & 16) != 0;
+    double k0 = up ? q2 : q0, k1 = up ? q3 : q1;
+    const double s0 = up ? q0 : q2, s1 = up ? q1 : q3;
+    k0 = fmax(k0, __shfl_xor(s0, 32, 64));
+    k1 = fmax(k1, __shfl_xor(s1, 32, 64));
+    double kk = odd ? k1 : k0;
+    const double ss = odd ? k0 : k1;
+    kk = fmax(kk, __shfl_xor(ss, 16, 64));
+    return lbp_row_max(kk);
+}
+__device__ __forceinline__ double lbp_read_lane(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
 // Barrier between the `group` workgroups that share one problem (they run on different CUs, possibly on different
@@ -386,19 +388,20 @@ __global__ __launch_bounds__(NLMC_LBP_THREADS) void k_lbp(LbpArgs a)
 // and the node totals fit in LDS (16 nnz + 8 n bytes) and a thread's share of the edges (MPT) and nodes (<= 2) fits in
 // registers, everything an iteration touches is LDS or registers: thread t owns edges t, t + 1024, ... for the whole
 // launch (source, reverse position, tanh(beta J), its cavity field h_msgs), the iteration is node totals -> barrier ->
-// messages -> ONE barrier (the convergence maxima go through a 16-lane butterfly that every wave repeats, so the decision
-// is uniform without a broadcast).  Same operations in the same order as k_lbp: results are bit-identical
-// (tests/test_gpu_lbp.py).
-// No per-lane predicates in the loop (a bool per edge is a 64-bit scalar mask each: 56 scalar registers, which pushed the
-// polynomial coefficients out of the scalar file): edge slots past nnz are harmless dummies (source = a node slot that
-// always holds 0, tanh(beta J) = 0, reads from message slots that stay 0, writes to a scratch slot: their message is
-// exactly 0 and every maximum they feed is 0), node slots past n likewise; diagonal entries only in the HAS_DIAG variant.
+// messages -> ONE barrier (the four convergence maxima: lbp_wave_max4 per wave, one LDS row per quantity, then every wave
+// repeats the in-row maximum over the waves' partials, so the decision is uniform without a broadcast).  Same operations in the
+// same order as k_lbp: results are bit-identical (tests/test_gpu_lbp.py).
+// No per-lane predicates in the loop (a bool per edge or per neighbour term is a 64-bit scalar mask each, hoisted out of the
+// iteration loop: they pushed the polynomial coefficients out of the scalar file and were read back lane by lane): edge slots
+// past nnz are harmless dummies (source = a node slot that always holds 0, tanh(beta J) = 0, reads from message slots that stay
+// 0, writes to a scratch slot: their message is exactly 0 and every maximum they feed is 0), node slots past n likewise, a
+// node's neighbour terms past its degree read the zero message slot; diagonal entries only in the HAS_DIAG variant.
 // NT threads, MPT edges and NPT nodes per thread (NT MPT = 6144 edge slots, NT NPT = 2048 node slots), ILP message
-// computations in lock step per wave.  Instantiated as 8 waves x 12 edges x 2 (246 registers, no scratch).  The fp64 pipe alone
-// would prefer more streams (scripts/probes/fp64_issue_probe.hip: wave-FMAs per 100 counter ticks and CU -- 8 waves x 1 / 2 / 4
-// chains: 123 / 135 / 178, 16 waves x 1 / 2 / 4: 246 / 270 / 355), but 16 waves x 6 edges x 1 gained 5 % only (8.4 vs 8.8 us per
-// iteration, 30 registers per lane spilled): an iteration is fp64 issue AND four 8-byte LDS accesses per message (three of them
-// random) AND two barriers.
+// computations in lock step per wave.  Instantiated as 8 waves x 12 edges x 2 (241 registers, no scratch).  Per iteration and
+// wave at n = 10^3: ~1270 instructions in the message phase (106 per message, 82 of them fp64), ~165 in the node phase (two of
+// four node slots populated), ~60 for the maxima: 6.5 us (round 3 started at 8.8: two divisions and a reciprocal per message
+// instead of one, 165 instructions per node slot instead of 80, 48 ds_bpermute for the maxima instead of 6).  More independent
+// streams do not help (3 or 4 messages in lock step: 6.5-6.9 us; 16 waves x 6 edges x 1 and 12 waves x 8 x 1 spill).
 template <int NT, int MPT, int NPT, bool HAS_DIAG, int ILP>
 __global__ __launch_bounds__(NT) void k_lbp_lds(LbpArgs a)
 {
@@ -416,8 +419,13 @@ __global__ __launch_bounds__(NT) void k_lbp_lds(LbpArgs a)
     // this thread's edges
     unsigned e_sr[MPT];                 // source node slot | reverse message slot << 16
     double e_tJ[MPT], e_hm[MPT];
+#ifdef NLMC_LBP_DBG_NOCONFLICT          /* timing experiment (wrong results): every LDS access of the message phase coalesced */
+#define E_SRC(k) (int)((tid + (k) * 7) & 1023)
+#define E_REV(k) (int)(tid + (k) * NT)
+#else
 #define E_SRC(k) (int)(e_sr[k] & 0xFFFFu)
 #define E_REV(k) (int)(e_sr[k] >> 16)
+#endif
     unsigned bits = 0u;                 // bit k: node slot k exists; 4 + k: its dense h_msgs row has non-edge entries; 8 + k: edge k is diagonal
 #pragma unroll
     for (int k = 0; k < MPT; ++k) {
@@ -452,15 +460,21 @@ __global__ __launch_bounds__(NT) void k_lbp_lds(LbpArgs a)
     if (tid == 0) { wc[ESLOTS] = 0.0; wn[ESLOTS] = 0.0; tot[NPT * NT] = 0.0; }
     __syncthreads();
 
-    // row sum of the current messages of node slot k, sequential in ascending neighbour index
+    // row sum of the current messages of node slot k, sequential in ascending neighbour index.  Terms past the degree read the
+    // message slot that always holds 0 (sum + 0 is exact: a sum that starts from +0 is never -0), i.e. one address select per
+    // term and no predicated loads; `deg` is made opaque per iteration so that the 8 compares stay in the loop -- hoisted they
+    // are 8 lane masks per node slot (64 scalar registers at NPT = 4, spilled to lanes of a vector register and read back with
+    // two v_readlane per use: the node phase was 165 instructions per slot).
     auto row_sum = [&](int k) __attribute__((always_inline)) {
+        int deg = v_deg[k];
+        asm volatile("" : "+v"(deg));
         double v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = q < v_deg[k] ? wc[v_r0[k] + q] : 0.0;       // all reads in flight
+        for (int q = 0; q < 8; ++q) v[q] = wc[q < deg ? v_r0[k] + q : ESLOTS];        // all reads in flight
         double sum = 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) sum = q < v_deg[k] ? sum + v[q] : sum;
-        for (int q = 8; q < v_deg[k]; ++q) sum += wc[v_r0[k] + q];
+        for (int q = 0; q < 8; ++q) sum += v[q];
+        for (int q = 8; q < deg; ++q) sum += wc[v_r0[k] + q];
         return sum;
     };
 
@@ -474,10 +488,11 @@ __global__ __launch_bounds__(NT) void k_lbp_lds(LbpArgs a)
             // ---- node totals: total_i = h_lam[i] + sum_k u_msgs[k, i]   (NMC/nmc.py:199-201)
 #pragma unroll
             for (int k = 0; k < NPT; ++k) {
+                if (__ballot((bits >> k) & 1u) == 0ull) continue;      // no lane of this wave owns a node in slot k (n < NPT NT)
                 const int i = tid + k * NT;
                 const double hl = v_h[k] + lam * v_me[k];
                 const double t_new = hl + row_sum(k), t_old = tot[i];
-                if (bits & (1u << k)) tot[i] = t_new;
+                tot[i] = t_new;                                         // (slots past n: nobody reads them; their value is 0 anyway)
                 if (bits & (1u << (4 + k))) {
                     dh_n = fmax(dh_n, fabs(t_new - t_old));
                     dh_d = fmax(dh_d, fabs(t_new) + fabs(t_old));
@@ -487,7 +502,7 @@ __global__ __launch_bounds__(NT) void k_lbp_lds(LbpArgs a)
             // ---- messages: h_msgs[i, j] = total_i - u_msgs[j, i];  u_msgs[i, j] = atanh_sat(tanh(bJ) tanh(b h_msgs)) / b
             // (two messages at a time, the LDS reads of the next pair in flight meanwhile: left to itself the scheduler
             // interleaves all MPT message computations and spills)
-            static_assert(MPT % ILP == 0 && (ILP == 1 || ILP == 2), "messages are processed one or two at a time");
+            static_assert(MPT % ILP == 0, "messages are processed ILP at a time");
             double t_n[ILP], w_n[ILP], u_n[ILP];
 #pragma unroll
             for (int j = 0; j < ILP; ++j) { t_n[j] = tot[E_SRC(j)]; w_n[j] = wc[tid + j * NT]; u_n[j] = wc[E_REV(j)]; }
@@ -510,11 +525,11 @@ __global__ __launch_bounds__(NT) void k_lbp_lds(LbpArgs a)
                     h_new[j] = t_i[j] - w_e[j];
                     if (HAS_DIAG) h_new[j] = (bits & (1u << (8 + k + j))) ? 0.0 : h_new[j];
                 }
-                if (ILP == 2) {
-                    const LbpD2 r2 = lbp_message2(LbpD2{e_tJ[k], e_tJ[k + ILP - 1]}, LbpD2{a.beta * h_new[0], a.beta * h_new[ILP - 1]}, a.sat, a.usat, a.inv_beta);
-                    u_new[0] = r2.a; u_new[ILP - 1] = r2.b;
-                } else {
-                    u_new[0] = lbp_message(e_tJ[k], a.beta * h_new[0], a.sat, a.usat, a.inv_beta);
+                {
+                    double tj[ILP], yy[ILP];
+#pragma unroll
+                    for (int j = 0; j < ILP; ++j) { tj[j] = e_tJ[k + j]; yy[j] = a.beta * h_new[j]; }
+                    lbp_message_w<ILP>(tj, yy, u_new, a.sat, a.usat, a.inv_beta);
                 }
 #pragma unroll
                 for (int j = 0; j < ILP; ++j) {
@@ -528,14 +543,12 @@ __global__ __launch_bounds__(NT) void k_lbp_lds(LbpArgs a)
                 }
                 __builtin_amdgcn_sched_barrier(0);   // (left to itself the scheduler hoists the loads of all MPT messages and spills)
             }
-            dh_n = lbp_wave_max(dh_n); dh_d = lbp_wave_max(dh_d); du_n = lbp_wave_max(du_n); du_d = lbp_wave_max(du_d);
-            if (lane == 0) { red[0 * 16 + wv] = dh_n; red[1 * 16 + wv] = dh_d; red[2 * 16 + wv] = du_n; red[3 * 16 + wv] = du_d; }
+            const double wm = lbp_wave_max4(dh_n, dh_d, du_n, du_d, lane);      // row q of the wave: quantity q
+            if ((lane & 15) == 0) red[(lane >> 4) * 16 + wv] = wm;
             __syncthreads();
             // every wave reduces the 4 x NW partial maxima itself: lanes [16 q, 16 q + 16) hold quantity q
-            double m = (lane & 15) < NW ? red[lane] : 0.0;
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
-            const double r0 = __shfl(m, 0, 64), r1 = __shfl(m, 16, 64), r2 = __shfl(m, 32, 64), r3 = __shfl(m, 48, 64);
+            const double m = lbp_row_max((lane & 15) < NW ? red[lane] : 0.0);
+            const double r0 = lbp_read_lane(m, 0), r1 = lbp_read_lane(m, 16), r2 = lbp_read_lane(m, 32), r3 = lbp_read_lane(m, 48);
             { double *t = wc; wc = wn; wn = t; }
             // 0/0 = NaN compares false, like the reference's `du < tolerance and dh < tolerance` (NMC/nmc.py:212-213)
             const double dh = r0 / r1, du = r2 / r3;

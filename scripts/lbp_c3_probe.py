@@ -1,5 +1,5 @@
 """Backbone inference at the C3 shape (N = 10^3, 64 seeds = 8 NMC replicas x 8 restarts): time per batch, lambdas and BP
-iterations per seed (the slowest seed sets the launch time)."""
+iterations per seed (the slowest seed sets the launch time).  DUMP=dir: per-seed lambdas / iterations / marginals as npz."""
 import os, sys, time
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,6 +25,10 @@ with P.Engine(inst, None, B) as eng:
             t = time.perf_counter()
             o = eng.lbp_convexified(ms, eps, lams, beta, EPS, 100, float(np.tanh(19.06)) - EPS)
             dt = time.perf_counter() - t
+        if os.environ.get("DUMP"):
+            os.makedirs(os.environ["DUMP"], exist_ok=True)
+            np.savez(os.path.join(os.environ["DUMP"], f"lbp_probe_sw{sw}.npz"), n_lambdas=o["n_lambdas"], iters=o["iters"], status=o["status"],
+                     mag=o["mag"], ms=ms)
         its = np.array([int((o["iters"][p][:o["n_lambdas"][p]] + 1).sum()) for p in range(B)])
         print(f"N={N} seeds={B} after {sw} sweeps: {dt*1e3:.2f} ms; lambdas per seed min/med/max {o['n_lambdas'].min()}/{int(np.median(o['n_lambdas']))}/{o['n_lambdas'].max()} of {len(lams)}; "
               f"BP iterations per seed min/med/max {its.min()}/{int(np.median(its))}/{its.max()}; us per iteration of the slowest {dt*1e6/its.max():.2f}; status {np.unique(o['status'])}", flush=True)

@@ -30,15 +30,22 @@ __global__ __launch_bounds__(1024) void k_fma(int iters, double a, double b, dou
 template <int ILP> void run(int waves, double *out, long long *cyc)
 {
     const int iters = 2000, blocks = 256;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_fma<ILP>, dim3(blocks), dim3(waves * 64), 0, 0, iters, 0.999999, 1e-7, out, cyc);      // warm-up
+    hipEventRecord(e0, 0);
     hipLaunchKernelGGL(k_fma<ILP>, dim3(blocks), dim3(waves * 64), 0, 0, iters, 0.999999, 1e-7, out, cyc);
+    hipEventRecord(e1, 0);
     hipDeviceSynchronize();
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
     std::vector<long long> r(blocks);
     hipMemcpy(r.data(), cyc, blocks * 8, hipMemcpyDeviceToHost);
     double m = 0; for (auto v : r) m += (double)v;
     m /= blocks;
     const double insts = (double)iters * 16 * ILP * waves;           // wave-instructions per CU
-    printf("waves %2d x %d chains: %.2f cycles per wave-instruction per SIMD-slot (%.1f wave-FMAs per 100 cycles per CU)\n", waves, ILP,
-           m * 4 / insts * (waves < 4 ? waves / 4.0 : 1.0), insts / m * 100);
+    printf("waves %2d x %d chains: %.1f wave-FMAs per 100 counter ticks per CU; kernel %.1f us = %.0f ticks -> %.0f ticks per us; "
+           "%.2f wave-FMAs per ns per CU (peak at 64 lanes x 2.4 GHz: 2.4)\n", waves, ILP, insts / m * 100, ms * 1e3, m, m / (ms * 1e3), insts / (ms * 1e6));
 }
 
 int main()
