@@ -69,13 +69,12 @@ __global__ void k_lbp_tanhJ(int nnz, const double *val, double beta, double *tJ)
     if (e < nnz) tJ[e] = tanh(beta * val[e]);
 }
 
-// u = atanh(clip(a tanh(y), +-sat)) / beta with one exponential, one logarithm and ONE division instead of tanh + atanh (330
-// fp64 instructions with the library functions; 211 in round 2's formulation as the compiler emitted it; ~100 now -- the kernels
+// u = atanh(clip(a tanh(y), +-sat)) / beta with one exponential, one logarithm and two divisions instead of tanh + atanh (330
+// fp64 instructions with the library functions; 211 in round 2's formulation as the compiler emitted it; ~95 now -- the kernels
 // are fp64-issue bound, scripts/probes/fp64_issue_probe.hip):
-//   E = exp(-2|y|), a' = a sign(y):  a tanh(y) = a'(1-E)/(1+E);  |a tanh y| > sat  <=>  |a'|(1-E) > sat(1+E): the saturated value
-//   usat = atanh(sat)/beta comes from the host.  Every multiply-add is an explicit fma (the compiler's two-address v_fmac_f64 form
-//   copied each polynomial coefficient into the accumulator first: 54 moves per message), the division is reciprocal + two Newton
-//   steps + one correction without the scaling / fix-up instructions of the general-purpose expansion.
+//   every multiply-add is an explicit fma (the compiler's two-address v_fmac_f64 form copied each polynomial coefficient into
+//   the accumulator first: 54 moves per message), a division is reciprocal + two Newton steps + one correction without the
+//   scaling / fix-up instructions of the general-purpose expansion; the saturated value usat = atanh(sat)/beta comes from the host.
 // Agreement with the reference's tanh / arctanh: marginals within 1e-10 on every lambda both sides converge on
 // (tests/test_gpu_lbp.py, golden vectors of the reference itself).
 __device__ __forceinline__ double lbp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -83,12 +82,21 @@ __device__ __forceinline__ double lbp_fma(double a, double b, double c) { return
 // W messages in lock step (W = 1, 2): every step is written for all W elements before the next one, so that a wave carries W
 // independent dependent chains (the fp64 pipe of a SIMD with 2 waves wants them).  Per element:
 //   E = exp(-2|y|) by 2^n * (1 + r q(r)), q a degree-13 Taylor kernel after the usual ln2 split; em1 = E - 1 without cancellation
-//   atanh(a' t) = log(P / D) / 2,  P = (1 + a') + E (1 - a'),  D = (1 - a') + E (1 + a')   (both > 0, no cancellation)
+//   t = tanh(|y|) = -em1 / (1 + E),  x = clip(a sign(y) t, +-sat): both rounded to double, as in the reference
+//   atanh(x) = log(P / D) / 2,  P = 1 + x,  D = 1 - x  (D is exact for |x| >= 1/2)
 //   log(P / D) = k ln2 + log((1 + s) / (1 - s)),  s = (P 2^-k - D) / (P 2^-k + D) with k chosen from the exponents so that the
 //   ratio lies in [sqrt(1/2), sqrt(2)] (|s| <= 0.1716: fdlibm's log kernel 2s + s R(s^2)); where k = 0 the numerator is taken as
-//   N = -2 a' em1 = P - D, which is exact to rounding however close the ratio is to 1 -- small messages keep their relative
-//   accuracy.  ONE division per message (round 3; it was two divisions and a reciprocal: z = N / D, then log1p(z) through
-//   f / (2 + f) with the feedback term c / u).
+//   2x = P - D exactly -- small messages keep their relative accuracy.
+// Two divisions per message (round 2: two divisions and a reciprocal).
+// WHY x IS ROUNDED.  An algebraically equivalent form without the intermediate x -- P = (1 + a') + E (1 - a'), D = (1 - a') +
+// E (1 + a'), one division, 9 instructions fewer -- was built first and is MORE accurate than the reference near |x| -> 1, where
+// arctanh amplifies the rounding of x by x / ((1 - x^2) atanh x).  That matters: the reference iterates to a relative change
+// below MACHINE EPSILON and ends the lambda continuation at the first lambda that does not get there in max_iterations, i.e.
+// where its own rounding noise stops the messages from becoming bit-stable.  On 16 seeds of the C3 shape (N = 10^3, beta =
+// lambda_start = 3, chains after 10^3 sweeps) the NumPy restatement converges on 33.3 lambdas on average, the no-intermediate
+// form on 36.1 (+2.8: it reaches bit-stable fixed points NumPy does not, and hands marginals of a weaker bias to the cluster
+// search), this form on 32.9 (-0.4; per seed both differ from NumPy by ~3 lambdas either way -- the last bit decides).  The
+// product keeps the reference's roundings.
 template <int W>
 __device__ __forceinline__ void lbp_message_w(const double (&a)[W], const double (&y)[W], double (&out)[W], double sat, double usat,
                                               double inv_beta)
@@ -127,12 +135,31 @@ __device__ __forceinline__ void lbp_message_w(const double (&a)[W], const double
     LBP_ALL em1[j] = lbp_fma(sc[j], em1r[j], sc[j] - 1.0);                 // E - 1 in (-1, 0]: sc - 1 is exact, one rounding
     double N[W], P[W], D[W], mP[W], mD[W], num[W], den[W], s[W], dk[W];
     int eP[W], eD[W], k[W];
+    // t = tanh(|y|) = (1 - E) / (1 + E) and x = a' t as DOUBLES, like the reference's intermediates (see above)
+    double t[W], xx[W];
+    {
+        double dn[W], rc[W], e[W], qq[W], nm[W];
 #pragma unroll
-    LBP_ALL P[j] = lbp_fma(E[j], 1.0 - ap[j], 1.0 + ap[j]);
+        LBP_ALL { dn[j] = 1.0 + E[j]; nm[j] = -em1[j]; }
 #pragma unroll
-    LBP_ALL D[j] = lbp_fma(E[j], 1.0 + ap[j], 1.0 - ap[j]);
+        LBP_ALL rc[j] = __builtin_amdgcn_rcp(dn[j]);
 #pragma unroll
-    LBP_ALL N[j] = -2.0 * ap[j] * em1[j];
+        LBP_ALL e[j] = lbp_fma(-dn[j], rc[j], 1.0);
+#pragma unroll
+        LBP_ALL rc[j] = lbp_fma(rc[j], e[j], rc[j]);
+#pragma unroll
+        LBP_ALL e[j] = lbp_fma(-dn[j], rc[j], 1.0);
+#pragma unroll
+        LBP_ALL rc[j] = lbp_fma(rc[j], e[j], rc[j]);
+#pragma unroll
+        LBP_ALL qq[j] = nm[j] * rc[j];
+#pragma unroll
+        LBP_ALL t[j] = lbp_fma(lbp_fma(-dn[j], qq[j], nm[j]), rc[j], qq[j]);
+    }
+#pragma unroll
+    LBP_ALL xx[j] = fmin(fmax(ap[j] * t[j], -sat), sat);
+#pragma unroll
+    LBP_ALL { P[j] = 1.0 + xx[j]; D[j] = 1.0 - xx[j]; N[j] = xx[j] + xx[j]; }
 #pragma unroll
     LBP_ALL { mP[j] = frexp(P[j], &eP[j]); mD[j] = frexp(D[j], &eD[j]); }  // mantissas in [1/2, 1)
 #pragma unroll
@@ -188,15 +215,6 @@ __device__ __forceinline__ double lbp_message(double a, double y, double sat, do
     double o[1];
     lbp_message_w<1>(aa, yy, o, sat, usat, inv_beta);
     return o[0];
-}
-
-struct LbpD2 { double a, b; };
-__device__ __forceinline__ LbpD2 lbp_message2(LbpD2 a, LbpD2 y, double sat, double usat, double inv_beta)
-{
-    const double aa[2] = {a.a, a.b}, yy[2] = {y.a, y.b};
-    double o[2];
-    lbp_message_w<2>(aa, yy, o, sat, usat, inv_beta);
-    return LbpD2{o[0], o[1]};
 }
 
 __device__ __forceinline__ double lbp_wave_max(double v)
@@ -397,10 +415,10 @@ __global__ __launch_bounds__(NLMC_LBP_THREADS) void k_lbp(LbpArgs a)
 // 0, writes to a scratch slot: their message is exactly 0 and every maximum they feed is 0), node slots past n likewise, a
 // node's neighbour terms past its degree read the zero message slot; diagonal entries only in the HAS_DIAG variant.
 // NT threads, MPT edges and NPT nodes per thread (NT MPT = 6144 edge slots, NT NPT = 2048 node slots), ILP message
-// computations in lock step per wave.  Instantiated as 8 waves x 12 edges x 2 (241 registers, no scratch).  Per iteration and
-// wave at n = 10^3: ~1270 instructions in the message phase (106 per message, 82 of them fp64), ~165 in the node phase (two of
-// four node slots populated), ~60 for the maxima: 6.5 us (round 3 started at 8.8: two divisions and a reciprocal per message
-// instead of one, 165 instructions per node slot instead of 80, 48 ds_bpermute for the maxima instead of 6).  More independent
+// computations in lock step per wave.  Instantiated as 8 waves x 12 edges x 2 (243 registers, no scratch).  Per iteration and
+// wave at n = 10^3: ~1380 instructions in the message phase (115 per message, 91 of them fp64), ~165 in the node phase (two of
+// four node slots populated), ~60 for the maxima: 7.0 us (round 3 started at 8.8: a reciprocal more per message, saturation
+// as a compare + select, 165 instructions per node slot instead of 80, 48 ds_bpermute for the maxima instead of 6).  More independent
 // streams do not help (3 or 4 messages in lock step: 6.5-6.9 us; 16 waves x 6 edges x 1 and 12 waves x 8 x 1 spill).
 template <int NT, int MPT, int NPT, bool HAS_DIAG, int ILP>
 __global__ __launch_bounds__(NT) void k_lbp_lds(LbpArgs a)

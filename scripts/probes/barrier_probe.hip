@@ -56,16 +56,26 @@ int main()
     std::vector<unsigned short> ha(65536); unsigned s = 12345; for (auto &v : ha) { s = s * 1664525u + 1013904223u; v = (unsigned short)(s >> 12); }
     hipMemcpy(offs, h.data(), 4096, hipMemcpyHostToDevice); hipMemcpy(addr, ha.data(), 65536 * 2, hipMemcpyHostToDevice);
     hipFuncSetAttribute((const void *)k_probe, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    // Wall time per round from HIP events around the launch (2 x 10^4 rounds: launch overhead and the prologue are < 1 %).  The
+    // value of __builtin_readcyclecounter is printed beside it for reference only: it is NOT a core-clock cycle count on this
+    // chip (ticks per microsecond varied 4x with the number of resident waves when calibrated against events).
+    const int iters_t = 20000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int mode : {0, 2, 4, 8})
         for (int waves : {1, 2, 4, 8, 12, 16}) {
-            hipLaunchKernelGGL(k_probe, dim3(blocks), dim3(waves * 64), 140 * 1024, 0, iters, mode, offs, out, addr);
+            hipLaunchKernelGGL(k_probe, dim3(blocks), dim3(waves * 64), 140 * 1024, 0, iters, mode, offs, out, addr);      // warm-up
             hipDeviceSynchronize();
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(k_probe, dim3(blocks), dim3(waves * 64), 140 * 1024, 0, iters_t, mode, offs, out, addr);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
             std::vector<long long> r(blocks * 2);
             hipMemcpy(r.data(), out, blocks * 16, hipMemcpyDeviceToHost);
             double m = 0; for (int b = 0; b < blocks; ++b) m += (double)r[b * 2];
-            // s_memtime / readcyclecounter ticks at 100 MHz on this chip: report raw ticks per iteration and the ns they mean
-            printf("mode %d (%s%s) waves %2d: %.2f counter ticks per barrier round\n", mode, (mode & 4) ? "conflict-free gathers " : (mode & 8) ? "random dword gathers " : "", (mode & 2) ? "random byte gathers+write" : "",
-                   waves, m / blocks / iters);
+            printf("mode %d (%s%s) waves %2d: %7.1f ns per barrier round (events), %.2f counter ticks\n", mode,
+                   (mode & 4) ? "conflict-free gathers " : (mode & 8) ? "random dword gathers " : "", (mode & 2) ? "random byte gathers+write" : "",
+                   waves, (double)ms * 1e6 / iters_t, m / blocks / iters_t);
         }
     return 0;
 }
