@@ -172,3 +172,21 @@ def test_apt_preprocessor():
                           float(g["beta_start"]), float(g["alpha"]), float(g["sigma_E_val"]), float(g["beta_max"]))
     assert np.allclose(beta, g["beta"], rtol=1e-12, atol=0)
     assert np.allclose(sigma, g["sigma"], rtol=1e-10, atol=1e-12)
+
+
+def test_lbp_lambda_counts_of_the_restatement_equal_the_reference_on_c3_seeds():
+    """The lambda at which LBP_convexified stops is decided by the last bit of every message (tolerance = machine epsilon): the
+    restatement reproduces the reference's count exactly on seeds of the C3 shape (tests/golden/stats_lbp_lambdas_c3.npz, the
+    reference itself; 2 of its 64 seeds here, ~10 s each -- all of the first 16 were checked when the fixture was made)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from helpers import make_instance
+    g = golden("stats_lbp_lambdas_c3")
+    J, h = make_instance(1000)
+    Jd = J.toarray()
+    h = np.asarray(h, float).reshape(-1)
+    eps = np.abs(h) + np.sum(np.abs(Jd), axis=1)
+    for p in (3, 9):
+        _, marg = refport.lbp_convexified(Jd, h, 3.0, 0.01, 0.9, g["m_star"][p].astype(float), eps, np.finfo(float).eps, 100,
+                                          0.9999999, 0.999999, 3.0, want_marginals=True)
+        assert len(marg) == int(g["n_lambdas_reference"][p])

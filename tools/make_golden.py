@@ -273,6 +273,37 @@ def gen_lbp_and_run():
 
 
 # ----------------------------------------------------------------------------------------------
+# G12: where the reference's lambda continuation stops (NMC/nmc.py:139-150) at the C3 shape.  The stopping lambda is decided by
+# rounding noise (tolerance = machine epsilon), so it is a STATISTIC of the arithmetic: 64 seeds, lambdas processed per seed.
+# Seeds: chain states of the device engine after 10^3 sweeps at beta = 3 (scripts/lbp_c3_probe.py DUMP=...), stored in the fixture.
+# ----------------------------------------------------------------------------------------------
+def _lbpstat_one(args):
+    Jd, m_star, eps = args
+    obj = ref_nmc.NMC(Jd.copy(), np.zeros(Jd.shape[0]))
+    with quiet():
+        try:
+            _, marg, _, _, _ = obj.LBP_convexified(3, 0.01, 0.9, m_star.copy(), eps, np.finfo(float).eps, 100, 0.9999999, 0.999999, 3.0)
+        except ValueError:
+            return 0
+    return len(marg)
+
+
+def gen_lbp_lambda_stats():
+    from multiprocessing import Pool
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from helpers import make_instance
+    dump = os.environ.get("NLMC_LBP_DUMP", os.path.join(REPO, "gpurun_out", "r3", "dump_rx", "lbp_probe_sw1000.npz"))
+    ms = np.load(dump)["ms"].astype(np.float64)
+    J, h = make_instance(1000)
+    Jd = J.toarray()
+    eps = np.abs(h) + np.sum(np.abs(Jd), axis=1)
+    with Pool(8) as pool:
+        nl = pool.map(_lbpstat_one, [(Jd, ms[p], eps) for p in range(ms.shape[0])])
+    save("stats_lbp_lambdas_c3", instance="tests/helpers.make_instance(1000)", m_star=ms.astype(np.int8), global_beta=3.0, lambda_start=3.0,
+         lambda_end=0.01, lambda_reduction_factor=0.9, max_iterations=100, n_lambdas_reference=np.array(nl, dtype=np.int32))
+
+
+# ----------------------------------------------------------------------------------------------
 # G4: NPT.run (inline executor)   (NPT/npt.py:535-700)
 # ----------------------------------------------------------------------------------------------
 PAIR_RE = re.compile(r"Selected pair indices: (\d+), (\d+)")
@@ -529,8 +560,8 @@ def gen_stats_nmc():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["mcmc", "large", "nmcsub", "lbp", "npt", "icm", "pre", "known", "stats", "statsmin", "statsmix", "statsnmc"]
-    table = dict(statsmix=gen_stats_min_mixed, statsnmc=gen_stats_nmc, mcmc=gen_mcmc, large=gen_mcmc_large, statsmin=gen_stats_min, nmcsub=gen_nmc_subroutine, lbp=gen_lbp_and_run, npt=gen_npt, icm=gen_icm,
+    which = sys.argv[1:] or ["mcmc", "large", "nmcsub", "lbp", "npt", "icm", "pre", "known", "stats", "statsmin", "statsmix", "statsnmc"]     # ("lbpstat" needs a device dump: on request)
+    table = dict(lbpstat=gen_lbp_lambda_stats, statsmix=gen_stats_min_mixed, statsnmc=gen_stats_nmc, mcmc=gen_mcmc, large=gen_mcmc_large, statsmin=gen_stats_min, nmcsub=gen_nmc_subroutine, lbp=gen_lbp_and_run, npt=gen_npt, icm=gen_icm,
                  pre=gen_preprocessor, known=gen_known_answers, stats=gen_stats)
     for w in which:
         table[w]()
