@@ -256,6 +256,17 @@ __device__ __forceinline__ double lbp_wave_max4(double q0, double q1, double q2,
     kk = fmax(kk, __shfl_xor(ss, 16, 64));
     return lbp_row_max(kk);
 }
+// sum of a 32-bit value over the wave (every lane gets it): in-row DPP steps, then the two cross-row exchanges
+__device__ __forceinline__ unsigned lbp_wave_sum_u32(unsigned v)
+{
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);
+    v += (unsigned)__shfl_xor((int)v, 16, 64);
+    v += (unsigned)__shfl_xor((int)v, 32, 64);
+    return v;
+}
 __device__ __forceinline__ double lbp_read_lane(double v, int l)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
@@ -415,11 +426,62 @@ __global__ __launch_bounds__(NLMC_LBP_THREADS) void k_lbp(LbpArgs a)
 // 0, writes to a scratch slot: their message is exactly 0 and every maximum they feed is 0), node slots past n likewise, a
 // node's neighbour terms past its degree read the zero message slot; diagonal entries only in the HAS_DIAG variant.
 // NT threads, MPT edges and NPT nodes per thread (NT MPT = 6144 edge slots, NT NPT = 2048 node slots), ILP message
-// computations in lock step per wave.  Instantiated as 8 waves x 12 edges x 2 (243 registers, no scratch).  Per iteration and
-// wave at n = 10^3: ~1380 instructions in the message phase (115 per message, 91 of them fp64), ~165 in the node phase (two of
+// computations in lock step per wave.  Instantiated as 8 waves x 12 edges x 2 (250 registers, no scratch).  Per iteration and
+// wave at n = 10^3: ~1380 instructions in the message phase (115 per message, 91 of them fp64), ~180 in the node phase (two of
 // four node slots populated), ~60 for the maxima: 7.0 us (round 3 started at 8.8: a reciprocal more per message, saturation
-// as a compare + select, 165 instructions per node slot instead of 80, 48 ds_bpermute for the maxima instead of 6).  More independent
-// streams do not help (3 or 4 messages in lock step: 6.5-6.9 us; 16 waves x 6 edges x 1 and 12 waves x 8 x 1 spill).
+// as a compare + select, 165 instructions per node slot instead of 80, 48 ds_bpermute for the maxima instead of 6).  More
+// independent streams do not help (3 or 4 messages in lock step: no gain; 16 waves x 6 edges x 1 and 12 waves x 8 x 1 spill).
+#define NLMC_LBP_HASH_FROM 10       // iterations of a lambda before the cycle detector starts hashing (most lambdas converge earlier)
+// The message phase of one iteration (a macro: it is instantiated with and without the state hash of the cycle detector, and a
+// lambda over this much captured state ends up in scratch memory).  Two messages at a time, the LDS reads of the next pair in
+// flight meanwhile (left to itself the scheduler interleaves all MPT message computations and spills).  Hash: a change of a message
+// by a few ulp always shows in the low mantissa bits; the multiplier is not affine in (thread, k): +1 ulp at two edges and -1 ulp
+// at the two "crossed" ones must not cancel.
+#define NLMC_LBP_MESSAGE_PHASE(HASH) \
+        { \
+            double t_n[ILP], w_n[ILP], u_n[ILP];                                                                               \
+_Pragma("unroll")                                                                                                              \
+            for (int j = 0; j < ILP; ++j) { t_n[j] = tot[E_SRC(j)]; w_n[j] = wc[tid + j * NT]; u_n[j] = wc[E_REV(j)]; }        \
+_Pragma("unroll")                                                                                                              \
+            for (int k = 0; k < MPT; k += ILP) {                                                                               \
+                double t_i[ILP], w_e[ILP], u_o[ILP], h_new[ILP], u_new[ILP];                                                   \
+_Pragma("unroll")                                                                                                              \
+                for (int j = 0; j < ILP; ++j) { t_i[j] = t_n[j]; w_e[j] = w_n[j]; u_o[j] = u_n[j]; }                           \
+                if (k + ILP < MPT) {                                                                                           \
+_Pragma("unroll")                                                                                                              \
+                    for (int j = 0; j < ILP; ++j) {                                                                            \
+                        const int kn = k + ILP + j < MPT ? k + ILP + j : 0;                                                    \
+                        t_n[j] = tot[E_SRC(kn)];                                                                               \
+                        w_n[j] = wc[tid + kn * NT];                                                                            \
+                        u_n[j] = wc[E_REV(kn)];                                                                                \
+                    }                                                                                                          \
+                }                                                                                                              \
+_Pragma("unroll")                                                                                                              \
+                for (int j = 0; j < ILP; ++j) {                                                                                \
+                    h_new[j] = t_i[j] - w_e[j];                                                                                \
+                    if (HAS_DIAG) h_new[j] = (bits & (1u << (8 + k + j))) ? 0.0 : h_new[j];                                    \
+                }                                                                                                              \
+                {                                                                                                              \
+                    double tj[ILP], yy[ILP];                                                                                   \
+_Pragma("unroll")                                                                                                              \
+                    for (int j = 0; j < ILP; ++j) { tj[j] = e_tJ[k + j]; yy[j] = a.beta * h_new[j]; }                          \
+                    lbp_message_w<ILP>(tj, yy, u_new, a.sat, a.usat, a.inv_beta);                                              \
+                }                                                                                                              \
+_Pragma("unroll")                                                                                                              \
+                for (int j = 0; j < ILP; ++j) {                                                                                \
+                    const double h_old = e_hm[k + j];                                                                          \
+                    e_hm[k + j] = h_new[j];                                                                                    \
+                    wn[E_REV(k + j)] = u_new[j];                                                                               \
+                    if (HASH) hs1 += __umul24((unsigned)__double2loint(u_new[j]), __umul24(c1, 2u * (unsigned)(k + j) + 1u));  \
+                    dh_n = fmax(dh_n, fabs(h_new[j] - h_old));                                                                 \
+                    dh_d = fmax(dh_d, fabs(h_new[j]) + fabs(h_old));                                                           \
+                    du_n = fmax(du_n, fabs(u_new[j] - u_o[j]));                                                                \
+                    du_d = fmax(du_d, fabs(u_new[j]) + fabs(u_o[j]));                                                          \
+                }                                                                                                              \
+                __builtin_amdgcn_sched_barrier(0);                                                                             \
+            }                                                                                                                  \
+        }
+
 template <int NT, int MPT, int NPT, bool HAS_DIAG, int ILP>
 __global__ __launch_bounds__(NT) void k_lbp_lds(LbpArgs a)
 {
@@ -461,14 +523,13 @@ __global__ __launch_bounds__(NT) void k_lbp_lds(LbpArgs a)
     }
     // this thread's nodes
     int v_r0[NPT], v_deg[NPT];
-    double v_h[NPT], v_me[NPT];
+    double v_hl[NPT];                   // h_lam of the running lambda (set where the lambda starts)
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
         const int i = tid + k * NT;
         const bool on = i < n;
         const int ic = on ? i : 0;
         v_r0[k] = a.rowptr[ic]; v_deg[k] = on ? a.rowptr[ic + 1] - v_r0[k] : 0;
-        v_h[k] = on ? a.h[ic] : 0.0; v_me[k] = on ? ms[ic] * a.eps[ic] : 0.0;
         int offdiag = 0;
         for (int e = v_r0[k]; e < v_r0[k] + v_deg[k]; ++e) offdiag += a.col[e] != ic;
         if (on) bits |= 1u << k;
@@ -484,31 +545,59 @@ __global__ __launch_bounds__(NT) void k_lbp_lds(LbpArgs a)
     // are 8 lane masks per node slot (64 scalar registers at NPT = 4, spilled to lanes of a vector register and read back with
     // two v_readlane per use: the node phase was 165 instructions per slot).
     auto row_sum = [&](int k) __attribute__((always_inline)) {
-        int deg = v_deg[k];
-        asm volatile("" : "+v"(deg));
+        int deg = v_deg[k], r0 = v_r0[k];
+        asm volatile("" : "+v"(deg), "+v"(r0));                                    // (r0: or 8 hoisted addresses per slot)
         double v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = wc[q < deg ? v_r0[k] + q : ESLOTS];        // all reads in flight
+        for (int q = 0; q < 8; ++q) v[q] = wc[q < deg ? r0 + q : ESLOTS];             // all reads in flight
         double sum = 0.0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) sum += v[q];
-        for (int q = 8; q < deg; ++q) sum += wc[v_r0[k] + q];
+        for (int q = 8; q < deg; ++q) sum += wc[r0 + q];
         return sum;
     };
 
+    // Exact limit cycles.  The reference iterates until both relative changes fall below machine epsilon or max_iterations is
+    // reached; the lambda where that fails is, in practice, one where the messages settle into a cycle of period 2 or 4 in
+    // their last bits (every exhausted lambda of 16 C3 seeds did, by iteration 9-39 of 100).  The map u(t) -> u(t+1) is a
+    // deterministic function of the message array alone, so once u(t) = u(t-p), u(t-1) = u(t-1-p) and u(t-2) = u(t-2-p) hold
+    // exactly, every later convergence test (a function of u(s), u(s-1), u(s-2)) repeats one that has already failed: the
+    // remaining iterations cannot change the outcome and are skipped -- same marginals, same lambda count, iteration count
+    // reported as max_iterations - 1.  States are compared through a 32-bit sum over all messages of (low mantissa bits x a per-edge
+    // odd multiplier) (two v_mul_u32_u24 per message); three consecutive matches at the same period are required, so a chance
+    // collision (2^-32 each) cannot end a lambda that would have converged.  Ring of the last 64 hashes: lane j of every wave holds
+    // the hash of the latest iteration == j (mod 64); periods up to 63 are seen.  On 64 C3 seeds: median iterations per seed
+    // 309 -> 229; the slowest seed of a batch rarely gains (one seed in 64 finds no short cycle), batches that fill the chip do.
+    static_assert(NW < 16, "red[15] / red[31] hold the hash sum of the running / the next iteration");
+    unsigned *const hsum = reinterpret_cast<unsigned *>(red);          // words 30, 31 (red[15]) and 62, 63 (red[31]): two slots
+    const unsigned hc1 = (((unsigned)tid * 0x9E3779B1u) >> 8) | 1u;       // 24 bits, odd
+    unsigned hr1 = 0u;
+    int hpar = 0;                                                     // slot of the running iteration (alternates across lambdas too)
+    if (tid == 0) { hsum[30] = 0u; hsum[62] = 0u; }
     int n_done = 0, status = 0;
     for (int l = 0; l < a.n_lams; ++l) {
         const double lam = a.lams[l];
-        int it = 0;
+        // h_lam = h + lam * (m_star * epsilon)  (NMC/nmc.py:137), slots past n: 0
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int i = tid + k * NT;
+            int ic = i < n ? i : 0;
+            asm volatile("" : "+v"(ic));             // (re-read per lambda: hoisted, the three inputs take 6 registers per slot)
+            const double me = ms[ic] * a.eps[ic];
+            v_hl[k] = i < n ? a.h[ic] + lam * me : 0.0;
+        }
+        int it = 0, cyc_run = 0, cyc_p = 0;
         for (int iter = 0; iter < a.max_iter; ++iter) {
             it = iter;
             double dh_n = 0.0, dh_d = 0.0, du_n = 0.0, du_d = 0.0;
+            unsigned hs1 = 0u, c1 = hc1;
+            asm volatile("" : "+v"(c1));                // (keeps the 12 per-edge multipliers out of registers: one multiply each, in the loop)
             // ---- node totals: total_i = h_lam[i] + sum_k u_msgs[k, i]   (NMC/nmc.py:199-201)
 #pragma unroll
             for (int k = 0; k < NPT; ++k) {
                 if (__ballot((bits >> k) & 1u) == 0ull) continue;      // no lane of this wave owns a node in slot k (n < NPT NT)
                 const int i = tid + k * NT;
-                const double hl = v_h[k] + lam * v_me[k];
+                const double hl = v_hl[k];
                 const double t_new = hl + row_sum(k), t_old = tot[i];
                 tot[i] = t_new;                                         // (slots past n: nobody reads them; their value is 0 anyway)
                 if (bits & (1u << (4 + k))) {
@@ -521,49 +610,35 @@ __global__ __launch_bounds__(NT) void k_lbp_lds(LbpArgs a)
             // (two messages at a time, the LDS reads of the next pair in flight meanwhile: left to itself the scheduler
             // interleaves all MPT message computations and spills)
             static_assert(MPT % ILP == 0, "messages are processed ILP at a time");
-            double t_n[ILP], w_n[ILP], u_n[ILP];
-#pragma unroll
-            for (int j = 0; j < ILP; ++j) { t_n[j] = tot[E_SRC(j)]; w_n[j] = wc[tid + j * NT]; u_n[j] = wc[E_REV(j)]; }
-#pragma unroll
-            for (int k = 0; k < MPT; k += ILP) {
-                double t_i[ILP], w_e[ILP], u_o[ILP], h_new[ILP], u_new[ILP];
-#pragma unroll
-                for (int j = 0; j < ILP; ++j) { t_i[j] = t_n[j]; w_e[j] = w_n[j]; u_o[j] = u_n[j]; }
-                if (k + ILP < MPT) {                 // the LDS reads of the next message(s) are in flight meanwhile
-#pragma unroll
-                    for (int j = 0; j < ILP; ++j) {
-                        const int kn = k + ILP + j < MPT ? k + ILP + j : 0;
-                        t_n[j] = tot[E_SRC(kn)];
-                        w_n[j] = wc[tid + kn * NT];
-                        u_n[j] = wc[E_REV(kn)];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < ILP; ++j) {
-                    h_new[j] = t_i[j] - w_e[j];
-                    if (HAS_DIAG) h_new[j] = (bits & (1u << (8 + k + j))) ? 0.0 : h_new[j];
-                }
-                {
-                    double tj[ILP], yy[ILP];
-#pragma unroll
-                    for (int j = 0; j < ILP; ++j) { tj[j] = e_tJ[k + j]; yy[j] = a.beta * h_new[j]; }
-                    lbp_message_w<ILP>(tj, yy, u_new, a.sat, a.usat, a.inv_beta);
-                }
-#pragma unroll
-                for (int j = 0; j < ILP; ++j) {
-                    const double h_old = e_hm[k + j];
-                    e_hm[k + j] = h_new[j];
-                    wn[E_REV(k + j)] = u_new[j];
-                    dh_n = fmax(dh_n, fabs(h_new[j] - h_old));
-                    dh_d = fmax(dh_d, fabs(h_new[j]) + fabs(h_old));
-                    du_n = fmax(du_n, fabs(u_new[j] - u_o[j]));
-                    du_d = fmax(du_d, fabs(u_new[j]) + fabs(u_o[j]));
-                }
-                __builtin_amdgcn_sched_barrier(0);   // (left to itself the scheduler hoists the loads of all MPT messages and spills)
-            }
+            const bool hashing = iter >= NLMC_LBP_HASH_FROM;             // (uniform)
+            if (hashing) NLMC_LBP_MESSAGE_PHASE(true) else NLMC_LBP_MESSAGE_PHASE(false)
             const double wm = lbp_wave_max4(dh_n, dh_d, du_n, du_d, lane);      // row q of the wave: quantity q
             if ((lane & 15) == 0) red[(lane >> 4) * 16 + wv] = wm;
+            const int hslot = 30 + 32 * hpar;
+            if (hashing) {
+                const unsigned w1 = lbp_wave_sum_u32(hs1);
+                if (lane == 0) atomicAdd(&hsum[hslot], w1);
+                hpar ^= 1;
+            }
             __syncthreads();
+            bool cycling = false;
+            if (hashing) {
+                const unsigned h1 = hsum[hslot];
+                if (tid == 0) hsum[hslot ^ 32] = 0u;                                      // the other slot: the next hashed iteration's sum
+                // lane j holds the hash of the latest iteration == j (mod 64) (valid if that iteration was hashed in this lambda);
+                // the nearest earlier equal state is p iterations back: rotate the match mask so that the entry of iteration
+                // iter - q sits at bit 63 - q, count leading zeros
+                const int r = iter & 63;
+                const int latest = iter - 1 - ((iter - 1 - lane) & 63);
+                unsigned long long m64 = __ballot(latest >= NLMC_LBP_HASH_FROM && hr1 == h1) & ~(1ull << r);
+                const int sh = 63 - r;
+                m64 = sh ? ((m64 << sh) | (m64 >> (64 - sh))) : m64;
+                const int pm = m64 ? __clzll((long long)m64) : 0;
+                cyc_run = (pm != 0 && pm == cyc_p) ? cyc_run + 1 : (pm != 0 ? 1 : 0);
+                cyc_p = pm;
+                if (lane == r) hr1 = h1;
+                cycling = cyc_run >= 3;
+            }
             // every wave reduces the 4 x NW partial maxima itself: lanes [16 q, 16 q + 16) hold quantity q
             const double m = lbp_row_max((lane & 15) < NW ? red[lane] : 0.0);
             const double r0 = lbp_read_lane(m, 0), r1 = lbp_read_lane(m, 16), r2 = lbp_read_lane(m, 32), r3 = lbp_read_lane(m, 48);
@@ -571,6 +646,7 @@ __global__ __launch_bounds__(NT) void k_lbp_lds(LbpArgs a)
             // 0/0 = NaN compares false, like the reference's `du < tolerance and dh < tolerance` (NMC/nmc.py:212-213)
             const double dh = r0 / r1, du = r2 / r3;
             if (du < a.tol && dh < a.tol) break;
+            if (cycling) { it = a.max_iter - 1; break; }          // an exact cycle: no later iteration can pass the test
         }
         if (tid == 0) a.out_iters[(size_t)p * a.n_lams + l] = it;
         const bool exhausted = (it == a.max_iter - 1);
@@ -579,7 +655,7 @@ __global__ __launch_bounds__(NT) void k_lbp_lds(LbpArgs a)
             // magnetizations = tanh(beta (h_lam + sum_k u_msgs[k, :]))  (NMC/nmc.py:216-217), rows added in ascending k
 #pragma unroll
             for (int k = 0; k < NPT; ++k)
-                if (bits & (1u << k)) mag[tid + k * NT] = tanh(a.beta * ((v_h[k] + lam * v_me[k]) + row_sum(k)));
+                if (bits & (1u << k)) mag[tid + k * NT] = tanh(a.beta * (v_hl[k] + row_sum(k)));
         }
         // exhausted at a later lambda: keep the previous marginals and stop (NMC/nmc.py:145-148)
         if (a.mag_all) {
