@@ -155,7 +155,9 @@ def test_device_lbp_does_not_depend_on_workgroups_per_problem(product, monkeypat
 @pytest.mark.parametrize("N,P", [(300, 3), (1000, 16), (1500, 5)])
 def test_lds_resident_kernel_equals_the_global_memory_kernel(product, N, P, monkeypatch):
     """k_lbp_lds (small instances: messages in LDS, a thread's edges in registers) does the operations of k_lbp in the same
-    order: marginals, lambda counts and iteration counts are the same bits."""
+    order: marginals, lambda counts and iteration counts are the same bits.  This is also the test of k_lbp_lds's exact-cycle
+    exit (it leaves a lambda whose message array has started to repeat; k_lbp has no such exit and runs every lambda to
+    max_iterations): nearly every seed ends its lambda loop on an exhausted lambda, and all outputs must still be equal."""
     J, h = make_instance(N, seed=N, with_h=True)
     inst = product.Instance(J, h)
     graph = product.lbp.EdgeGraph(inst)
@@ -170,6 +172,7 @@ def test_lds_resident_kernel_equals_the_global_memory_kernel(product, N, P, monk
     for k in ("mag", "n_lambdas", "status"):
         assert np.array_equal(a[k], b[k]), k
     assert a["n_lambdas"].min() >= 3
+    assert sum(int(a["iters"][q, int(a["n_lambdas"][q]) - 1]) == 99 for q in range(P)) >= 1      # exhausted lambdas were seen
     for q in range(P):                        # (rows behind the last processed lambda are not written)
         m = int(a["n_lambdas"][q])
         assert np.array_equal(a["iters"][q, :m], b["iters"][q, :m])
