@@ -226,6 +226,12 @@ int nlmc_select_chains(nlmc_ctx *ctx, int which);
  * unmarked chains' sweeps (select UNMARKED first) run beside it -- the reference's pool runs MCMC_task and NMC_task side by
  * side too (NPT/npt.py:616-640).  Same results either way. */
 int nlmc_overlap_subsets(nlmc_ctx *ctx, int on);
+/* From now on the context queues its work on a non-blocking HIP stream of its own (created here, destroyed with the context)
+ * instead of the stream given at creation.  For several contexts on ONE device driven by one process (distributed.LocalTempering
+ * with repeated device ids): contexts that were all created on the NULL stream execute one after the other; with a stream each
+ * they share the chip -- the reference's knob for this is the pool of num_cores workers, NPT/npt.py:616-640.  Call it right
+ * after nlmc_create (pending work of the old stream is waited for), before nlmc_comm_init. */
+int nlmc_own_stream(nlmc_ctx *ctx);
 int nlmc_subset_count(const nlmc_ctx *ctx);
 int nlmc_get_subset(nlmc_ctx *ctx, int32_t *out_chains /*[nlmc_subset_count] local chain ids*/);
 int nlmc_track_minimum(nlmc_ctx *ctx, int on);

@@ -41,6 +41,7 @@ template <typename T> struct DevBuf {
 struct nlmc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = false;             // nlmc_own_stream: `stream` was created by the library
     // Work on the MARKED chain subset may run on a second stream beside the unmarked chains' sweeps (nlmc_overlap_subsets):
     // `cur` is the stream the subset-aware launches go to, forked from / joined to `stream` by nlmc_select_chains.
     hipStream_t aux = nullptr, cur = nullptr;
@@ -1051,6 +1052,7 @@ void nlmc_destroy(nlmc_ctx *c)
     if (c->comm && g_rccl.ok) (void)g_rccl.CommDestroy(c->comm);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
+    if (c->owns_stream && c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     c->rowptr.release(); c->col.release(); c->val64.release(); c->h64.release(); c->edge32.release(); c->hq.release();
@@ -1623,8 +1625,11 @@ int nlmc_pt_swap_philox(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs,
     if (c->ladder_len == 0) return fail(c, NLMC_ERR_STATE, "nlmc_pt_swap_philox: call nlmc_pt_init first");
     const int L = c->ladder_len, G = c->n_chains_global, nl = G / L;
     if (n_pairs < 0 || n_pairs > std::max(0, L - 1)) return fail(c, NLMC_ERR_ARG, "Cannot find non-overlapping pairs.");
-    if (!energies_all_dev && (c->chain_base != 0 || c->n_chains != G))
-        return fail(c, NLMC_ERR_ARG, "nlmc_pt_swap_philox: a sharded context needs the all-gathered energies");
+    // a context that owns whole ladders needs nobody else's energies: it decides its own ladders from its tracked energies
+    // (same Philox keys -- round, GLOBAL ladder index, pair -- as the context that holds all chains)
+    const bool whole_ladders = c->chain_base % L == 0 && c->n_chains % L == 0;
+    if (!energies_all_dev && !whole_ladders)
+        return fail(c, NLMC_ERR_ARG, "nlmc_pt_swap_philox: a context whose block cuts a ladder needs the all-gathered energies");
     if (L > 4096) return fail(c, NLMC_ERR_UNSUPPORTED, "nlmc_pt_swap_philox: ladder_len > 4096");
     HIP_TRY(c, hipSetDevice(c->device));
     if (n_pairs == 0) return NLMC_OK;
@@ -1639,6 +1644,9 @@ int nlmc_pt_swap_philox(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs,
     a.escale = c->escale;
     a.slot_of_chain = c->slot_of_chain.p; a.chain_of_slot = c->chain_of_slot.p;
     a.out_pairs = c->pt_pairs.p; a.out_acc = c->pt_acc.p; a.status = c->pt_status.p;
+    a.ladder0 = energies_all_dev ? 0 : c->chain_base / L;
+    a.chain_base = c->chain_base;
+    const int n_decide = energies_all_dev ? nl : c->n_chains / L;            // ladders this launch decides
     if (c->pt_log_on && c->pt_log_npairs == n_pairs && round >= c->pt_log_round0 &&
         round < c->pt_log_round0 + (uint32_t)c->pt_log_rounds && !out_pairs && !out_accepted) {
         const size_t r = round - c->pt_log_round0;       // device-side log: read back once (nlmc_pt_log_read)
@@ -1654,7 +1662,7 @@ int nlmc_pt_swap_philox(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs,
     // one lane per selected pair when the selection is planned (the in-kernel selection is written for ONE wave)
     const int swap_nt = a.plan_pairs ? std::min(256, (n_pairs + 63) / 64 * 64) : 64;
     c->sub_dirty = true;
-    hipLaunchKernelGGL(k_pt_swap, dim3(nl), dim3(std::max(64, swap_nt)), 0, c->stream, a);
+    hipLaunchKernelGGL(k_pt_swap, dim3(n_decide), dim3(std::max(64, swap_nt)), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     if (out_pairs || out_accepted) {
         int32_t st = 0;
@@ -2183,6 +2191,23 @@ int nlmc_select_chains(nlmc_ctx *c, int which)
     }
     c->forked = false;
     c->subset = which;
+    return NLMC_OK;
+}
+
+int nlmc_own_stream(nlmc_ctx *c)
+{
+    if (!c) return NLMC_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->owns_stream) return NLMC_OK;
+    if (c->cur != c->stream) return fail(c, NLMC_ERR_STATE, "nlmc_own_stream: select all chains first");
+    if (c->comm) return fail(c, NLMC_ERR_STATE, "nlmc_own_stream: call it before nlmc_comm_init");
+    // whatever was queued on the stream given at creation is finished first: from here on the two streams are unrelated
+    if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream)); else HIP_TRY(c, hipDeviceSynchronize());
+    hipStream_t s = nullptr;
+    HIP_TRY(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    c->stream = s;
+    c->cur = s;
+    c->owns_stream = true;
     return NLMC_OK;
 }
 

@@ -27,6 +27,7 @@ struct PtSwapArgs {
     int32_t *status;            // sticky: 1 = "Cannot find non-overlapping pairs."
     const int32_t *plan_pairs;  // this round's planned selection [n_ladders][n_pairs][2] or nullptr
     const int32_t *plan_ok;     // [n_ladders]
+    int ladder0, chain_base;    // a context that owns WHOLE ladders decides those alone: block b = ladder ladder0 + b, efix by local chain id
 };
 
 // position of the r-th (0-based) set bit of w (r < popcount(w)): binary search on popcounts
@@ -105,7 +106,7 @@ __global__ void k_pt_select(PtSelectArgs a)      // grid = n_rounds * n_ladders,
 // (NPT/npt.py:668-671), one lane per selected pair.
 __global__ void k_pt_swap(PtSwapArgs a)
 {
-    const int L = a.ladder_len, g = blockIdx.x, lane = threadIdx.x, nt = blockDim.x;     // nt == 64 unless the selection is planned
+    const int L = a.ladder_len, g = a.ladder0 + blockIdx.x, lane = threadIdx.x, nt = blockDim.x;     // nt == 64 unless the selection is planned
     int32_t *pairs = a.out_pairs + (size_t)g * a.n_pairs * 2;
     const int32_t *sel = pairs;          // where the acceptance step reads this round's selection from
     int good;
@@ -125,8 +126,8 @@ __global__ void k_pt_swap(PtSwapArgs a)
     for (int p = lane; p < a.n_pairs; p += nt) {
         const int i = sel[2 * p];
         const int ca = a.chain_of_slot[(size_t)g * L + i], cb = a.chain_of_slot[(size_t)g * L + i + 1];
-        const double Ea = a.energies ? a.energies[ca] : (double)a.efix[ca] * inv;
-        const double Eb = a.energies ? a.energies[cb] : (double)a.efix[cb] * inv;
+        const double Ea = a.energies ? a.energies[ca] : (double)a.efix[ca - a.chain_base] * inv;
+        const double Eb = a.energies ? a.energies[cb] : (double)a.efix[cb - a.chain_base] * inv;
         const double dE = Eb - Ea, dB = a.beta[i + 1] - a.beta[i];
         const u32x4 r = philox4x32_10((uint32_t)p, a.round, (uint32_t)g, NLMC_TAG_SWAP, a.seed_lo, a.seed_hi);
         const double u = uniform_from(r, 0.0);

@@ -142,18 +142,26 @@ class ShardedTempering:
 class LocalTempering:
     """The same sharded tempering driven by ONE process over several contexts -- one per entry of `device_ids`
     (NPT.run(device_ids=...), APT_ICM.run(device_ids=...); the reference's knob is num_cores, NPT/npt.py:535-539,616).
-    Chains are cut into contiguous blocks like ShardedTempering; per round the tracked energies of every block pass
-    through host memory (G float64) and every context takes the identical Philox-keyed swap decision, so the trajectory
-    equals the single-context one bit for bit.  For one GPU per process over RCCL use ShardedTempering."""
+    Chains are cut into contiguous blocks like ShardedTempering.  Blocks of whole ladders (restarts >= contexts) decide their
+    own ladders' swaps on the device and never meet: the contexts run out of step, which is also how `device_ids=[0] * k`
+    shortens a round whose cost is its slowest chain (NMC slots: the backbone inference).  Blocks that cut a ladder pass the
+    tracked energies through host memory every round (G float64) and every context takes the identical Philox-keyed
+    decision.  Either way the trajectory equals the single-context one bit for bit.  For one GPU per process over RCCL use
+    ShardedTempering."""
 
     def __init__(self, inst, beta_list, n_chains_global, seed, n_pairs, device_ids, precision="f32"):
         self.G, self.seed, self.n_pairs, self.precision = int(n_chains_global), int(seed), int(n_pairs), precision
         devs = list(device_ids)
         self.parts = [block_partition(self.G, len(devs), r) for r in range(len(devs))]
+        L = len(np.asarray(beta_list).reshape(-1))
+        # every context owns whole ladders: each decides its own ladders' swaps from its own tracked energies (same Philox keys
+        # as one context holding everything), nothing passes through the host and the contexts run out of step with each other
+        self.whole_ladders = all(base % L == 0 and count % L == 0 for base, count in self.parts)
         self.engs = []
         try:
             for d, (base, count) in zip(devs, self.parts):
-                e = Engine(inst, None, count, device=int(d), chain_base=base, n_chains_global=self.G)
+                e = Engine(inst, None, count, device=int(d), chain_base=base, n_chains_global=self.G,
+                           own_stream=len(devs) > 1)
                 e.pt_init(np.asarray(beta_list, dtype=np.float64))
                 self.engs.append(e)
         except Exception:
@@ -259,8 +267,9 @@ class LocalTempering:
             outs.append(rec)
         self.sweeps_done += n_sweeps
         if self.n_pairs > 0:
-            if len(self.engs) == 1:
-                self.engs[0].pt_swap_philox(self.rounds_done, self.seed, self.n_pairs, want_log=False)
+            if len(self.engs) == 1 or self.whole_ladders:
+                for e in self.engs:
+                    e.pt_swap_philox(self.rounds_done, self.seed, self.n_pairs, want_log=False)
             else:
                 E = np.concatenate([e.energy_tracked() for e in self.engs])
                 for e in self.engs:
@@ -269,10 +278,20 @@ class LocalTempering:
         return outs
 
     def slots(self):
-        return self.engs[0].pt_slots()
+        if len(self.engs) == 1 or not self.whole_ladders:
+            return self.engs[0].pt_slots()
+        return np.concatenate([e.pt_slots()[base:base + count] for e, (base, count) in zip(self.engs, self.parts)])
 
     def swap_log(self):
-        return self.engs[0].pt_log_read()
+        if len(self.engs) == 1 or not self.whole_ladders:
+            return self.engs[0].pt_log_read()
+        L = self.engs[0].ladder_len
+        pairs, acc = self.engs[0].pt_log_read()
+        for e, (base, count) in list(zip(self.engs, self.parts))[1:]:          # every context logged its own ladders' rows
+            p, a = e.pt_log_read()
+            pairs[:, base // L:(base + count) // L] = p[:, base // L:(base + count) // L]
+            acc[:, base // L:(base + count) // L] = a[:, base // L:(base + count) // L]
+        return pairs, acc
 
     def gather_spins(self):
         return np.concatenate([e.get_spins() for e in self.engs])

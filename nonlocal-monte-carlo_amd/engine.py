@@ -51,7 +51,7 @@ def _beta_table(beta, R, S):
 
 
 class Engine:
-    def __init__(self, J, h, n_chains, device=0, stream=None, chain_base=0, n_chains_global=None):
+    def __init__(self, J, h, n_chains, device=0, stream=None, chain_base=0, n_chains_global=None, own_stream=False):
         self.inst = J if isinstance(J, Instance) else Instance(J, h)
         if not self.inst.symmetric:
             raise ValueError("J must be symmetric: the heat-bath field and the incremental energy assume J == J^T")
@@ -67,6 +67,8 @@ class Engine:
                                  self.n_chains_global)
         _abi.check(rc, None)
         self._ctx = h_
+        if own_stream:                # several contexts on one device: a stream each, or they execute one after the other
+            self._ck(self._L.nlmc_own_stream(self._ctx))
         self.ladder_len = 0
         self.energy_scale = int(self._L.nlmc_energy_scale(self._ctx))
         self.field_scale = int(self._L.nlmc_field_scale(self._ctx))      # qs of the "f32" path: Jq = rint(J 2^qs)
