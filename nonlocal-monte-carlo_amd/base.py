@@ -283,18 +283,24 @@ class Common(SweepMixin):
 
         if self._variant == "npt" and not provided:      # NPT/npt.py:397-403: LBP once per call
             all_clusters = detect(m_star)
-        for cycle in range(num_cycles):
-            if self._variant == "nmc":                   # NMC/nmc.py:365-373: clusters re-detected every cycle
-                print(f'\nCurrent iteration = {cycle + 1}')
-                if not provided:
-                    all_clusters = detect(m_star)
-            phase("C", m_init)
-            phase("NC", m_init)
-            if cycle % full_update_frequency == 0:
-                o = phase("ALL", m_init)
-                if self._variant == "nmc":
-                    m_star = m_init.copy()
-                    print(f'\ncurrent m_star energy = {o["min_energy"][0]:.8f}')
+        if self.rng == "philox" and N >= 256:             # (device RNG: the phases' level schedules do not depend on the spins)
+            eng.plan_ahead(self._sweep_counter, sum(2 + (1 if c % full_update_frequency == 0 else 0) for c in range(num_cycles)),
+                           S, self.seed)
+        try:
+            for cycle in range(num_cycles):
+                if self._variant == "nmc":                   # NMC/nmc.py:365-373: clusters re-detected every cycle
+                    print(f'\nCurrent iteration = {cycle + 1}')
+                    if not provided:
+                        all_clusters = detect(m_star)
+                phase("C", m_init)
+                phase("NC", m_init)
+                if cycle % full_update_frequency == 0:
+                    o = phase("ALL", m_init)
+                    if self._variant == "nmc":
+                        m_star = m_init.copy()
+                        print(f'\ncurrent m_star energy = {o["min_energy"][0]:.8f}')
+        finally:
+            eng.plan_ahead(None, 0, 0, 0)
         M_overall = M_overall[:, :at]
         energy_overall = energy_overall[:at]
         min_energy = np.min(energy_overall)

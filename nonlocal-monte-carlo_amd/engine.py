@@ -70,6 +70,7 @@ class Engine:
         if own_stream:                # several contexts on one device: a stream each, or they execute one after the other
             self._ck(self._L.nlmc_own_stream(self._ctx))
         self.ladder_len = 0
+        self._ahead = None
         self.energy_scale = int(self._L.nlmc_energy_scale(self._ctx))
         self.field_scale = int(self._L.nlmc_field_scale(self._ctx))      # qs of the "f32" path: Jq = rint(J 2^qs)
 
@@ -227,6 +228,20 @@ class Engine:
         T = fused_window(S) if window is None else int(window)
         budget = self.FUSED_PLAN_BUDGET if budget_bytes is None else int(budget_bytes)
         rec_e = bool(want_recorded_energy and record_stride)
+        a = getattr(self, "_ahead", None)
+        if (a is not None and window is None and a.window and S == a.S and int(seed) == a.seed and (int(sweep0) - a.sweep0) % max(1, S) == 0
+                and 0 <= (int(sweep0) - a.sweep0) // max(1, S) < a.R
+                and sweeps_per_plan_piece(self.fused_plan_bytes(a.window), S, a.window, budget, record_stride) == S):
+            ii = (int(sweep0) - a.sweep0) // S          # launch ii of the run announced with plan_ahead: its windows are (or get)
+            if not (a._fused_from <= ii < a._fused_to):  # planned together with those of the launches that follow
+                a._plan(ii, True)
+            if a._fused_from <= ii < a._fused_to:
+                self.fused_last_call = True
+                o = self.sweep_philox(S, seed, sweep0=sweep0, beta=beta, record_stride=record_stride, want_energy=want_energy,
+                                      want_min=want_min, want_state=want_state)
+                if rec_e:
+                    o["energy_recorded"] = self.energy_of_recorded(o["spins"].shape[1])
+                return o
         if not T or S % T or S == 0:
             self.fused_last_call = False
             o = self.sweep_philox(S, seed, sweep0=sweep0, beta=beta, record_stride=record_stride, want_energy=want_energy,
@@ -237,6 +252,9 @@ class Engine:
         per_piece = sweeps_per_plan_piece(self.fused_plan_bytes(T), S, T, budget, record_stride)
         b = None if beta is None else np.asarray(beta, dtype=np.float64)
         outs, fused = [], True
+        if a is not None:                    # this call plans into the slot the announced run's windows live in: they are gone
+            a._fused_from = a._fused_to = 0
+            self.plan_slot(a.slot)
         for t0 in range(0, S, per_piece):
             t1 = min(S, t0 + per_piece)
             if fused:
@@ -251,6 +269,18 @@ class Engine:
         if rec_e and len(outs) > 1:
             o["energy_recorded"] = np.concatenate([p["energy_recorded"] for p in outs], axis=1)
         return o
+
+    def plan_ahead(self, sweep0, n_launches, sweeps_per_launch, seed, budget_bytes=None):
+        """Announce `n_launches` sweep_philox_windows calls of `sweeps_per_launch` sweeps each at consecutive sweep indices from
+        `sweep0` (the phases of an NMC run): their fused windows depend on the RNG only and are planned a budget's worth of
+        LAUNCHES at a time instead of one launch at a time -- a planning launch is latency-bound (~1.5 ms whether it builds 9
+        windows or 200; per phase launch that was 27 % of C2 through NMC.run_restarts).  plan_ahead(None) ends it."""
+        if sweep0 is None or n_launches <= 0 or sweeps_per_launch <= 0:
+            self._ahead = None
+            return
+        self._ahead = RoundPlanner(self, sweep0, n_launches, sweeps_per_launch, seed,
+                                   budget_bytes=self.FUSED_PLAN_BUDGET if budget_bytes is None else budget_bytes, slot=0,
+                                   fused_outputs=True)
 
     def plan_philox(self, sweep0, n_sweeps, seed, precision="f32"):
         prec = {"f32": _abi.F32, "f64": _abi.F64}[precision]

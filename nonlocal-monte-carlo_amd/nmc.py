@@ -111,6 +111,7 @@ class NMC(Common):
                 mask = np.zeros((R, N), dtype=np.uint8)
                 mask[:, np.asarray(all_clusters, dtype=int)] = 1
                 eng.set_cluster_mask(mask)
+            eng.plan_ahead(sweep0, 3 * num_NMC_cycles, S, self.seed)      # the phase launches' windows, planned together
             try:
                 for cycle in range(num_NMC_cycles):
                     if all_clusters is None:
@@ -120,6 +121,7 @@ class NMC(Common):
                         launch(S, float(global_beta))
                 eng.backbone_check()
             finally:
+                eng.plan_ahead(None, 0, 0, 0)
                 eng.set_flags(None)
         self._sweep_counter = sweep0
         # the running minima were tracked in the fixed-point model; report the fp64 energies of the kept states
@@ -157,6 +159,8 @@ class NMC(Common):
             m = launch(m, S0, np.repeat(sched[None, :], R, axis=0), None)
         m_star = m.copy()
         flat = np.full((R, S), float(global_beta)) if S > 0 else None
+        n_launches = sum(2 + (1 if cycle % full_update_frequency == 0 else 0) for cycle in range(num_NMC_cycles))
+        eng.plan_ahead(sweep0, n_launches, S, self.seed)
         for cycle in range(num_NMC_cycles):
             if S == 0:
                 break
@@ -171,6 +175,7 @@ class NMC(Common):
             if cycle % full_update_frequency == 0:
                 m = launch(m, S, flat, None)
                 m_star = m.copy()
+        eng.plan_ahead(None, 0, 0, 0)
         eng.set_flags(None)
         self._sweep_counter = sweep0
         # the running minima were tracked incrementally from fp32 fields; report the fp64 energies of the kept states

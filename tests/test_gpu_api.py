@@ -420,6 +420,8 @@ def test_npt_philox_restarts_devices_and_trace_kwargs(product):
         assert np.array_equal(M, M2) and np.array_equal(E, E2) and np.array_equal(o.restart_energies, o2.restart_energies)
         assert np.array_equal(o.swap_pairs, o2.swap_pairs) and np.array_equal(o.swap_accepted, o2.swap_accepted)
         assert np.array_equal(o.final_slots, o2.final_slots)
+        for a, b in zip(o.swap_log_all, o2.swap_log_all):              # every restart's log (contexts log their own ladders)
+            assert np.array_equal(a, b)
     _, M5, E5 = go(return_trace="int8")
     assert M5.dtype == np.int8 and np.array_equal(M5, M1) and np.array_equal(E5, E1)
     _, M6, E6 = go(return_trace=None)
