@@ -64,7 +64,7 @@ class NMC(Common):
         eng = self._cache.engine(self.J, self.h, R)
         m = np.sign(2 * np.random.default_rng(self.seed).random((R, N)) - 1).astype(np.int8)
         args = (lambda_start, lambda_end, lambda_reduction_factor, threshold_initial, threshold_cutoff, max_iterations, tolerance)
-        if full_update_frequency == 1:
+        if full_update_frequency == 1 and (all_clusters is not None or self.lbp == "device"):     # (lbp="host": the bit-exact host inference)
             return self._run_restarts_device(eng, inst, m, S0, S, num_NMC_cycles, temp_x, global_beta, all_clusters, *args)
         return self._run_restarts_host(eng, inst, m, S0, S, num_NMC_cycles, full_update_frequency, temp_x, global_beta,
                                        all_clusters, *args)
