@@ -265,3 +265,42 @@ def test_fused_lane_pairs_when_most_rows_are_long(product, weights):
         assert np.abs(o["energy"] - E).max() <= tol
         k = np.argmin(o["energy"], axis=1)
         assert np.array_equal(o["argmin"], k) and np.array_equal(o["argmin_state"], o["spins"][np.arange(R), k])
+
+
+def test_plan_ahead_and_own_stream_change_no_bit(product):
+    """Engine.plan_ahead (the windows of several announced sweep_philox_windows launches planned together) and a context on a
+    stream of its own (nlmc_own_stream) are scheduling decisions: states, minima, argmin states and recorded energies of a run of
+    phase launches are the same bits with and without them, and a launch that does not fit the announcement (other length)
+    still runs (its own plan replaces the announced one, the next announced launch plans again)."""
+    N, R, S, L = 1200, 5, 24, 4
+    J, h = make_instance(N, seed=41, with_h=True)
+    inst = product.Instance(J, h)
+    m0 = init_spins(R, N)
+
+    def run(ahead, own):
+        out = []
+        with product.Engine(inst, None, R, own_stream=own) as eng:
+            eng.set_spins(m0)
+            if ahead:
+                eng.plan_ahead(7, L, S, SEED)
+            for i in range(L):
+                o = eng.sweep_philox_windows(S, SEED, sweep0=7 + i * S, beta=1.7, record_stride=2, want_energy=True, want_min=True,
+                                             want_state=True, want_recorded_energy=True)
+                assert eng.fused_last_call
+                out.append(o)
+                if i == 1:                   # a call outside the announcement, in between
+                    out.append(eng.sweep_philox_windows(10, SEED, sweep0=1000, beta=0.9, want_min=True, want_state=True))
+                    eng.set_spins(o["argmin_state"])
+            if ahead:
+                assert eng._ahead.chunks_planned == 2          # all four launches at once, then again after the foreign call
+                eng.plan_ahead(None, 0, 0, 0)
+            return out, eng.get_spins(), eng.energy()
+
+    ref, s_ref, e_ref = run(False, False)
+    for ahead, own in ((True, False), (False, True), (True, True)):
+        got, s, e = run(ahead, own)
+        assert np.array_equal(s, s_ref) and np.array_equal(e, e_ref)
+        for a, b in zip(got, ref):
+            for k in ("spins", "energy", "min_energy", "argmin", "argmin_state", "energy_recorded"):
+                if k in b and b[k] is not None:
+                    assert np.array_equal(a[k], b[k]), (ahead, own, k)
