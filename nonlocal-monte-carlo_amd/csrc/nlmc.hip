@@ -344,7 +344,14 @@ int run_levelize(nlmc_ctx *c, int n_orders, const uint32_t *keys_in, int per_cha
 // worker waves of a sweep workgroup of nt threads; the others generate uniforms and warm the cache
 // (NLMC_FUSED_WORKERS: tuning knob for the 16-wave case)
 // threads of a fused sweep workgroup: at least 4 waves (3 workers + 1 helper) also for small instances
-int fused_block(int n) { return std::max(256, sweep_block(n)); }
+// (3 n / 16 threads: 6-14 % faster than the n / 8 of the sweep-by-sweep kernels between N = 2000 and N = 6000 -- more worker
+// waves per level, fewer levels split at the workgroup's width; N = 10^3 is flat from 256 to 768 threads, N >= 5500 has 1024)
+int fused_block(int n)
+{
+    if (getenv("NLMC_SWEEP_NT")) return std::max(256, sweep_block(n));
+    const int nt = ((3 * n + 15) / 16 + 63) / 64 * 64;
+    return std::min(1024, std::max(256, nt));
+}
 
 int fused_workers(int nt)
 {
