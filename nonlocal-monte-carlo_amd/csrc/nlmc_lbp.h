@@ -434,9 +434,9 @@ __global__ __launch_bounds__(NLMC_LBP_THREADS) void k_lbp(LbpArgs a)
 #define NLMC_LBP_HASH_FROM 10       // iterations of a lambda before the cycle detector starts hashing (most lambdas converge earlier)
 // The message phase of one iteration (a macro: it is instantiated with and without the state hash of the cycle detector, and a
 // lambda over this much captured state ends up in scratch memory).  Two messages at a time, the LDS reads of the next pair in
-// flight meanwhile (left to itself the scheduler interleaves all MPT message computations and spills).  Hash: a change of a message
-// by a few ulp always shows in the low mantissa bits; the multiplier is not affine in (thread, k): +1 ulp at two edges and -1 ulp
-// at the two "crossed" ones must not cancel.
+// flight meanwhile (left to itself the scheduler interleaves all MPT message computations and spills).  Hash: the low mantissa
+// word (a change by a few ulp always shows there) mixed with sign, exponent and high mantissa bits; the multiplier is not affine
+// in (thread, k): +1 ulp at two edges and -1 ulp at the two "crossed" ones must not cancel.
 #define NLMC_LBP_MESSAGE_PHASE(HASH) \
         { \
             double t_n[ILP], w_n[ILP], u_n[ILP];                                                                               \
@@ -472,7 +472,7 @@ _Pragma("unroll")                                                               
                     const double h_old = e_hm[k + j];                                                                          \
                     e_hm[k + j] = h_new[j];                                                                                    \
                     wn[E_REV(k + j)] = u_new[j];                                                                               \
-                    if (HASH) hs1 += __umul24((unsigned)__double2loint(u_new[j]), __umul24(c1, 2u * (unsigned)(k + j) + 1u));  \
+                    if (HASH) hs1 += __umul24((unsigned)__double2loint(u_new[j]) ^ __builtin_rotateleft32((unsigned)__double2hiint(u_new[j]), 13), __umul24(c1, 2u * (unsigned)(k + j) + 1u)); \
                     dh_n = fmax(dh_n, fabs(h_new[j] - h_old));                                                                 \
                     dh_d = fmax(dh_d, fabs(h_new[j]) + fabs(h_old));                                                           \
                     du_n = fmax(du_n, fabs(u_new[j] - u_o[j]));                                                                \
@@ -563,8 +563,8 @@ __global__ __launch_bounds__(NT) void k_lbp_lds(LbpArgs a)
     // deterministic function of the message array alone, so once u(t) = u(t-p), u(t-1) = u(t-1-p) and u(t-2) = u(t-2-p) hold
     // exactly, every later convergence test (a function of u(s), u(s-1), u(s-2)) repeats one that has already failed: the
     // remaining iterations cannot change the outcome and are skipped -- same marginals, same lambda count, iteration count
-    // reported as max_iterations - 1.  States are compared through a 32-bit sum over all messages of (low mantissa bits x a per-edge
-    // odd multiplier) (two v_mul_u32_u24 per message); three consecutive matches at the same period are required, so a chance
+    // reported as max_iterations - 1.  States are compared through a 32-bit sum over all messages of (24 bits mixed from both words x a
+    // per-edge odd multiplier) (two v_mul_u32_u24 per message); three consecutive matches at the same period are required, so a chance
     // collision (2^-32 each) cannot end a lambda that would have converged.  Ring of the last 64 hashes: lane j of every wave holds
     // the hash of the latest iteration == j (mod 64); periods up to 63 are seen.  On 64 C3 seeds: median iterations per seed
     // 309 -> 229; the slowest seed of a batch rarely gains (one seed in 64 finds no short cycle), batches that fill the chip do.
