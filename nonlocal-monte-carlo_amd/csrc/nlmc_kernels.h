@@ -50,11 +50,11 @@ struct LevelizeArgs {
     EdgeQ *ell32;         // [n_orders][8][n][2]  first 16 entries of row k(i) as 8 planes of 2 entries (16 B),
                           //                      zero-padded (col 0, q 0)
     int2 *head32;         // [n_orders][n]     { k | deg << 16, hq_k }
-    int32_t *ellc64;      // [n_orders][8][n]
-    double *ellv64;       // [n_orders][8][n]
+    int32_t *ellc64;      // [n_orders][NLMC_ELL_W / 4][n] planes of 4 columns (16 B)
+    double *ellv64;       // [n_orders][NLMC_ELL_W / 2][n] planes of 2 couplings (16 B)
     double *headh64;      // [n_orders][n]
 };
-#define NLMC_ELL_W 8          // packed row window, fp64 path
+#define NLMC_ELL_W 16         // packed row window, fp64 path (second half read by the waves that may hold a long row only)
 #ifndef NLMC_ELL_W32
 #define NLMC_ELL_W32 16       // packed row window, fp32 path: covers every row of a degree-6 random graph (max ~16)
 #endif
@@ -189,14 +189,22 @@ __global__ void k_levelize(LevelizeArgs a)
             }
         }
         if (a.ellc64) {
+            // 16-byte planes like the fixed-point window: columns 4 to a plane, couplings 2 to a plane -- the sweep kernel reads an
+            // item with 2 + 4 wide loads (it was 8 + 8 narrow ones: the fp64 kernel was bound by its vector-memory instructions)
             a.headh64[(size_t)o * n + pos] = a.g.h64[k];
+            static_assert(NLMC_ELL_W % 4 == 0, "columns 4 to a plane, couplings 2 to a plane");
+            int cj[NLMC_ELL_W]; double vj[NLMC_ELL_W];
 #pragma unroll
             for (int q = 0; q < NLMC_ELL_W; ++q) {
-                int cj = 0; double vj = 0.0;
-                if (q < deg) { cj = a.g.col[rs + q]; vj = a.g.val64[rs + q]; }
-                a.ellc64[((size_t)o * NLMC_ELL_W + q) * n + pos] = cj;
-                a.ellv64[((size_t)o * NLMC_ELL_W + q) * n + pos] = vj;
+                cj[q] = 0; vj[q] = 0.0;
+                if (q < deg) { cj[q] = a.g.col[rs + q]; vj[q] = a.g.val64[rs + q]; }
             }
+#pragma unroll
+            for (int pl = 0; pl < NLMC_ELL_W / 4; ++pl)
+                reinterpret_cast<int4 *>(a.ellc64)[((size_t)o * (NLMC_ELL_W / 4) + pl) * n + pos] = make_int4(cj[4 * pl], cj[4 * pl + 1], cj[4 * pl + 2], cj[4 * pl + 3]);
+#pragma unroll
+            for (int pl = 0; pl < NLMC_ELL_W / 2; ++pl)
+                reinterpret_cast<double2 *>(a.ellv64)[((size_t)o * (NLMC_ELL_W / 2) + pl) * n + pos] = make_double2(vj[2 * pl], vj[2 * pl + 1]);
         }
     }
 }
@@ -825,8 +833,20 @@ template <> struct Pf<double> {
     __device__ __forceinline__ void issue(const View &v, int i, bool valid)
     {
         const int ic = valid ? i : 0;
+        const nlmc_i4 *pc4 = reinterpret_cast<const nlmc_i4 *>(v.pc);
+        typedef double nlmc_d2 __attribute__((ext_vector_type(2)));
+        const nlmc_d2 *pv2 = reinterpret_cast<const nlmc_d2 *>(v.pv);
+        constexpr int NQ = TAIL ? NLMC_ELL_W : 8;          // entries this wave reads: the first 8, or the whole window
 #pragma unroll
-        for (int q = 0; q < NLMC_ELL_W; ++q) { cj[q] = v.pc[(size_t)q * v.n + ic]; vj[q] = v.pv[(size_t)q * v.n + ic]; }
+        for (int pl = 0; pl < NQ / 4; ++pl) {
+            const nlmc_i4 c4 = pc4[(size_t)pl * v.n + ic];
+            cj[4 * pl] = c4.x; cj[4 * pl + 1] = c4.y; cj[4 * pl + 2] = c4.z; cj[4 * pl + 3] = c4.w;
+        }
+#pragma unroll
+        for (int pl = 0; pl < NQ / 2; ++pl) {
+            const nlmc_d2 v2 = pv2[(size_t)pl * v.n + ic];
+            vj[2 * pl] = v2.x; vj[2 * pl + 1] = v2.y;
+        }
         kd_ = v.po[ic].x;
         h_ = v.ph[ic];
     }
@@ -1051,7 +1071,8 @@ __device__ __forceinline__ void run_levels(const SweepArgs &a, ChainCtx &x, cons
     // n_bar: levels [0, n_bar) end with a workgroup barrier; levels [n_bar, nl) are at most one wave wide and belong
     // to wave 0 alone, which runs them back to back (LDS executes one wave's accesses in order, so its own writes are
     // visible to its own later reads) while the other waves already prepare the next sweep (k_sweep_philox).
-    // software pipeline over levels: while level l is computed, the schedule items of level l+1 are in flight.
+    // software pipeline over levels: while level l is computed, the schedule items of level l+1 are in flight
+    // (fp64: level l+2 as well was measured -- three register sets, 170 registers -- and changed nothing: 4.9 vs 5.0e10).
     // Their addresses depend only on the level offsets (LDS), never on spin values, and the schedule was built with
     // level_cap == blockDim.x: at most one spin per thread and level.
     const int n = FUSED ? n_items : x.n, tid = x.tid;     // positions per plane of the packed schedule
