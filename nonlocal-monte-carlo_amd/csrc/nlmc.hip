@@ -1669,6 +1669,10 @@ int nlmc_pt_swap_philox(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs,
     // one lane per selected pair when the selection is planned (the in-kernel selection is written for ONE wave)
     const int swap_nt = a.plan_pairs ? std::min(256, (n_pairs + 63) / 64 * 64) : 64;
     c->sub_dirty = true;
+    if ((out_pairs || out_accepted) && n_decide < nl) {          // rows of the ladders other contexts decide: "no pair"
+        HIP_TRY(c, hipMemsetAsync(c->pt_pairs.p, 0xFF, sizeof(int32_t) * (size_t)nl * n_pairs * 2, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->pt_acc.p, 0, (size_t)nl * n_pairs, c->stream));
+    }
     hipLaunchKernelGGL(k_pt_swap, dim3(n_decide), dim3(std::max(64, swap_nt)), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     if (out_pairs || out_accepted) {
