@@ -156,7 +156,10 @@ int nlmc_pt_apply_swap(nlmc_ctx *ctx, int ladder, int slot_a, int slot_b);
 /* Device-decided round: pair selection with the law of NPT/npt.py:514-533 and Metropolis acceptance
  * u < min(1, exp(dBeta*dE)) (NPT/npt.py:668-671), Philox-keyed by (seed, round, ladder).
  *   energies_all_dev: device pointer [n_chains_global] (after the caller's all-gather) or NULL = this context's
- *   own current energies (single GPU).  out_pairs [n_ladders][n_pairs][2] slots, out_accepted [n_ladders][n_pairs]. */
+ *   own current energies: the single-GPU case, and any context whose block of chains consists of WHOLE ladders -- it then
+ *   decides its own ladders only (same keys, same bits as the context that holds every chain), other ladders' rows of the log
+ *   read "no pair" (-1, not accepted) and its copy of their slot maps is not advanced.  A block that cuts a ladder needs the
+ *   gathered energies.  out_pairs [n_ladders][n_pairs][2] slots, out_accepted [n_ladders][n_pairs]. */
 int nlmc_pt_swap_philox(nlmc_ctx *ctx, uint32_t round, uint64_t seed, int n_pairs, const double *energies_all_dev,
                         int32_t *out_pairs, uint8_t *out_accepted);
 /* Same round with the all-gathered energies handed over in HOST memory (several contexts driven by one process,
