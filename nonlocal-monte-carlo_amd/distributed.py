@@ -149,7 +149,7 @@ class LocalTempering:
     decision.  Either way the trajectory equals the single-context one bit for bit.  For one GPU per process over RCCL use
     ShardedTempering."""
 
-    def __init__(self, inst, beta_list, n_chains_global, seed, n_pairs, device_ids, precision="f32"):
+    def __init__(self, inst, beta_list, n_chains_global, seed, n_pairs, device_ids, precision="f32", engine_factory=None):
         self.G, self.seed, self.n_pairs, self.precision = int(n_chains_global), int(seed), int(n_pairs), precision
         devs = list(device_ids)
         self.parts = [block_partition(self.G, len(devs), r) for r in range(len(devs))]
@@ -160,8 +160,11 @@ class LocalTempering:
         self.engs = []
         try:
             for d, (base, count) in zip(devs, self.parts):
-                e = Engine(inst, None, count, device=int(d), chain_base=base, n_chains_global=self.G,
-                           own_stream=len(devs) > 1)
+                if engine_factory is not None:           # (tests: the CPU double of tests/fake_engine.py)
+                    e = engine_factory(inst, count, base, self.G)
+                else:
+                    e = Engine(inst, None, count, device=int(d), chain_base=base, n_chains_global=self.G,
+                               own_stream=len(devs) > 1)
                 e.pt_init(np.asarray(beta_list, dtype=np.float64))
                 self.engs.append(e)
         except Exception:

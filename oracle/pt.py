@@ -9,7 +9,9 @@ LOG2E = 1.4426950408889634
 TAG_SWAP, TAG_PAIR, TAG_ICM = 3, 4, 5
 
 
-def swap_round(E, slot_of_chain, betas, ladder_len, n_pairs, rnd, seed):
+def swap_round(E, slot_of_chain, betas, ladder_len, n_pairs, rnd, seed, ladder0=0):
+    """ladder0: global index of the first ladder of the block handed in (the Philox key of a ladder is its GLOBAL index: a
+    context that owns whole ladders decides them alone, csrc/nlmc_pt_icm.h: k_pt_swap)."""
     lo, hi = int(seed) & 0xFFFFFFFF, int(seed) >> 32
     G = len(E)
     slots = np.array(slot_of_chain, dtype=np.int32).copy()
@@ -23,13 +25,13 @@ def swap_round(E, slot_of_chain, betas, ladder_len, n_pairs, rnd, seed):
         for p in range(n_pairs):
             if not avail:
                 raise ValueError("Cannot find non-overlapping pairs.")
-            r = int(philox(p, rnd, g, TAG_PAIR, lo, hi)[0])
+            r = int(philox(p, rnd, ladder0 + g, TAG_PAIR, lo, hi)[0])
             i = avail[(r * len(avail)) >> 32]
             sel.append(i)
             avail = [q for q in avail if abs(q - i) > 1]
         for p, i in enumerate(sel):
             ca, cb = chain_of_slot[i], chain_of_slot[i + 1]
-            w = philox(p, rnd, g, TAG_SWAP, lo, hi)
+            w = philox(p, rnd, ladder0 + g, TAG_SWAP, lo, hi)
             u = ((int(w[0]) >> 5) * 67108864.0 + (int(w[1]) >> 6)) / 9007199254740992.0
             z = ((betas[i + 1] - betas[i]) * (E[cb] - E[ca])) * LOG2E
             acc = u < lib().nlo_exp2_f64(z)

@@ -20,7 +20,7 @@ class OracleEngine:
 
     def pt_init(self, betas):
         self.betas = np.asarray(betas, float)
-        self.L = len(self.betas)
+        self.L = self.ladder_len = len(self.betas)
         self.slots = (np.arange(self.G) % self.L).astype(np.int32)
 
     def set_spins(self, s):
@@ -60,10 +60,23 @@ class OracleEngine:
     def pt_swap_philox(self, rnd, seed, n_pairs, energies_all_dev=None, want_log=True):
         if energies_all_dev:
             E = np.array((ctypes.c_double * self.G).from_address(int(energies_all_dev))[:])
-        else:
-            assert self.n_chains == self.G
+        elif self.n_chains == self.G:
             E = self._energies()
+        else:
+            # a context that owns whole ladders decides them from its own energies (include/nlmc.h: nlmc_pt_swap_philox)
+            assert self.chain_base % self.L == 0 and self.n_chains % self.L == 0
+            b, e = self.chain_base, self.chain_base + self.n_chains
+            self.slots[b:e], pairs, acc = opt.swap_round(self._energies(), self.slots[b:e], self.betas, self.L, n_pairs, rnd, seed,
+                                                         ladder0=b // self.L)
+            return pairs, acc
         self.slots, pairs, acc = opt.swap_round(E, self.slots, self.betas, self.L, n_pairs, rnd, seed)
+        return pairs, acc
+
+    def energy_tracked(self):
+        return self._energies()
+
+    def pt_swap_philox_host(self, rnd, seed, n_pairs, energies_all, want_log=False):
+        self.slots, pairs, acc = opt.swap_round(np.asarray(energies_all, float), self.slots, self.betas, self.L, n_pairs, rnd, seed)
         return pairs, acc
 
     def pt_slots(self):

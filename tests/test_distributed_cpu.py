@@ -109,3 +109,35 @@ def test_fused_window_choice():
     P = load_product()
     fw = P.engine.fused_window
     assert fw(10) == 10 and fw(100) == 50 and fw(64) == 64 and fw(97) == 0 and fw(2) == 0 and fw(128) == 64 and fw(9) == 9
+
+
+def test_local_tempering_contexts_of_whole_and_of_cut_ladders_give_the_same_bits():
+    """distributed.LocalTempering (one process, several contexts) on the CPU double: 4 ladders of 4 slots in 1 context, in 2 and
+    4 contexts (whole ladders: every context decides its own ladders' swaps, nothing passes through the host) and in 8 contexts
+    (every ladder cut in two: tracked energies gathered on the host) -- same spins, same slots after every round."""
+    from fake_engine import OracleEngine
+    P = load_product()
+    J, h = make_instance(N, seed=3, with_h=True, gaussian=True)
+    inst = P.Instance(J, h)
+    Lq, NLq = 4, 4
+    G = Lq * NLq
+    betas = np.geomspace(0.3, 2.5, Lq)
+    m0 = init_spins(G, N)
+
+    def drive(k):
+        lt = P.distributed.LocalTempering(inst, betas, G, SEED, 1, [0] * k, engine_factory=lambda i, n, b, g: OracleEngine(i, n, b, g))
+        assert lt.whole_ladders == (k <= NLq)
+        lt.set_spins(m0)
+        hist = []
+        for _ in range(ROUNDS):
+            lt.round(S)
+            hist.append(lt.slots().copy())
+        out = lt.gather_spins(), np.array(hist)
+        lt.close()
+        return out
+    ref_s, ref_h = drive(1)
+    assert not np.array_equal(ref_h[-1], np.arange(G) % Lq)
+    for k in (2, 4, 8):
+        s_, h_ = drive(k)
+        assert np.array_equal(s_, ref_s), k
+        assert np.array_equal(h_, ref_h), k
