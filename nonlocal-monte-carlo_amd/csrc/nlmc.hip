@@ -52,6 +52,7 @@ struct nlmc_ctx {
     int n_chains = 0, chain_base = 0, n_chains_global = 0;
     int escale = 32;
     bool compact16 = false;            // every Jq fits 16 bits: fused-window schedules use 4-byte entries
+    bool f64_pack16 = false;           // ... and every J equals Jq 2^-qs exactly: the fp64 schedule window holds 16-bit columns / Jq
     bool sign8 = false;                // every Jq is +-1: fused-window schedules may use 2-byte entries (NLMC_FMT_ADDR)
     // diagnostic switches read ONCE, at nlmc_create (NLMC_NO_WARM, NLMC_FUSED_NOPRIO, NLMC_NO_DBUF, NLMC_DBG_FLAGS): not
     // looked up again on the launch path
@@ -66,7 +67,7 @@ struct nlmc_ctx {
     bool has_diag = false;
     bool has_zero_vals = false;   // a stored entry is 0.0 (or underflows to 0 in fp32)
     size_t lds_opt[48] = {};      // dynamic-LDS opt-in already granted, one slot per kernel: 0 k_levelize, 1 k_icm_components,
-                                  // 2..7 sweep-by-sweep kernels, 8..15 k_sweep_fused variants, 16 k_levelize_fused, 17..20 k_lbp_lds, 21 k_icm_round, 24..47 k_sweep_fused variants
+                                  // 2..7 sweep-by-sweep kernels, 8..15 k_sweep_fused variants, 16 k_levelize_fused, 17..20 k_lbp_lds, 21 k_icm_round, 22..23 packed fp64 sweep kernels, 24..47 k_sweep_fused variants
 
     DevBuf<int32_t> rowptr, col;
     DevBuf<double> val64, h64;
@@ -329,7 +330,7 @@ int run_levelize(nlmc_ctx *c, int n_orders, const uint32_t *keys_in, int per_cha
     a.nlev = sc.nlev.p;
     a.hi_max = sc.hi_max.p;
     if (ell_mode == 1) { a.ell32 = sc.ell32.p; a.head32 = sc.head32.p; }
-    if (ell_mode == 2) { a.ellc64 = sc.ellc64.p; a.ellv64 = sc.ellv64.p; a.headh64 = sc.headh64.p; }
+    if (ell_mode == 2) { a.ellc64 = sc.ellc64.p; a.ellv64 = sc.ellv64.p; a.headh64 = sc.headh64.p; a.pack16 = c->f64_pack16 ? 1 : 0; }
     const size_t lds_one = (size_t)(c->n + 2) * 4 + (((size_t)c->n * 2 + 3) / 4) * 4;
     const size_t lds_two = lds_one + (size_t)(c->n + 2) * 4;
     a.two_sided = lds_two + 16 <= (size_t)150 * 1024;
@@ -714,11 +715,13 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
     const int lds_red_off = cur;
     const size_t lds = (size_t)cur + 16;
     const void *kfun = stream_mode ? reinterpret_cast<const void *>(k_sweep_stream)
-                       : f64 ? (c->has_diag ? reinterpret_cast<const void *>(k_sweep_philox<double, true>)
-                                            : reinterpret_cast<const void *>(k_sweep_philox<double, false>))
+                       : f64 ? (c->f64_pack16 ? (c->has_diag ? reinterpret_cast<const void *>(k_sweep_philox<double, true, true>)
+                                                             : reinterpret_cast<const void *>(k_sweep_philox<double, false, true>))
+                                              : (c->has_diag ? reinterpret_cast<const void *>(k_sweep_philox<double, true>)
+                                                             : reinterpret_cast<const void *>(k_sweep_philox<double, false>)))
                              : (c->has_diag ? reinterpret_cast<const void *>(k_sweep_philox<float, true>)
                                             : reinterpret_cast<const void *>(k_sweep_philox<float, false>));
-    const int kslot = stream_mode ? 2 : (f64 ? 3 : 5) + (c->has_diag ? 1 : 0);
+    const int kslot = stream_mode ? 2 : (f64 ? (c->f64_pack16 ? 22 : 3) : 5) + (c->has_diag ? 1 : 0);
     { int rc = ensure_lds(c, kslot, kfun, lds); if (rc) return rc; }
 
     for (int t0 = 0; t0 < n_sweeps; t0 += W) {
@@ -774,6 +777,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         a.escale = c->escale;
         a.eshift = c->escale - c->qs;
         a.qinv = std::ldexp(1.0f, -c->qs);
+        a.qinv64 = std::ldexp(1.0, -c->qs);
         a.etrace = o.out_energy ? c->etrace.p : nullptr;
         a.trace_sweeps = n_sweeps;
         a.t0 = t0;
@@ -792,6 +796,10 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         a.lds_flags_off = lds_flags_off; a.lds_u_off = lds_u_off; a.lds_loff_off = lds_loff_off; a.lds_red_off = lds_red_off;
         if (stream_mode)
             hipLaunchKernelGGL(k_sweep_stream, dim3(R), dim3(nt), lds, c->cur, a);
+        else if (f64 && c->f64_pack16 && c->has_diag)
+            hipLaunchKernelGGL((k_sweep_philox<double, true, true>), dim3(R), dim3(nt), lds, c->cur, a);
+        else if (f64 && c->f64_pack16)
+            hipLaunchKernelGGL((k_sweep_philox<double, false, true>), dim3(R), dim3(nt), lds, c->cur, a);
         else if (f64 && c->has_diag)
             hipLaunchKernelGGL((k_sweep_philox<double, true>), dim3(R), dim3(nt), lds, c->cur, a);
         else if (f64)
@@ -986,12 +994,15 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
     std::vector<int32_t> hq((size_t)n);
     bool fits16 = n <= 65535;        // compact schedule entries of the fused windows: col << 16 | (Jq & 0xFFFF)
     bool pm1 = true;                 // sign format: col | (Jq < 0) << 15
+    bool exact_q = true;             // every J is Jq 2^-qs exactly (packed fp64 schedule window)
     for (int64_t e = 0; e < nnz; ++e) {
         e32[e].col = colidx[e]; e32[e].q = (int32_t)rq(vals[e], qs);
         if (e32[e].q > 32767 || e32[e].q < -32768) fits16 = false;
+        if (std::ldexp((double)e32[e].q, -qs) != vals[e]) exact_q = false;
         if (e32[e].q != 1 && e32[e].q != -1) pm1 = false;
     }
     c->compact16 = fits16 && !getenv("NLMC_NO_COMPACT");
+    c->f64_pack16 = fits16 && exact_q && n <= 65535 && !getenv("NLMC_NO_PACK64");
     c->sign8 = c->compact16 && pm1 && nnz > 0 && !getenv("NLMC_NO_SIGNFMT");
     c->knob_no_warm = getenv("NLMC_NO_WARM") != nullptr;
     c->knob_no_prio = getenv("NLMC_FUSED_NOPRIO") != nullptr;

@@ -53,6 +53,7 @@ struct LevelizeArgs {
     int32_t *ellc64;      // [n_orders][NLMC_ELL_W / 4][n] planes of 4 columns (16 B)
     double *ellv64;       // [n_orders][NLMC_ELL_W / 2][n] planes of 2 couplings (16 B)
     double *headh64;      // [n_orders][n]
+    int pack16;           // fp64 path, couplings exactly Jq 2^-qs with |Jq| < 2^15: 16-bit columns and Jq, 4 planes in ellc64
 };
 #define NLMC_ELL_W 16         // packed row window, fp64 path (second half read by the waves that may hold a long row only)
 #ifndef NLMC_ELL_W32
@@ -188,7 +189,27 @@ __global__ void k_levelize(LevelizeArgs a)
                 reinterpret_cast<int4 *>(a.ell32)[((size_t)o * (NLMC_ELL_W32 / 2) + q / 2) * n + pos] = pk;
             }
         }
-        if (a.ellc64) {
+        if (a.ellc64 && a.pack16) {
+            // packed fp64 window (Pf<double, true>): plane 0 = columns 0-7, plane 1 = Jq 0-7, planes 2 / 3 = entries 8-15, 16 bits
+            // each -- 48 instead of 112 bytes for a row of <= 8 entries.  Every chain reads the whole schedule: at 112 bytes
+            // the 32 CUs of an XCD pulled 1.8 MB per level through its L2, which is what a level then waited for.
+            a.headh64[(size_t)o * n + pos] = a.g.h64[k];
+            unsigned cw[NLMC_ELL_W / 2], qw[NLMC_ELL_W / 2];
+#pragma unroll
+            for (int q = 0; q < NLMC_ELL_W; q += 2) {
+                EdgeQ e0{0, 0}, e1{0, 0};
+                if (q < deg) e0 = a.g.edge32[rs + q];
+                if (q + 1 < deg) e1 = a.g.edge32[rs + q + 1];
+                cw[q / 2] = ((unsigned)e0.col & 0xFFFFu) | ((unsigned)e1.col << 16);
+                qw[q / 2] = ((unsigned)e0.q & 0xFFFFu) | ((unsigned)e1.q << 16);
+            }
+            uint4 *dst = reinterpret_cast<uint4 *>(a.ellc64);
+#pragma unroll
+            for (int hf = 0; hf < NLMC_ELL_W / 8; ++hf) {
+                dst[((size_t)o * (NLMC_ELL_W / 4) + 2 * hf) * n + pos] = make_uint4(cw[4 * hf], cw[4 * hf + 1], cw[4 * hf + 2], cw[4 * hf + 3]);
+                dst[((size_t)o * (NLMC_ELL_W / 4) + 2 * hf + 1) * n + pos] = make_uint4(qw[4 * hf], qw[4 * hf + 1], qw[4 * hf + 2], qw[4 * hf + 3]);
+            }
+        } else if (a.ellc64) {
             // 16-byte planes like the fixed-point window: columns 4 to a plane, couplings 2 to a plane -- the sweep kernel reads an
             // item with 2 + 4 wide loads (it was 8 + 8 narrow ones: the fp64 kernel was bound by its vector-memory instructions)
             a.headh64[(size_t)o * n + pos] = a.g.h64[k];
@@ -559,6 +580,7 @@ struct SweepArgs {
     const int2 *head32;
     const int32_t *ellc64;
     const double *ellv64, *headh64;
+    double qinv64;                // 2^-qs (packed fp64 window: J = Jq 2^-qs exactly)
     int per_chain;            // order id = c * n_sweeps + t, else t
     int n_sweeps;             // sweeps in this launch
     uint32_t sweep0;          // global index of sweep 0 of this launch
@@ -762,11 +784,12 @@ __global__ void k_sweep_stream(SweepArgs a)
 }
 
 // ---- PHILOX mode (throughput) ---------------------------------------------------------------------------
-template <typename T> struct Pf;            // one schedule item: k, degree, h_k and the packed window of row k
+template <typename T, bool PK = false> struct Pf;   // one schedule item: k, degree, h_k and the packed window of row k
+                                                    // (PK: fp64 path with 16-bit columns / couplings)
 typedef int nlmc_i4 __attribute__((ext_vector_type(4)));
 typedef int nlmc_i2 __attribute__((ext_vector_type(2)));
 typedef float nlmc_f4 __attribute__((ext_vector_type(4)));
-template <> struct Pf<float> {
+template <> struct Pf<float, false> {
     static constexpr int W = NLMC_ELL_W32;
     nlmc_i4 pk[W / 2];            // plane q: { col(2q), Jq(2q), col(2q+1), Jq(2q+1) }   (fixed-point couplings)
     nlmc_i2 hd;                   // { k | deg << 16, hq_k }
@@ -809,7 +832,7 @@ template <> struct Pf<float> {
     __device__ __forceinline__ int val(int q) const { return (q & 1) ? pk[q >> 1].w : pk[q >> 1].y; }
     static __device__ __forceinline__ void tail(const CsrDev &g, int e, int &cj, int &vj) { const EdgeQ t = g.edge32[e]; cj = t.col; vj = t.q; }
 };
-template <> struct Pf<double> {
+template <> struct Pf<double, false> {
     static constexpr int W = NLMC_ELL_W;
     int cj[NLMC_ELL_W];
     double vj[NLMC_ELL_W];
@@ -857,6 +880,51 @@ template <> struct Pf<double> {
     static __device__ __forceinline__ void tail(const CsrDev &g, int e, int &c, double &v) { c = g.col[e]; v = g.val64[e]; }
 };
 
+template <> struct Pf<double, true> {
+    static constexpr int W = NLMC_ELL_W;
+    nlmc_i4 pc[NLMC_ELL_W / 8], pq[NLMC_ELL_W / 8];   // 8 columns / 8 couplings per 16-byte plane
+    int kd_;
+    double h_, qi;
+    struct View {
+        const nlmc_i4 *pp;
+        const double *ph;
+        const int2 *po;
+        int n;
+        double qi;
+        __device__ __forceinline__ void bind(const SweepArgs &a, size_t oid, int n_)
+        {
+            n = n_;
+            pp = reinterpret_cast<const nlmc_i4 *>(a.ellc64 + oid * NLMC_ELL_W * n);
+            ph = a.headh64 + oid * n;
+            po = a.ord2 + oid * n;
+            qi = a.qinv64;
+        }
+    };
+    template <bool TAIL>
+    __device__ __forceinline__ void issue(const View &v, int i, bool valid)
+    {
+        const int ic = valid ? i : 0;
+#pragma unroll
+        for (int hf = 0; hf < (TAIL ? NLMC_ELL_W / 8 : 1); ++hf) {
+            pc[hf] = v.pp[(size_t)(2 * hf) * v.n + ic];
+            pq[hf] = v.pp[(size_t)(2 * hf + 1) * v.n + ic];
+        }
+        kd_ = v.po[ic].x;
+        h_ = v.ph[ic];
+        qi = v.qi;
+    }
+    static __device__ __forceinline__ int word(const nlmc_i4 &w, int j) { return j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w; }
+    __device__ __forceinline__ int kd() const { return kd_; }
+    __device__ __forceinline__ double h() const { return h_; }
+    __device__ __forceinline__ int col(int q) const { return (int)(((unsigned)word(pc[q >> 3], (q & 7) >> 1) >> ((q & 1) * 16)) & 0xFFFFu); }
+    __device__ __forceinline__ double val(int q) const     // Jq 2^-qs: exact (a power-of-two scale)
+    {
+        const int w = word(pq[q >> 3], (q & 7) >> 1);
+        return (double)((q & 1) ? (w >> 16) : (int)(short)(w & 0xFFFF)) * qi;
+    }
+    static __device__ __forceinline__ void tail(const CsrDev &g, int e, int &c, double &v) { c = g.col[e]; v = g.val64[e]; }
+};
+
 // -(ds) * x * 2^escale rounded to the nearest integer (fp64 paths)
 __device__ __forceinline__ long long fixed_delta_slow(double xt, int ds, double esc) { return __double2ll_rn(-(double)ds * xt * esc); }
 
@@ -870,8 +938,8 @@ template <bool DIAG, bool TAIL, bool FUSED>
 __device__ __forceinline__ void update_spin_q(const SweepArgs &a, ChainCtx &x, const float *wt, const Pf<float> &pf, size_t oid, int i,
                                               float cq0, float cq1);
 
-template <typename T, bool DIAG, bool TAIL, bool FUSED = false>
-__device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, const T *ur, const Pf<T> &pf, size_t oid, int i,
+template <typename T, bool DIAG, bool TAIL, bool FUSED = false, bool PK = false>
+__device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, const T *ur, const Pf<T, PK> &pf, size_t oid, int i,
                                             T cb0, T cb1, double esc)
 {
     if constexpr (sizeof(T) == 4) {            // "f32" throughput mode: fixed-point field, threshold test
@@ -891,7 +959,7 @@ __device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, con
     long long u0, u1, u2, u3, u4;
     NLMC_CLK(u0)
 #endif
-    constexpr int W = Pf<T>::W;
+    constexpr int W = Pf<T, PK>::W;
     // The spins sit at LDS offset 0 (first region of the dynamic LDS, no static LDS in this kernel -- checked at
     // kernel entry), so a column index IS the LDS address: no per-read base add.
     typedef const int8_t __attribute__((address_space(3))) *lds_i8;
@@ -923,7 +991,7 @@ __device__ __forceinline__ void update_spin(const SweepArgs &a, ChainCtx &x, con
         const int rs = FUSED ? a.g.rowptr[k] : a.ord2[oid * x.n + i].y;
         for (int e = W; e < deg; ++e) {
             int j; T v;
-            Pf<T>::tail(a.g, rs + e, j, v);
+            Pf<T, PK>::tail(a.g, rs + e, j, v);
             const T sv = (T)s[j];
             xs = fma_rn(v, sv, xs);
             if (DIAG && j == k) xd = fma_rn(v, sv, xd);
@@ -1062,7 +1130,7 @@ __device__ __forceinline__ void fill_uniforms(double *ur, int n, uint32_t tt, ui
 // therefore also loads / folds the second half of the 16-entry row window.
 struct NoGen { __device__ __forceinline__ void operator()(int) const {} };
 
-template <typename T, bool DIAG, bool TAIL, bool FUSED = false, typename Gen = NoGen>
+template <typename T, bool DIAG, bool TAIL, bool FUSED = false, typename Gen = NoGen, bool PK = false>
 __device__ __forceinline__ void run_levels(const SweepArgs &a, ChainCtx &x, const T *ur, const int *loff, size_t so, int nl,
                                            int n_bar, T cb0, T cb1, double esc, int n_items = 0, Gen gen = Gen())
 {
@@ -1076,13 +1144,13 @@ __device__ __forceinline__ void run_levels(const SweepArgs &a, ChainCtx &x, cons
     // Their addresses depend only on the level offsets (LDS), never on spin values, and the schedule was built with
     // level_cap == blockDim.x: at most one spin per thread and level.
     const int n = FUSED ? n_items : x.n, tid = x.tid;     // positions per plane of the packed schedule
-    Pf<T> pfa, pfb;                // ping-pong (manual 2x unroll: no register rotation)
+    Pf<T, PK> pfa, pfb;                // ping-pong (manual 2x unroll: no register rotation)
     bool va, vb;                   // lane has an item in the level held by pfa / pfb
     int ia, ib;
-    typename Pf<T>::View view;
+    typename Pf<T, PK>::View view;
     view.bind(a, so, n);
     int lo_next = loff[0], hi_next = loff[min(1, nl)];      // offsets of the level the next fetch will load
-    auto fetch = [&](int l, Pf<T> &p, bool &valid, int &ic) {
+    auto fetch = [&](int l, Pf<T, PK> &p, bool &valid, int &ic) {
         const int i = lo_next + tid;
         valid = (l < nl) && (i < hi_next);
         ic = valid ? i : 0;
@@ -1115,17 +1183,17 @@ __device__ __forceinline__ void run_levels(const SweepArgs &a, ChainCtx &x, cons
 #endif
 #if defined(NLMC_V_FETCH_AFTER)
 #define NLMC_STAGE(lv, pnext, vnext, inext, pcur, vcur, icur) \
-    if (vcur) update_spin<T, DIAG, TAIL, FUSED>(a, x, ur, pcur, so, icur, cb0, cb1, esc); \
+    if (vcur) update_spin<T, DIAG, TAIL, FUSED, PK>(a, x, ur, pcur, so, icur, cb0, cb1, esc); \
     fetch((lv) + 1, pnext, vnext, inext); gen(lv);
 #elif defined(NLMC_V_GEN_AFTER)
 #define NLMC_STAGE(lv, pnext, vnext, inext, pcur, vcur, icur) \
     fetch((lv) + 1, pnext, vnext, inext); \
-    if (vcur) update_spin<T, DIAG, TAIL, FUSED>(a, x, ur, pcur, so, icur, cb0, cb1, esc); \
+    if (vcur) update_spin<T, DIAG, TAIL, FUSED, PK>(a, x, ur, pcur, so, icur, cb0, cb1, esc); \
     gen(lv);
 #else
 #define NLMC_STAGE(lv, pnext, vnext, inext, pcur, vcur, icur) \
     fetch((lv) + 1, pnext, vnext, inext); gen(lv); \
-    if (vcur) update_spin<T, DIAG, TAIL, FUSED>(a, x, ur, pcur, so, icur, cb0, cb1, esc);
+    if (vcur) update_spin<T, DIAG, TAIL, FUSED, PK>(a, x, ur, pcur, so, icur, cb0, cb1, esc);
 #endif
 #ifdef NLMC_STAMPS
     // diagnostic build: per-wave cycle split of a level -- work (fetch issue + side job + update) vs barrier wait
@@ -1162,7 +1230,7 @@ __device__ __forceinline__ void run_levels(const SweepArgs &a, ChainCtx &x, cons
     for (; l < n_bar; ++l) { gen(l); __syncthreads(); }   // retired: this wave has no item in any remaining barrier level
 }
 
-template <typename T, bool DIAG>
+template <typename T, bool DIAG, bool PK = false>
 __global__ __launch_bounds__(sizeof(T) == 8 ? 512 : DIAG ? 768 : 1024) void k_sweep_philox(SweepArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -1229,9 +1297,9 @@ __global__ __launch_bounds__(sizeof(T) == 8 ? 512 : DIAG ? 768 : 1024) void k_sw
             // waves whose lanes can hold one run the variant that also prefetches the second half of the row window.
             // Two copies of the level loop, chosen per wave and sweep, keep the number of loads per stage STATIC in
             // each copy (so hipcc emits counted vmcnt waits); both copies execute the same n_bar barriers.
-            const bool role_long = (Pf<T>::W > 8) && ((tid & ~63) < a.hi_max[oid]);
-            if (role_long) run_levels<T, DIAG, true>(a, x, ur, loff, so, nl, n_bar, cb0, cb1, esc);
-            else run_levels<T, DIAG, false>(a, x, ur, loff, so, nl, n_bar, cb0, cb1, esc);
+            const bool role_long = (Pf<T, PK>::W > 8) && ((tid & ~63) < a.hi_max[oid]);
+            if (role_long) run_levels<T, DIAG, true, false, NoGen, PK>(a, x, ur, loff, so, nl, n_bar, cb0, cb1, esc);
+            else run_levels<T, DIAG, false, false, NoGen, PK>(a, x, ur, loff, so, nl, n_bar, cb0, cb1, esc);
 
             // While wave 0 finishes the narrow tail of this sweep, the other waves prepare the next one in the second
             // set of LDS buffers: its uniforms (the Philox work of a whole sweep) and its level offsets.
@@ -1256,11 +1324,11 @@ __global__ __launch_bounds__(sizeof(T) == 8 ? 512 : DIAG ? 768 : 1024) void k_sw
             for (int l = 0; l < nl; ++l) {
                 const int lo = off[l], hi = off[l + 1];
                 for (int i = lo + tid; i < hi; i += nt) {
-                    Pf<T> pe;
-                    typename Pf<T>::View vw;
+                    Pf<T, PK> pe;
+                    typename Pf<T, PK>::View vw;
                     vw.bind(a, so, n);
                     pe.template issue<true>(vw, i, true);
-                    update_spin<T, DIAG, true>(a, x, ur, pe, so, i, cb0, cb1, esc);
+                    update_spin<T, DIAG, true, false, PK>(a, x, ur, pe, so, i, cb0, cb1, esc);
                 }
                 __syncthreads();
             }
