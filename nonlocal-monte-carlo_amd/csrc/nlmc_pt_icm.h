@@ -170,6 +170,25 @@ __device__ __forceinline__ int icm_find(int32_t *lab, int k)
     return r;                                          // root (atomicMin on lab[k] as well) can never be overwritten
 }
 
+__device__ __forceinline__ int icm_find_halving(int32_t *lab, int k)
+{
+    // (k_icm_round only: its hooks are compare-and-swaps that succeed on true roots alone, so a node that has a parent is never
+    // written by a hook and the plain stores below cannot lose one.)  Root of k with path halving on the way (every node visited is re-pointed at its grandparent, as in ECL-CC): parents always
+    // have SMALLER indices than their children and a node that has a parent never becomes a root again, so a racing store can
+    // only replace one ancestor by another -- the forest stays a forest -- and the long chains that "hook the larger root under
+    // the smaller" leaves behind in a giant component are halved by every find that walks them (k_icm_round spent 53 of 83
+    // thousand cycles in its merge pass with compression of the start node only).
+    int prev = k, cur = lab[k];
+    if (cur == k) return k;
+    int next;
+    while (cur > (next = lab[cur])) {
+        lab[prev] = next;
+        prev = cur;
+        cur = next;
+    }
+    return cur;
+}
+
 __global__ void k_icm_components(IcmArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -315,13 +334,13 @@ __global__ __launch_bounds__(1024) void k_icm_round(IcmRoundArgs a)
     const bool converged = true;
     auto merge = [&](int k, int j) {
         if (j >= k || lab[j] == INT_MAX) return;           // (j == k: the padding of the adjacency table / the diagonal)
-        int ra = icm_find(lab, k), rb = icm_find(lab, j);
+        int ra = icm_find_halving(lab, k), rb = icm_find_halving(lab, j);
         while (ra != rb) {
             if (ra < rb) { const int t = ra; ra = rb; rb = t; }            // ra > rb
             const int old = atomicCAS(&lab[ra], ra, rb);
             if (old == ra) break;                                          // ra was a root and now hangs under rb
-            ra = icm_find(lab, old);
-            rb = icm_find(lab, rb);
+            ra = icm_find_halving(lab, old);
+            rb = icm_find_halving(lab, rb);
         }
     };
     if (a.adj) {
@@ -361,12 +380,12 @@ __global__ __launch_bounds__(1024) void k_icm_round(IcmRoundArgs a)
     int cnt = 0;
     for (int idx = tid; idx < nc; idx += nt) {
         const int k = (int)cand[idx];
-        const int l = icm_find(lab, k);
+        const int l = icm_find_halving(lab, k);
         cnt += (l == k);
     }
     if (cnt) atomicAdd(&nroots, cnt);
     __syncthreads();
-    for (int idx = tid; idx < nc; idx += nt) { const int k = (int)cand[idx]; lab[k] = icm_find(lab, k); }
+    for (int idx = tid; idx < nc; idx += nt) { const int k = (int)cand[idx]; lab[k] = icm_find_halving(lab, k); }
     __syncthreads();
     const int ncomp = converged ? nroots : -1;
     if (ncomp <= 0) {                       // nothing to move (identical or opposite... no disagreement), or not converged
