@@ -711,7 +711,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
                       !c->knob_no_dbuf;
     cur += u_bytes * (dbuf ? 2 : 1);
     const int lds_loff_off = cur;
-    if (!stream_mode) cur += NLMC_LCAP * 4 * (dbuf ? 2 : 1);
+    cur += NLMC_LCAP * 4 * (dbuf ? 2 : 1);               // (stream mode: one copy, the level offsets of the running sweep)
     const int lds_red_off = cur;
     const size_t lds = (size_t)cur + 16;
     const void *kfun = stream_mode ? reinterpret_cast<const void *>(k_sweep_stream)

@@ -734,11 +734,18 @@ __global__ void k_sweep_stream(SweepArgs a)
     extern __shared__ __align__(16) unsigned char lds_raw[];
     ChainCtx x;
     chain_load(a, lds_raw, x);
-    const int n = x.n, tid = x.tid, nt = x.nt, c = x.c;
+    const int n = x.n, tid = x.tid, c = x.c;
     int8_t *s = x.s;
     const uint8_t *fl = x.fl;
     const double esc = __longlong_as_double((long long)(1023 + a.escale) << 52);   // 2^escale
 
+    // One item per thread and level (k_levelize splits levels at the workgroup's width).  Software pipeline over the levels of a
+    // sweep (round 3; the loop used to chase ord -> col / val -> spin one dependent global load after the other, 1 + degree
+    // round trips per level: 52 us per sweep of one chain at N = 10^3): while level l is computed, the first 8 entries of the
+    // rows of level l+1 (+ their uniform and field term) and the schedule entries of level l+2 are in flight.  The sums keep
+    // the reference's association: entries in CSR order, one rounding per term.  (col / val64 are allocated with 16 padding
+    // entries, so the unconditional 8-entry reads of a short last row stay inside the arrays.)
+    struct Row { int cj[8]; double vj[8]; double u, h; };
     for (int t = 0; t < a.n_sweeps; ++t) {
         const int oid = a.per_chain ? (c * a.n_sweeps + t) : t;
         const int2 *__restrict__ ord = a.ord2 + (size_t)oid * n;
@@ -746,30 +753,71 @@ __global__ void k_sweep_stream(SweepArgs a)
         const int nl = a.nlev[oid];
         const double beta = a.tab[(size_t)c * a.tab_cs + (size_t)t * a.tab_ss];
         const double *__restrict__ ut = a.ustream + ((size_t)c * a.n_sweeps + t) * n;
+        // level offsets of the sweep in LDS (a scalar load per level would sit in the same counter as the LDS reads of the
+        // update: every wait for a spin would wait for it, too)
+        int *loff = reinterpret_cast<int *>(lds_raw + a.lds_loff_off);
+        const bool in_lds = nl < NLMC_LCAP;
+        if (in_lds) {
+            __syncthreads();                               // (the previous sweep's readers are done)
+            for (int l = tid; l <= nl; l += x.nt) loff[l] = off[l];
+            __syncthreads();
+        }
+        auto item_at = [&](int l, int2 &en, bool &valid) __attribute__((always_inline)) {
+            const int lc = min(l, max(nl - 1, 0));
+            const int lo = in_lds ? loff[lc] : off[lc], hi = in_lds ? loff[lc + 1] : off[lc + 1];
+            valid = (l < nl) && (lo + tid < hi);
+            en = ord[valid ? lo + tid : 0];
+        };
+        auto row_of = [&](const int2 &en, Row &r) __attribute__((always_inline)) {
+            const int k = en.x & 0xFFFF, rs = en.y;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { r.cj[q] = a.g.col[rs + q]; r.vj[q] = a.g.val64[rs + q]; }
+            r.u = ut[k];
+            r.h = a.g.h64[k];
+        };
+        int2 enA, enB;
+        bool vA, vB;
+        Row rA;
+        item_at(0, enA, vA);
+        row_of(enA, rA);
+        item_at(1, enB, vB);
         for (int l = 0; l < nl; ++l) {
-            const int lo = off[l], hi = off[l + 1];
-            for (int i = lo + tid; i < hi; i += nt) {
-                const int2 en = ord[i];
-                const int k = en.x & 0xFFFF, rs = en.y, re = en.y + (int)((unsigned)en.x >> 16);
+            int2 enC;
+            bool vC;
+            Row rB;
+            item_at(l + 2, enC, vC);
+            row_of(enB, rB);
+            if (vA) {
+                const int k = enA.x & 0xFFFF, rs = enA.y, deg = (int)((unsigned)enA.x >> 16), re = rs + deg;
                 const unsigned f = fl ? (unsigned)fl[k] : 0u;
                 const int so = (int)s[k];
+                double sj[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sj[q] = (double)s[rA.cj[q]];      // (entries past the row: some valid column, unused)
                 double xs = 0.0, xd = 0.0;   // xd: diagonal term, excluded from the energy delta
-                for (int e = rs; e < re; ++e) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const double tm = rA.vj[q] * sj[q];
+                    if (q < deg) { xs += tm; if (rA.cj[q] == k) xd += tm; }
+                }
+                for (int e = rs + 8; e < re; ++e) {
                     const int j = a.g.col[e];
                     const double tm = a.g.val64[e] * (double)s[j];
                     xs += tm;
                     if (j == k) xd += tm;
                 }
-                const double hk = a.g.h64[k];
+                const double hk = rA.h;
                 const double x_true = (xs - xd) + hk;   // field of the UNMODIFIED (J,h)
                 double xp;
                 if (f == 0u) xp = xs + hk;
                 else if (f == 1u) {   // cluster rows divided element-wise by temp_x (NMC/nmc.py:379-380)
                     double y = 0.0;
-                    for (int e = rs; e < re; ++e) y += (a.g.val64[e] / a.temp_x) * (double)s[a.g.col[e]];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { const double tm = (rA.vj[q] / a.temp_x) * sj[q]; if (q < deg) y += tm; }
+                    for (int e = rs + 8; e < re; ++e) y += (a.g.val64[e] / a.temp_x) * (double)s[a.g.col[e]];
                     xp = y + hk / a.temp_x;
                 } else xp = xs + ((f == 2u) ? 10000.0 : -10000.0);   // NMC/nmc.py:381,401
-                const double v = tanh(beta * xp) - 2.0 * ut[k] + 1.0;
+                const double v = tanh(beta * xp) - 2.0 * rA.u + 1.0;
                 const int sn = (v > 0.0) - (v < 0.0);                // np.sign
                 if (sn != so) {
                     x.e_loc += __double2ll_rn(-(double)(sn - so) * x_true * esc);
@@ -777,6 +825,8 @@ __global__ void k_sweep_stream(SweepArgs a)
                 }
             }
             __syncthreads();
+            enA = enB; vA = vB; rA = rB;
+            enB = enC; vB = vC;
         }
         sweep_epilogue(a, x, t);
     }
