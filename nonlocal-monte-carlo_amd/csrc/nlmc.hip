@@ -67,7 +67,7 @@ struct nlmc_ctx {
     bool has_diag = false;
     bool has_zero_vals = false;   // a stored entry is 0.0 (or underflows to 0 in fp32)
     size_t lds_opt[48] = {};      // dynamic-LDS opt-in already granted, one slot per kernel: 0 k_levelize, 1 k_icm_components,
-                                  // 2..7 sweep-by-sweep kernels, 8..15 k_sweep_fused variants, 16 k_levelize_fused, 17..20 k_lbp_lds, 21 k_icm_round, 22..23 packed fp64 sweep kernels, 24..47 k_sweep_fused variants
+                                  // 2..7 sweep-by-sweep kernels, 8 k_stream_scatter, 16 k_levelize_fused, 17..20 k_lbp_lds, 21 k_icm_round, 22..23 packed fp64 sweep kernels, 24..47 k_sweep_fused variants
 
     DevBuf<int32_t> rowptr, col;
     DevBuf<double> val64, h64;
@@ -79,6 +79,9 @@ struct nlmc_ctx {
     DevBuf<int32_t> argmin;
     DevBuf<double> energy, tab, ustream, etrace_d;
     DevBuf<uint32_t> keys;
+    DevBuf<int32_t> perm_raw;          // stream mode: the caller's permutations / uniforms as drawn, scattered by spin on the device
+    DevBuf<double> u_raw;
+    DevBuf<int32_t> stream_bad;
     DevBuf<int8_t> strace, cfg, snap_g;
     int strace_nrec = 0;          // recorded configurations per chain held in strace by the last sweep call (0: none)
     int strace_rows = 0;          // chains (rows) of that trace: the subset the call ran on
@@ -1076,7 +1079,7 @@ void nlmc_destroy(nlmc_ctx *c)
     c->rowptr.release(); c->col.release(); c->val64.release(); c->h64.release(); c->edge32.release(); c->hq.release();
     c->spins.release(); c->best.release(); c->flags.release(); c->efix.release(); c->emin.release(); c->etrace.release();
     c->argmin.release(); c->energy.release(); c->tab.release(); c->ustream.release(); c->etrace_d.release();
-    c->keys.release(); c->strace.release(); c->cfg.release(); c->snap_g.release(); c->scratch.release(); c->plan.release();
+    c->keys.release(); c->perm_raw.release(); c->u_raw.release(); c->stream_bad.release(); c->strace.release(); c->cfg.release(); c->snap_g.release(); c->scratch.release(); c->plan.release();
     c->slot_mark.release(); c->sub_list_buf.release(); c->cmask.release(); c->nmc_status.release(); c->nmc_thr.release();
     c->fz_glv.release(); c->fz_perm.release(); c->fz_adj.release(); c->fz_stats.release(); c->fz[0].release(); c->fz[1].release();
     c->lbp_src.release(); c->lbp_rev.release(); c->lbp_flag.release(); c->lbp_out_i.release(); c->lbp_tJ.release();
@@ -1229,34 +1232,31 @@ int nlmc_sweep_stream(nlmc_ctx *c, int n_sweeps, const int32_t *perm, const doub
     const int R = c->n_chains, n = c->n;
     if (R == 0 || n_sweeps == 0) return NLMC_OK;
     const size_t tot = (size_t)R * n_sweeps;
-    // scatter the stream by spin: rank[perm[i]] = i, u_spin[perm[i]] = u[i]
-    std::vector<uint32_t> rank(tot * n);
-    std::vector<double> us(tot * n);
-    std::vector<uint8_t> seen((size_t)n);
-    for (size_t o = 0; o < tot; ++o) {
-        const int32_t *p = perm + o * n;
-        const double *uu = u + o * n;
-        std::fill(seen.begin(), seen.end(), 0);
-        for (int i = 0; i < n; ++i) {
-            const int k = p[i];
-            if (k < 0 || k >= n || seen[k]) return fail(c, NLMC_ERR_ARG, "nlmc_sweep_stream: perm is not a permutation");
-            seen[k] = 1;
-            rank[o * n + k] = (uint32_t)i;
-            us[o * n + k] = uu[i];
-        }
-    }
     // beta table -> dense [R][n_sweeps]
     std::vector<double> tab(tot);
     for (int r = 0; r < R; ++r)
         for (int t = 0; t < n_sweeps; ++t) tab[(size_t)r * n_sweeps + t] = beta[(size_t)r * chain_stride + (size_t)t * sweep_stride];
     HIP_TRY(c, c->keys.reserve(tot * n));
     HIP_TRY(c, c->ustream.reserve(tot * n));
+    HIP_TRY(c, c->perm_raw.reserve(tot * n));
+    HIP_TRY(c, c->u_raw.reserve(tot * n));
+    HIP_TRY(c, c->stream_bad.reserve(1));
     c->tab_host.clear();
     HIP_TRY(c, c->tab.reserve(tot));
-    HIP_TRY(c, hipMemcpyAsync(c->keys.p, rank.data(), sizeof(uint32_t) * tot * n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->ustream.p, us.data(), sizeof(double) * tot * n, hipMemcpyHostToDevice, c->stream));
+    // the stream goes up as it was drawn and is scattered by spin on the device (rank[perm[i]] = i, u_spin[perm[i]] = u[i]; the
+    // host loop + its staging vectors were 9 + 9 ms per 2000 sweeps at N = 2048), which also checks that every row IS a permutation
+    HIP_TRY(c, hipMemsetAsync(c->stream_bad.p, 0, sizeof(int32_t), c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->perm_raw.p, perm, sizeof(int32_t) * tot * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->u_raw.p, u, sizeof(double) * tot * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->tab.p, tab.data(), sizeof(double) * tot, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rc = ensure_lds(c, 8, reinterpret_cast<const void *>(k_stream_scatter), (size_t)n * 4); if (rc) return rc; }
+    hipLaunchKernelGGL(k_stream_scatter, dim3((unsigned)tot), dim3(256), (size_t)n * 4, c->stream, n, c->perm_raw.p, c->u_raw.p, c->keys.p,
+                       c->ustream.p, c->stream_bad.p);
+    HIP_TRY(c, hipGetLastError());
+    int32_t bad = 0;
+    HIP_TRY(c, hipMemcpyAsync(&bad, c->stream_bad.p, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));          // (also: the caller's buffers and `tab` may go away)
+    if (bad) return fail(c, NLMC_ERR_ARG, "nlmc_sweep_stream: perm is not a permutation");
     SweepOut o{record_stride, out_spins, out_energy, out_min_energy, out_argmin, out_argmin_state};
     int rc = run_sweeps(c, true, NLMC_F64, NLMC_ORDER_PER_CHAIN, n_sweeps, 0, 0, c->tab.p, n_sweeps, 1, false, c->keys.p,
                         c->ustream.p, o);

@@ -729,6 +729,22 @@ __device__ __forceinline__ void chain_store(const SweepArgs &a, ChainCtx &x)
 
 // ---- STREAM mode: the reference's arithmetic, fp64, externally drawn uniforms --------------------------
 // m_k = sign(tanh(beta x_k) - 2u + 1),  x = (sum_e J_e m_e) + h_k in CSR order  (NMC/nmc.py:86-87)
+// The reference stream of one (chain, sweep) as drawn -- perm[i] = spin visited i-th, u[i] = its uniform -- scattered by spin:
+// rank[perm[i]] = i (the sort key of k_levelize), u_spin[perm[i]] = u[i].  *bad is set when a row is not a permutation.
+__global__ void k_stream_scatter(int n, const int32_t *perm, const double *u, uint32_t *rank, double *us, int32_t *bad)
+{
+    extern __shared__ unsigned int seen_lds[];
+    const size_t o = blockIdx.x;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) seen_lds[i] = 0u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int k = perm[o * n + i];
+        if (k < 0 || k >= n || atomicExch(&seen_lds[k], 1u) != 0u) { atomicOr(bad, 1); continue; }
+        rank[o * n + k] = (uint32_t)i;
+        us[o * n + k] = u[o * n + i];
+    }
+}
+
 __global__ void k_sweep_stream(SweepArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
