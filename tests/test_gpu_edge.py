@@ -176,3 +176,31 @@ def test_energies_of_the_recorded_trace_on_the_device(product, n, fused):
         eng.sweep_philox(2, 99, sweep0=S, beta=1.0)              # records nothing
         with pytest.raises(RuntimeError):
             eng.energy_of_recorded(1)
+
+
+def test_stream_rows_that_are_not_permutations_are_refused(product):
+    """nlmc_sweep_stream scatters the reference stream by spin on the device (k_stream_scatter) and checks on the way that every
+    (chain, sweep) row of `perm` is a permutation of 0..n-1: a repeated or out-of-range entry is a ValueError, and the state is
+    untouched; a valid stream right after runs normally."""
+    N, R, S = 200, 2, 3
+    J, h = make_instance(N, seed=5)
+    m0 = init_spins(R, N)
+    rng = np.random.default_rng(0)
+    perm = np.stack([np.stack([rng.permutation(N) for _ in range(S)]) for _ in range(R)]).astype(np.int32)
+    u = rng.random((R, S, N))
+    with product.Engine(J, h, R) as eng:
+        eng.set_spins(m0)
+        for bad in ("repeat", "range"):
+            p = perm.copy()
+            if bad == "repeat":
+                p[1, 2, 7] = p[1, 2, 8]
+            else:
+                p[0, 1, 3] = N
+            with pytest.raises(ValueError, match="not a permutation"):
+                eng.sweep_stream(p, u, 1.0)
+            assert np.array_equal(eng.get_spins(), m0)
+        a = eng.sweep_stream(perm, u, 1.0, record_stride=1)["spins"]
+    with product.Engine(J, h, R) as eng:
+        eng.set_spins(m0)
+        b = eng.sweep_stream(perm, u, 1.0, record_stride=1)["spins"]
+    assert np.array_equal(a, b)
