@@ -105,9 +105,28 @@ class SweepMixin:
         eng.set_spins(s0.astype(np.int8)[None, :])
         eng.set_flags(None if flags is None else flags[None, :], temp_x)
         if self.rng == "numpy":
-            perm, u = hostlogic.draw_legacy_stream(num_sweeps, n)
-            return eng.sweep_stream(perm[None], u[None], np.asarray(beta_run)[None, :], record_stride=rs,
-                                    want_energy=True, want_min=True, want_state=True)
+            b = np.asarray(beta_run, dtype=np.float64)
+            piece = 256 if rs <= 1 else max(rs, 256 // rs * rs)
+            if num_sweeps < 3 * piece:
+                perm, u = hostlogic.draw_legacy_stream(num_sweeps, n)
+                return eng.sweep_stream(perm[None], u[None], b[None, :], record_stride=rs,
+                                        want_energy=True, want_min=True, want_state=True)
+            # Long runs: the draws of piece i+1 (the reference's own np.random calls, in its order, on ONE worker thread) are made
+            # while the GPU sweeps piece i (the C-ABI call releases the GIL): 12 of 48 us per sweep at N = 10^3 leave the
+            # critical path.  The pieces are stitched exactly as one call would return them (trace, energies, first argmin).
+            from concurrent.futures import ThreadPoolExecutor
+            from .engine import _stitch_outputs
+            cuts = list(range(0, num_sweeps, piece)) + [num_sweeps]
+            outs = []
+            with ThreadPoolExecutor(max_workers=1) as ex:
+                fut = ex.submit(hostlogic.draw_legacy_stream, cuts[1] - cuts[0], n)
+                for i in range(len(cuts) - 1):
+                    perm, u = fut.result()
+                    if i + 2 < len(cuts):
+                        fut = ex.submit(hostlogic.draw_legacy_stream, cuts[i + 2] - cuts[i + 1], n)
+                    outs.append(eng.sweep_stream(perm[None], u[None], b[None, cuts[i]:cuts[i + 1]], record_stride=rs,
+                                                 want_energy=True, want_min=True, want_state=True))
+            return _stitch_outputs(outs, piece, rs, True, True, True)
         beta2 = np.asarray(beta_run)[None, :]
         # Arithmetic of the single-chain device-RNG calls (MCMC(), the phases of NMC.run / NMC_subroutine): a property of the
         # INSTANCE alone -- not of M_skip, not of the number of sweeps.  n >= 256: the "f32" dynamics of the

@@ -482,3 +482,29 @@ def test_apt_preprocessor_philox_mode_on_fused_windows(product, tmp_path, monkey
     monkeypatch.delenv("NLMC_NO_FUSED")
     b4, _ = go(6)
     assert b4 != b1
+
+
+@pytest.mark.gpu
+def test_long_numpy_mode_runs_draw_ahead_without_changing_the_stream(product):
+    """MCMC in the default mode (the reference's global np.random stream) draws the next piece of a long run on a worker thread
+    while the GPU sweeps the current one: the trace, the energies behind it and the state of np.random afterwards are those of
+    drawing everything first and sweeping in one call (900 sweeps: three pieces of 256 + one of 132; strided recording too)."""
+    from helpers import make_instance
+    N, S = 150, 900
+    J, h = make_instance(N, seed=9, with_h=True, gaussian=True)
+    Jd = J.toarray()
+    m0 = np.sign(np.random.default_rng(1).random(N) - 0.5)
+    obj = product.NMC(Jd, h)
+    np.random.seed(77)
+    with quiet():
+        M1 = obj.MCMC(S, m0.copy(), 1.5, Jd, h, anneal=True)
+    after1 = np.random.rand(3)
+    np.random.seed(77)
+    perm, u = product.hostlogic.draw_legacy_stream(S, N)
+    after2 = np.random.rand(3)
+    sched = product.hostlogic.beta_schedule(S, 1.5, True, 1, 0)
+    with product.Engine(Jd, h, 1) as eng:
+        eng.set_spins(m0.astype(np.int8)[None])
+        o = eng.sweep_stream(perm[None], u[None], sched[None, :], record_stride=1)
+    assert np.array_equal(after1, after2)
+    assert M1.shape == (N, S) and np.array_equal(M1, o["spins"][0].T.astype(np.float64))
