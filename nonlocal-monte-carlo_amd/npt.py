@@ -153,10 +153,24 @@ class NPT(Common):
             phases += ["C", "NC"] + (["ALL"] if cycle % full_update_frequency == 0 else [])
         log_pairs, log_acc = [], []
         count = np.zeros(self.num_swap_attempts)
+        drawer = None
         try:
             w = S_nmc // M_skip
             if nm and S > 0 and len(phases) * w < S:       # NPT/npt.py:643-644: M[block] = M_nmc[:, -S:] cannot be filled
                 raise ValueError(f"could not broadcast input array from shape ({N},{len(phases) * w}) into shape ({N},{S})")
+            # The np.random calls of a round are the same whatever the spins do: per replica, in order, one permutation + N
+            # uniforms per sweep (NPT/npt.py:622-640 run in order), then one uniform per selected pair (NPT/npt.py:668).  In the
+            # default mode they are therefore made one round AHEAD on a worker thread, in the reference's order, while the GPU
+            # sweeps the current round (they were 61 % of the wall time at N = 10^3 x 8 replicas).
+            def draw_round():
+                st = {r: hostlogic.draw_legacy_stream(len(phases) * S_nmc if self.doNMC[r] else S, N) for r in range(R)}
+                return st, [np.random.rand() for _ in range(self.num_swapping_pairs)]
+
+            fut = None
+            if numpy_mode and self.num_swap_attempts > 0:
+                from concurrent.futures import ThreadPoolExecutor
+                drawer = ThreadPoolExecutor(max_workers=1)
+                fut = drawer.submit(draw_round)
             for ii in range(self.num_swap_attempts):
                 print(f"\nRunning swap attempt = {ii + 1}")
                 # Only the LAST column of a round's block is ever read again (next start state, swap energies) -- except
@@ -164,10 +178,11 @@ class NPT(Common):
                 last_round = ii == self.num_swap_attempts - 1
                 rs = 1 if last_round else 0
                 # --- draws in the reference's program order: replica by replica (NPT/npt.py:622-640 run in order)
-                streams = {}
+                streams, swap_u = {}, []
                 if numpy_mode:
-                    for r in range(R):
-                        streams[r] = hostlogic.draw_legacy_stream(len(phases) * S_nmc if self.doNMC[r] else S, N)
+                    streams, swap_u = fut.result()
+                    if not last_round:
+                        fut = drawer.submit(draw_round)
                 # --- plain replicas: one launch for all of them
                 if mc:
                     eng_m.set_flags(None)
@@ -235,7 +250,7 @@ class NPT(Common):
                     print(f"β values: {beta_sel}, {beta_next}")
                     print(f"Energies: {E_sel}, {E_next}")
                     log_pairs.append((sel, nxt))
-                    u = np.random.rand() if numpy_mode else host_rng.random()
+                    u = swap_u[len(log_acc) - ii * self.num_swapping_pairs] if numpy_mode else host_rng.random()
                     ok = u < min(1, np.exp((beta_next - beta_sel) * (E_next - E_sel)))
                     log_acc.append(int(ok))
                     if ok:
@@ -247,6 +262,8 @@ class NPT(Common):
             for r in range(R):                       # min over the FIRST R_swap columns (NPT/npt.py:685-692, :41)
                 Energy[r] = self.replica_energy(M[r * N:(r + 1) * N, :], self.num_sweeps_read_per_swap)[0]
         finally:
+            if drawer is not None:
+                drawer.shutdown(wait=True)
             for e in (eng_m, eng_n):
                 if e is not None:
                     e.close()
