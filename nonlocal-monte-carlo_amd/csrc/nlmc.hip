@@ -25,15 +25,25 @@ std::string g_create_error;
 template <typename T> struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;   // elements
+    bool borrowed = false;      // p points into the context's arena (nlmc_create): not freed here
     hipError_t reserve(size_t n)
     {
         if (n <= cap) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        if (p && !borrowed) { hipError_t e = hipFree(p); if (e != hipSuccess) { p = nullptr; cap = 0; return e; } }
+        p = nullptr; cap = 0; borrowed = false;
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(n, 1) * sizeof(T));
         if (e == hipSuccess) cap = n;
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void borrow(void *base, size_t &offset, size_t n)     // n elements at the next 256-byte boundary of the arena
+    {
+        offset = (offset + 255) & ~(size_t)255;
+        p = reinterpret_cast<T *>(static_cast<char *>(base) + offset);
+        cap = n; borrowed = true;
+        offset += std::max<size_t>(n, 1) * sizeof(T);
+    }
+    static size_t arena_bytes(size_t n) { return ((std::max<size_t>(n, 1) * sizeof(T)) + 255 + 255) & ~(size_t)255; }
+    void release() { if (p && !borrowed) (void)hipFree(p); p = nullptr; cap = 0; borrowed = false; }
 };
 
 }  // namespace
@@ -42,6 +52,8 @@ struct nlmc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;             // nlmc_own_stream: `stream` was created by the library
+    void *arena = nullptr;                // ONE allocation behind the fixed-size buffers of nlmc_create (13 hipMalloc + 7 blocking
+                                          // memsets + 6 blocking copies were 6 of the 29 ms of an NPT.run call at the C4 shape)
     // Work on the MARKED chain subset may run on a second stream beside the unmarked chains' sweeps (nlmc_overlap_subsets):
     // `cur` is the stream the subset-aware launches go to, forked from / joined to `stream` by nlmc_select_chains.
     hipStream_t aux = nullptr, cur = nullptr;
@@ -1013,37 +1025,40 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
     if (const char *e = getenv("NLMC_DBG_FLAGS")) c->knob_dbg_flags = atoi(e);
     for (int k = 0; k < n; ++k) hq[k] = (int32_t)rq(h[k], qs);
 
-    CT(c->rowptr.reserve((size_t)n + 1));
-    // +16 entries of padding: fixed-width row windows are read unconditionally (never used past the row end)
-    CT(c->col.reserve((size_t)nnz + 16));
-    CT(c->val64.reserve((size_t)nnz + 16));
-    CT(c->edge32.reserve((size_t)nnz + 16));
-    CT(hipMemset(c->col.p, 0, sizeof(int32_t) * ((size_t)nnz + 16)));
-    CT(hipMemset(c->val64.p, 0, sizeof(double) * ((size_t)nnz + 16)));
-    CT(hipMemset(c->edge32.p, 0, sizeof(EdgeQ) * ((size_t)nnz + 16)));
-    CT(c->h64.reserve((size_t)n));
-    CT(c->hq.reserve((size_t)n));
-    CT(hipMemcpy(c->rowptr.p, rowptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
+    // +16 entries of padding behind the row arrays: fixed-width row windows are read unconditionally (never used past the row end)
+    const size_t R = (size_t)std::max(n_chains, 1), npad = (size_t)c->n_pad, nz = (size_t)nnz + 16;
+    const size_t total = DevBuf<int32_t>::arena_bytes((size_t)n + 1) + DevBuf<int32_t>::arena_bytes(nz) + DevBuf<double>::arena_bytes(nz) +
+                         DevBuf<EdgeQ>::arena_bytes(nz) + DevBuf<double>::arena_bytes((size_t)n) + DevBuf<int32_t>::arena_bytes((size_t)n) +
+                         3 * DevBuf<int8_t>::arena_bytes(R * npad) + 2 * DevBuf<long long>::arena_bytes(R) +
+                         DevBuf<int32_t>::arena_bytes(R) + DevBuf<double>::arena_bytes(R) + 256;
+    CT(hipMalloc(&c->arena, total));
+    size_t off = 0;
+    c->rowptr.borrow(c->arena, off, (size_t)n + 1);
+    c->col.borrow(c->arena, off, nz);
+    c->val64.borrow(c->arena, off, nz);
+    c->edge32.borrow(c->arena, off, nz);
+    c->h64.borrow(c->arena, off, (size_t)n);
+    c->hq.borrow(c->arena, off, (size_t)n);
+    c->spins.borrow(c->arena, off, R * npad);
+    c->best.borrow(c->arena, off, R * npad);
+    c->flags.borrow(c->arena, off, R * npad);
+    c->efix.borrow(c->arena, off, R);
+    c->emin.borrow(c->arena, off, R);
+    c->argmin.borrow(c->arena, off, R);
+    c->energy.borrow(c->arena, off, R);
+    if (off > total) { c->err = "nlmc_create: arena accounting"; return bail(NLMC_ERR_HIP); }
+    // everything zero (padding, states, flags, tracked energies), then the instance: stream-ordered, ONE wait (the host arrays
+    // handed to the copies are the caller's and this function's own: both outlive the wait)
+    CT(hipMemsetAsync(c->arena, 0, total, c->stream));
+    CT(hipMemcpyAsync(c->rowptr.p, rowptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
     if (nnz > 0) {
-        CT(hipMemcpy(c->col.p, colidx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
-        CT(hipMemcpy(c->val64.p, vals, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
-        CT(hipMemcpy(c->edge32.p, e32.data(), sizeof(EdgeQ) * (size_t)nnz, hipMemcpyHostToDevice));
+        CT(hipMemcpyAsync(c->col.p, colidx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, c->stream));
+        CT(hipMemcpyAsync(c->val64.p, vals, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, c->stream));
+        CT(hipMemcpyAsync(c->edge32.p, e32.data(), sizeof(EdgeQ) * (size_t)nnz, hipMemcpyHostToDevice, c->stream));
     }
-    CT(hipMemcpy(c->h64.p, h, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-    CT(hipMemcpy(c->hq.p, hq.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
-
-    const size_t R = (size_t)std::max(n_chains, 1);
-    CT(c->spins.reserve(R * c->n_pad));
-    CT(c->best.reserve(R * c->n_pad));
-    CT(c->flags.reserve(R * c->n_pad));
-    CT(c->efix.reserve(R));
-    CT(c->emin.reserve(R));
-    CT(c->argmin.reserve(R));
-    CT(c->energy.reserve(R));
-    CT(hipMemset(c->spins.p, 0, R * c->n_pad));
-    CT(hipMemset(c->best.p, 0, R * c->n_pad));
-    CT(hipMemset(c->flags.p, 0, R * c->n_pad));
-    CT(hipMemset(c->efix.p, 0, R * sizeof(long long)));
+    CT(hipMemcpyAsync(c->h64.p, h, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    CT(hipMemcpyAsync(c->hq.p, hq.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    CT(hipStreamSynchronize(c->stream));
 
     c->g.n = n; c->g.n_pad = c->n_pad;
     c->g.rowptr = c->rowptr.p; c->g.col = c->col.p; c->g.val64 = c->val64.p; c->g.edge32 = c->edge32.p;
@@ -1077,6 +1092,7 @@ void nlmc_destroy(nlmc_ctx *c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     c->rowptr.release(); c->col.release(); c->val64.release(); c->h64.release(); c->edge32.release(); c->hq.release();
+    // (borrowed buffers: released above / below without a free; the arena goes last)
     c->spins.release(); c->best.release(); c->flags.release(); c->efix.release(); c->emin.release(); c->etrace.release();
     c->argmin.release(); c->energy.release(); c->tab.release(); c->ustream.release(); c->etrace_d.release();
     c->keys.release(); c->perm_raw.release(); c->u_raw.release(); c->stream_bad.release(); c->strace.release(); c->cfg.release(); c->snap_g.release(); c->scratch.release(); c->plan.release();
@@ -1089,6 +1105,7 @@ void nlmc_destroy(nlmc_ctx *c)
     c->pt_tab.release(); c->pt_beta.release(); c->pt_energies_all.release();
     c->slot_of_chain.release(); c->chain_of_slot.release(); c->pt_pairs.release(); c->pt_status.release();
     c->pt_acc.release(); c->pt_log_acc.release(); c->pt_log_pairs.release(); c->pt_plan_pairs.release(); c->pt_plan_ok.release(); c->icm_label.release(); c->icm_info.release(); c->icm_pairs.release();
+    if (c->arena) (void)hipFree(c->arena);
     delete c;
 }
 
