@@ -7,9 +7,13 @@ With N > 1 and no torch.distributed environment this script starts `python -m to
 bench.py ...` itself as a CHILD process (before anything touches the GPU) and exits with the child's code; launched by
 torch.distributed.run it is one rank per GPU over RCCL.
 
-A "step" is ROUNDS_PER_STEP = 512 replica-exchange rounds of NPT (64 ms of GPU time: the default 16 steps and the
-driver's --steps 20 both time more than a second); a round is S_SWAP = 10 heat-bath sweeps of every
-replica at its ladder temperature followed by one swap-attempt round.  Workload (SURVEY.md section 8d, config C4 on
+A "step" is ROUNDS_PER_STEP = 4096 replica-exchange rounds of NPT (~0.5 s of GPU time: the driver's --steps 20 times ~10 s
+per leg, the default 4 steps 2 s); a round is S_SWAP = 10 heat-bath sweeps of every replica at its ladder temperature
+followed by one swap-attempt round.  TWO legs of equal standing run with the same --steps / --warmup, GPU work first, CPU
+baselines last: the headline leg in the reference's arithmetic (fp64 field, 53-bit uniform: NMC/nmc.py:86-87 -- the "f64"
+mode, on fused windows because the +-J instance makes the fp64 field an exact integer, bit-identical to the sweep-by-sweep
+fp64 kernel and the fp64 oracle) and the fixed-point "f32" throughput mode (`fixed_point_f32`; its own stated tolerance,
+DESIGN.md section 2).  Workload (SURVEY.md section 8d, config C4 on
 one GPU): synthetic +-J spin glass, N = 10^4 spins, exactly 3N edges (mean degree 6), h = 0; 256 replicas PER GPU on a
 geometric beta ladder 0.05 -> 4 that spans all GPUs (256*N_gpus slots; --strong: 256 replicas in total, 256/N per
 GPU); round(0.3 * replicas) swap pairs per round.  The only collective is one all-gather of the local float64 energies
@@ -20,12 +24,13 @@ EVERYTHING a round needs is inside the timed region: the per-sweep visiting orde
 selections (k_pt_select) are built chunk by chunk (256 rounds) by the round that first needs them, after t0.  Only
 the instance, the replica states and the ladder are resident in HBM before the timed region starts.
 
-Prints ONE JSON line (rank 0).  `value` = end-to-end spin-updates/s of the whole job; `value_kernel_loop` = the same
-updates over the summed durations of the sweep kernel alone; `roofline` prices the dominant kernel with HIP events
-recorded on the stream it runs on; `cpu_baseline` times the oracle (a C port of the same algorithm, one thread) on a
+Prints ONE JSON line (rank 0).  `value` = end-to-end spin-updates/s of the whole job (headline leg); `value_kernel_loop` = the same
+updates over the summed durations of the sweep kernel alone; `roofline` prices the dominant kernel (HIP events recorded on the
+stream it runs on) against the bound that binds it -- levels per second of a level-synchronous workgroup against the floor of one
+level (barrier + LDS gather + write), MEASURED in the same run by nlmc_probe_level_round -- and `roofline_algorithmic` keeps the
+contract figure of SURVEY.md section 8d (algorithmic bytes over the HBM peak; above 1 because the design does not move those bytes); `cpu_baseline` times the oracle (a C port of the same algorithm, one thread) on a
 bounded sample of the same workload (`cpu_baseline_all_cores`: one such process per host core); `cpu_baseline_numpy_path` times the reference's own NumPy loop structure
-(restated in oracle/numpy_path.py, pinned to a golden) the same way; `f64_field` is a short second leg of the same
-workload with the fp64 field sum of the parity mode (91 algorithmic bytes per update).
+(restated in oracle/numpy_path.py, pinned to a golden) the same way.
 """
 import argparse
 import json
@@ -42,7 +47,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 N_SPINS = 10_000
 REPLICAS_PER_GPU = 256
 S_SWAP = 10
-ROUNDS_PER_STEP = 512        # 512 rounds x 0.12 ms: a step is ~64 ms, so that any sensible --steps times >= 1 s
+ROUNDS_PER_STEP = 4096       # 4096 rounds x ~0.125 ms: a step is ~0.5 s, the driver's --steps 20 times ~10 s per leg (VERDICT r3 #1c)
 EVENT_EVERY = int(os.environ.get("NLMC_BENCH_EVENT_EVERY", "8"))   # HIP events around every 8th sweep-kernel launch of the timed region
 PLAN_CHUNK_ROUNDS = 256      # rounds whose schedules are built together (one workgroup per window: fills the chip)
 BETA_MIN, BETA_MAX = 0.05, 4.0
@@ -61,8 +66,9 @@ SCHEDULE_BYTES_PER_POSITION = 24 # what the sweep kernel streams per schedule po
 
 
 def load_pmc():
-    """Per-launch PMC figures of the sweep kernel on THIS workload (collected by scripts/profile_round.sh in separate
-    --pmc passes, committed under profiles/; PMC cannot be read live).  Returns {} when the file is absent."""
+    """Per-launch PMC figures of the sweep kernels on THIS workload, keyed by leg ("f64" / "f32") (collected by
+    scripts/profile_round.sh in separate --pmc passes, committed under profiles/; PMC cannot be read live).  Returns {} when the
+    file is absent."""
     path = os.path.join(REPO, "profiles", "current_sweep_pmc.json")
     try:
         with open(path) as f:
@@ -71,30 +77,32 @@ def load_pmc():
         return {}
 
 
-def cpu_baseline(J, h, seconds=12.0, chain=0):
-    """oracle/nlo.c (kind "port"): sequential C restatement of the same philox-mode sweep, one chain, one thread."""
+def cpu_baseline(J, h, seconds=12.0, chain=0, use_f64=True):
+    """oracle/nlo.c (kind "port"): sequential C restatement of the same philox-mode sweep (the arithmetic of the headline leg),
+    one chain, one thread."""
     import numpy as np
     import oracle
     csr = oracle.Csr(J)
     s = np.where(np.random.default_rng(1000 + chain).random(csr.n) < 0.5, -1, 1).astype(np.int8)
     chunk = 20
-    cb = np.tile(np.array(oracle.cb_pair(1.0)), (chunk, 1))
-    oracle.sweeps_philox(csr, h, s, cb[:1], PHILOX_SEED, chain, want_M=False)     # warm-up / page-in
+    cb = np.tile(np.array(oracle.cb_pair(1.0, 1.0, use_f64)), (chunk, 1))
+    oracle.sweeps_philox(csr, h, s, cb[:1], PHILOX_SEED, chain, use_f64=use_f64, want_M=False)     # warm-up / page-in
     esc = oracle.field_scale(csr, h)[1]
     done, t0, emin, ef = 0, time.perf_counter(), None, 0
     ef = int(np.rint(oracle.energy(csr, h, s) * 2.0 ** esc))
     while time.perf_counter() - t0 < seconds:
-        _, s, tr = oracle.sweeps_philox(csr, h, s, cb, PHILOX_SEED, chain, sweep0=done, escale=esc, efix0=ef, want_M=False)
+        _, s, tr = oracle.sweeps_philox(csr, h, s, cb, PHILOX_SEED, chain, sweep0=done, escale=esc, efix0=ef, use_f64=use_f64, want_M=False)
         ef = int(tr[-1])
         emin = min(float(tr.min()) * 2.0 ** -esc, emin) if emin is not None else float(tr.min()) * 2.0 ** -esc
         done += chunk
     dt = time.perf_counter() - t0
     return {"value": done * csr.n / dt, "unit": "spin-updates/s", "cores": 1, "kind": "port",
-            "sample": f"1 chain x {csr.n} spins x {done} sweeps at beta=1 ({dt:.1f} s of oracle/nlo.c:nlo_sweeps_philox)",
+            "sample": f"1 chain x {csr.n} spins x {done} sweeps at beta=1 ({dt:.1f} s of oracle/nlo.c:nlo_sweeps_philox, "
+                      f"{'f64' if use_f64 else 'f32'} mode)",
             "min_energy_seen": emin}
 
 
-def cpu_baseline_all_cores(seconds=8.0):
+def cpu_baseline_all_cores(seconds=8.0, use_f64=True):
     """The same oracle loop in one CHILD process per host core of this process's CPU set (each its own chain; children
     are started with subprocess and never touch the GPU): what the C port does with the whole host."""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -109,7 +117,8 @@ def cpu_baseline_all_cores(seconds=8.0):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     env["OMP_NUM_THREADS"] = "1"
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(seconds), "--cpu-chain", str(i)],
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(seconds), "--cpu-chain", str(i),
+                               "--headline", "f64" if use_f64 else "f32"],
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for i in range(cores)]
     vals = []
     for pr in procs:
@@ -162,11 +171,12 @@ def self_launch(a, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16, help="timed steps; one step = %d swap rounds" % ROUNDS_PER_STEP)
+    ap.add_argument("--steps", type=int, default=4, help="timed steps; one step = %d swap rounds" % ROUNDS_PER_STEP)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--strong", action="store_true", help="256 replicas in total instead of 256 per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-f64-leg", action="store_true")
+    ap.add_argument("--no-second-leg", action="store_true", help="skip the fixed-point leg")
+    ap.add_argument("--headline", choices=["f64", "f32"], default="f64", help=argparse.SUPPRESS)
     ap.add_argument("--dry-run-launch", action="store_true", help="print the launcher command of --gpus N and exit")
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)     # child of cpu_baseline_all_cores
     ap.add_argument("--cpu-chain", type=int, default=0, help=argparse.SUPPRESS)
@@ -175,7 +185,7 @@ def main():
     if a.cpu_worker > 0:                       # CPU-only child process: never touches the GPU
         from helpers import make_instance
         J, h = make_instance(N_SPINS, seed=INSTANCE_SEED)
-        print(json.dumps(cpu_baseline(J, h, seconds=a.cpu_worker, chain=a.cpu_chain)), flush=True)
+        print(json.dumps(cpu_baseline(J, h, seconds=a.cpu_worker, chain=a.cpu_chain, use_f64=(a.headline == "f64"))), flush=True)
         return
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -242,7 +252,8 @@ def main():
         st.set_spins(np.concatenate([np.zeros((base, N_SPINS), np.int8), init_spins(count, N_SPINS, base=1000 + base),
                                      np.zeros((G - base - count, N_SPINS), np.int8)]) if world > 1 else init_spins(G, N_SPINS))
         e_start = st.eng.energy()
-        chunk = PLAN_CHUNK_ROUNDS if precision == "f32" else 8
+        fused = precision in st.eng.fused_modes(S_SWAP)
+        chunk = PLAN_CHUNK_ROUNDS if fused else 8
         wr = warmup * ROUNDS_PER_STEP
         if wr:
             # (buffers for a full chunk are allocated here: memory allocation is not part of a round's work)
@@ -251,7 +262,7 @@ def main():
                 st.round(S_SWAP)
         tr = steps * ROUNDS_PER_STEP
         st.plan(tr * S_SWAP, tr, chunk_rounds=chunk, lazy=True)     # a fresh, EMPTY planner: nothing is built yet
-        st.eng.timing_reset(True, every=EVENT_EVERY if precision == "f32" else 1)
+        st.eng.timing_reset(True, every=EVENT_EVERY if fused else 1)
         sync()
         t0 = time.perf_counter()
         for _ in range(tr):
@@ -265,78 +276,87 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         e_end = st.eng.energy()
+        e_exact = st.eng.energy_of(st.eng.get_spins())            # tracked fixed-point energies == fp64 recomputation (untimed)
         sched = st.eng.last_schedule_stats()
         chunks = st._planner.chunks_planned if getattr(st, "_planner", None) is not None else 0
         coll = ("rccl ncclAllGather issued by libnlmc_hip.so on the kernels' stream" if st.lib_collective else
                 "torch.distributed all_gather_into_tensor" if st.collective else None)
+        # the floor of one level-synchronous step on THIS device, measured now (include/nlmc.h: nlmc_probe_level_round)
+        probe = {"conflict_free_ns": st.eng.probe_level_round(16, True), "random_gather_ns": st.eng.probe_level_round(16, False)}
         st.close()
         return {"dt": dt, "tm": tm, "rounds": tr, "count": count, "e_start": e_start, "e_end": e_end, "sched": sched,
-                "chunks": chunks, "collective": coll}
+                "chunks": chunks, "collective": coll, "fused": fused, "probe": probe, "precision": precision,
+                "tracked_equals_recomputed": bool(np.array_equal(e_end, e_exact))}
 
-    r = run_leg("f32", a.steps, a.warmup)
+    KERNEL = {("f64", True): "k_sweep_fused<DIAG=false,FLAGS=false,OUT=false,FMT_ADDR,F64=true>", ("f64", False): "k_sweep_philox<double,false,PK=true>",
+              ("f32", True): "k_sweep_fused<DIAG=false,FLAGS=false,OUT=false,FMT_ADDR,F64=false>", ("f32", False): "k_sweep_philox<float,false>"}
+    DTYPE = {"f64": "f64 field + 53-bit uniform (the reference's arithmetic, NMC/nmc.py:86-87; on this +-J instance the fp64 field is an "
+                    "exact integer and the fp64 acceptance test an exact integer threshold per field value: bit-identical to the "
+                    "sweep-by-sweep fp64 kernel and the fp64 oracle)",
+             "f32": "i32 field (24-bit fixed-point J) + f32 logistic threshold from 32 random bits (stated tolerance: DESIGN.md section 2)"}
 
-    if rank == 0:
+    def leg_report(r):
+        """Figures of one leg.  `roofline`: the bound that binds -- a workgroup advances one level per barrier round, and a round
+        costs at least the probe's round (barrier + 8 LDS byte gathers in flight + 1 write at 16 waves, measured in this run);
+        `roofline_algorithmic`: SURVEY 8d's bytes per update over the HBM peak (the contract line; not a bound of this design)."""
         dt, tm, tr, count = r["dt"], r["tm"], r["rounds"], r["count"]
         updates = float(G) * N_SPINS * S_SWAP * tr
         upd_launch = float(count) * N_SPINS * S_SWAP
         ms_launch = tm["ms_sweep"] / max(1, tm["launches_timed"])       # average over the launches that had events
         sec_launch = ms_launch * 1e-3
-        achieved = upd_launch * BYTES_PER_UPDATE / sec_launch / 1e9 if ms_launch > 0 else 0.0
-        pmc = load_pmc() if (world == 1 and count == REPLICAS_PER_GPU) else {}
+        launches_per_round = tm["launches_sweep"] / max(1, tr)
+        bpu = BYTES_PER_UPDATE_F64 if r["precision"] == "f64" else BYTES_PER_UPDATE
+        pmc = load_pmc().get(r["precision"], {}) if (world == 1 and count == REPLICAS_PER_GPU and r["fused"]) else {}
+        levels_launch = r["sched"]["levels"] if r["fused"] else r["sched"]["levels"] / max(1, r["sched"]["orders"]) * S_SWAP / max(1.0, launches_per_round)
+        ach_lv = levels_launch / sec_launch if ms_launch > 0 else 0.0
+        peak_lv = 1e9 / r["probe"]["conflict_free_ns"]
+        achieved = upd_launch * bpu / sec_launch / 1e9 if ms_launch > 0 else 0.0
         out = {
-            "metric": "spin-updates/s (replicas x spins x sweeps / s), NPT sweep + swap rounds, schedule construction included",
-            "value": updates / dt,
-            "unit": "spin-updates/s",
-            "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong" if a.strong else "weak",
-            "vs_baseline": None,
-            "dtype": "i32 field (24-bit fixed-point J) + f32 acceptance test",
-            "data": "synthetic",
-            "config": {"workload": "NPT heat-bath sweeps + replica exchange, sparse +-J spin glass (C4 per GPU)",
-                       "spins": N_SPINS, "edges": 3 * N_SPINS, "replicas_per_gpu": count,
-                       "replicas_total": G, "sweeps_per_round": S_SWAP, "rounds_per_step": ROUNDS_PER_STEP,
-                       "swap_pairs_per_round": n_pairs, "beta_ladder": [BETA_MIN, BETA_MAX], "rng": "philox4x32-10",
-                       "order": "one permutation per sweep", "plan_chunk_rounds": PLAN_CHUNK_ROUNDS},
-            "collective": r["collective"],         # the one collective of a round (None: a single process, nothing to gather)
-            "ranks_seen": world,
-            "plan_in_timed_region": True,
+            "value": updates / dt, "unit": "spin-updates/s", "dtype": DTYPE[r["precision"]], "rounds_timed": tr,
+            "seconds_timed": dt, "ms_per_round": dt / tr * 1e3,
+            "value_kernel_loop": (upd_launch / sec_launch / launches_per_round) * world if ms_launch > 0 else None,
+            "kernel": KERNEL[(r["precision"], r["fused"])], "us_per_launch": ms_launch * 1e3,
+            "sweep_launches": tm["launches_sweep"], "sweep_launches_with_events": tm["launches_timed"],
+            "ms_levelize": tm["ms_levelize"], "ms_sweep_kernels": ms_launch * tm["launches_sweep"],
             "plan_chunks_in_timed_region": r["chunks"],
-            "rounds_timed": tr,
-            "ms_per_round": dt / tr * 1e3,
-            "value_kernel_loop": (upd_launch / (ms_launch * 1e-3)) * world if ms_launch > 0 else None,
-            "ms_levelize": tm["ms_levelize"],
-            "ms_sweep_kernels": ms_launch * tm["launches_sweep"],      # extrapolated from the launches that had events
-            "sweep_launches": tm["launches_sweep"],
-            "sweep_launches_with_events": tm["launches_timed"],
-            # contract line: ALGORITHMIC bytes over the launch time measured live with HIP events; `traffic` and
-            # everything derived from it are STATIC figures of the committed PMC passes (counters cannot be read live)
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc.get("hbm_bytes_per_launch"),
-                         "hbm_measured_frac": (pmc["hbm_bytes_per_launch"] / sec_launch / 1e9 / HBM_PEAK_GBS)
-                         if (pmc.get("hbm_bytes_per_launch") and ms_launch > 0) else None,
-                         "static_from": pmc.get("source"),
-                         "launches_timed": tm["launches_timed"], "launches_total": tm["launches_sweep"],
-                         "algorithmic_bytes_per_launch": upd_launch * BYTES_PER_UPDATE,
-                         "kernel": "k_sweep_fused<false,false,false>", "us_per_launch": ms_launch * 1e3,
-                         "bytes_per_update": BYTES_PER_UPDATE, "updates_per_launch": upd_launch,
-                         "note": "frac = SURVEY 8d algorithmic bytes (63 B per update, no discount for rows shared by chains) over "
-                                 "the HBM peak: > 1 because this design does not move those bytes (spins live in LDS, one "
-                                 "level schedule serves all chains of a launch); hbm_measured_frac = PMC traffic over the "
-                                 "same launch time, the physical HBM utilisation; the kernel is bound by the dependent "
-                                 "chain of a level, see roofline_l2 / roofline_issue (DESIGN.md section 5)"},
-            # every workgroup (= chain = CU) streams the whole window schedule through its L1 from its XCD's L2
-            "roofline_l2": {"bound": "l2", "unit": "GB/s", "peak": L2_PEAK_GBS,
-                            "achieved": upd_launch * sched_bytes / sec_launch / 1e9 if ms_launch > 0 else 0.0,
-                            "frac": upd_launch * sched_bytes / sec_launch / 1e9 / L2_PEAK_GBS if ms_launch > 0 else 0.0,
-                            "bytes_per_update": sched_bytes, "schedule_positions_per_update": positions_per_update},
             "levels_per_sweep": r["sched"]["levels"] / max(1, r["sched"]["orders"]),
             "min_energy": {"start": float(r["e_start"].min()), "end": float(r["e_end"].min())},
+            "tracked_energies_equal_fp64_recomputation": r["tracked_equals_recomputed"],
+            "roofline": {"bound": "lds-latency", "unit": "levels/s per workgroup", "achieved": ach_lv, "peak": peak_lv,
+                         "frac": ach_lv / peak_lv if peak_lv > 0 else None,
+                         "traffic": pmc.get("hbm_bytes_per_launch"),
+                         "levels_per_launch": levels_launch, "us_per_level": (sec_launch * 1e6 / levels_launch) if levels_launch else None,
+                         "peak_ns_per_level": r["probe"]["conflict_free_ns"],
+                         "peak_source": "nlmc_probe_level_round in this run: 256 workgroups x 16 waves, barrier + 8 LDS byte gathers in "
+                                        "flight + 1 LDS write per round, bank-conflict-free addresses",
+                         "random_gather_round_ns": r["probe"]["random_gather_ns"],
+                         "frac_vs_random_gather_round": ach_lv * r["probe"]["random_gather_ns"] * 1e-9,
+                         "kernel": KERNEL[(r["precision"], r["fused"])], "us_per_launch": ms_launch * 1e3,
+                         "launches_timed": tm["launches_timed"], "launches_total": tm["launches_sweep"],
+                         "note": "a chain is one workgroup that advances one level of its schedule per barrier round; the level's "
+                                 "dependent chain (barrier -> LDS gather -> sum -> decide -> LDS write -> barrier) is the floor of a "
+                                 "round; everything else (schedule stream from L2, Philox, energy) must hide behind it.  HBM, L2 "
+                                 "and VALU fractions of the same launch: roofline_algorithmic.hbm_measured_frac, roofline_l2, "
+                                 "roofline_issue"},
+            # contract line (SURVEY 8d): ALGORITHMIC bytes over the launch time measured live with HIP events; `traffic` and
+            # everything derived from it are STATIC figures of the committed PMC passes (counters cannot be read live)
+            "roofline_algorithmic": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes_per_launch"),
+                                     "hbm_measured_frac": (pmc["hbm_bytes_per_launch"] / sec_launch / 1e9 / HBM_PEAK_GBS)
+                                     if (pmc.get("hbm_bytes_per_launch") and ms_launch > 0) else None,
+                                     "static_from": pmc.get("source"), "bytes_per_update": bpu, "updates_per_launch": upd_launch,
+                                     "algorithmic_bytes_per_launch": upd_launch * bpu,
+                                     "note": "SURVEY 8d algorithmic bytes per update (63 B with 4-byte J, 91 B with fp64 J; no discount for "
+                                             "rows shared by chains) over the HBM peak: > 1 because this design does not move those "
+                                             "bytes (spins live in LDS, one level schedule serves all chains of a launch) -- not a bound; "
+                                             "hbm_measured_frac = PMC traffic over the same launch time"},
         }
+        if r["fused"]:
+            # every workgroup (= chain = CU) streams the whole window schedule through its L1 from its XCD's L2
+            out["roofline_l2"] = {"bound": "l2", "unit": "GB/s", "peak": L2_PEAK_GBS,
+                                  "achieved": upd_launch * sched_bytes / sec_launch / 1e9 if ms_launch > 0 else 0.0,
+                                  "frac": upd_launch * sched_bytes / sec_launch / 1e9 / L2_PEAK_GBS if ms_launch > 0 else 0.0,
+                                  "bytes_per_update": sched_bytes, "schedule_positions_per_update": positions_per_update}
         if pmc.get("valu_wave_insts_per_launch") and ms_launch > 0:
             lane_insts = pmc["valu_wave_insts_per_launch"] * 64.0
             t_issue = lane_insts / (N_CUS * VALU_LANES_PER_CU_CLK * CLOCK_GHZ * 1e9)
@@ -347,20 +367,45 @@ def main():
                                      "valu_lane_insts_per_schedule_position": lane_insts / upd_launch / positions_per_update,
                                      "lds_bank_conflict_frac": pmc.get("lds_bank_conflict_frac"),
                                      "wait_any_frac": pmc.get("wait_any_frac"), "static_from": pmc.get("source")}
-        if world == 1 and not a.no_f64_leg:
-            f = run_leg("f64", 1, 0)
-            ms64 = f["tm"]["ms_sweep"] / max(1, f["tm"]["launches_timed"])
-            upd64 = float(f["count"]) * N_SPINS * S_SWAP * f["rounds"]
-            out["f64_field"] = {"value": upd64 / f["dt"], "unit": "spin-updates/s", "rounds_timed": f["rounds"],
-                                "dtype": "f64", "bytes_per_update": BYTES_PER_UPDATE_F64,
-                                "kernel": "k_sweep_philox<double>", "ms_sweep_kernels": f["tm"]["ms_sweep"],
-                                "ms_levelize": f["tm"]["ms_levelize"],
-                                "roofline_frac_hbm": upd64 * BYTES_PER_UPDATE_F64 / (f["tm"]["ms_sweep"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-                                if f["tm"]["ms_sweep"] > 0 else None}
+        return out
+
+    first, second = a.headline, ("f32" if a.headline == "f64" else "f64")
+    r = run_leg(first, a.steps, a.warmup)
+    r2 = None if a.no_second_leg else run_leg(second, a.steps, a.warmup)
+
+    if rank == 0:
+        head = leg_report(r)
+        out = {
+            "metric": "spin-updates/s (replicas x spins x sweeps / s), NPT sweep + swap rounds, schedule construction included",
+            "value": head["value"],
+            "unit": "spin-updates/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": r["dt"] / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong" if a.strong else "weak",
+            "vs_baseline": None,
+            "dtype": head["dtype"],
+            "data": "synthetic",
+            "config": {"workload": "NPT heat-bath sweeps + replica exchange, sparse +-J spin glass (C4 per GPU)",
+                       "spins": N_SPINS, "edges": 3 * N_SPINS, "replicas_per_gpu": r["count"],
+                       "replicas_total": G, "sweeps_per_round": S_SWAP, "rounds_per_step": ROUNDS_PER_STEP,
+                       "swap_pairs_per_round": n_pairs, "beta_ladder": [BETA_MIN, BETA_MAX], "rng": "philox4x32-10",
+                       "order": "one permutation per sweep", "plan_chunk_rounds": PLAN_CHUNK_ROUNDS},
+            "collective": r["collective"],         # the one collective of a round (None: a single process, nothing to gather)
+            "ranks_seen": world,
+            "plan_in_timed_region": True,
+        }
+        for k, v in head.items():
+            if k not in ("value", "unit", "dtype"):
+                out[k] = v
+        if r2 is not None:
+            out["fixed_point_f32" if second == "f32" else "f64_field"] = leg_report(r2)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(J, h)
+            out["cpu_baseline"] = cpu_baseline(J, h, use_f64=(first == "f64"))
             out["cpu_baseline_numpy_path"] = numpy_path_baseline(J, h)
-            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(use_f64=(first == "f64"))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

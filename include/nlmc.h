@@ -48,7 +48,7 @@ enum { NLMC_SPIN_NORMAL = 0, NLMC_SPIN_SCALED = 1, NLMC_SPIN_FROZEN_UP = 2, NLMC
  * library whose value differs.  2 (round 3): nlmc_timing_total has a fifth out-pointer and nlmc_timing_reset's argument is
  * a sampling period (both since round 2), NLMC_F32 means 24-bit fixed-point couplings + logistic thresholds, chain
  * subsets / plan slots / device-side NMC hand-offs were added. */
-#define NLMC_ABI_VERSION 2
+#define NLMC_ABI_VERSION 3
 
 int nlmc_abi_version(void);
 int nlmc_device_count(void);
@@ -135,9 +135,24 @@ int nlmc_plan_philox(nlmc_ctx *ctx, int precision, int order_mode, uint32_t swee
  * fused schedule (0 when the instance does not qualify: n < 256 or n > 11264,
  * window < 3 or > 64, or the three threshold tables do not fit in LDS next to the spins). */
 int nlmc_plan_philox_fused(nlmc_ctx *ctx, uint32_t sweep0, int n_windows, int window, uint64_t seed, int32_t *out_planned);
+/* Which precisions may run on fused windows of `window` sweeps on this context: bit 0 = NLMC_F32, bit 1 = NLMC_F64.  The fp64
+ * mode (the reference's arithmetic, NMC/nmc.py:86-87: fp64 field, 53-bit uniform) qualifies when every coupling AND every field
+ * is an exact multiple of 2^-qs (+-J, integer and dyadic instances) with max_k (sum|Jq| + |hq|) <= 4095: its field is then the
+ * exact integer X times 2^-qs, z = -2 log2(e) beta x takes one value per X, and the test fma(u, 2^z, u) < 1 of the fp64 spec is
+ * monotone in the 53-bit integer of u -- one exact integer threshold per (chain, X), built in the kernel's prologue by bisection on
+ * the spec's own test.  A plan is shared by both precisions; an fp64 call runs on it while no phase flags are in force and the
+ * call has one temperature per chain (otherwise: sweep by sweep).  Bit-identical to the sweep-by-sweep fp64 kernel. */
+int nlmc_fused_modes(nlmc_ctx *ctx, int window);
 /* Only allocates the plan buffers for up to n_windows windows of `window` sweeps (a later nlmc_plan_philox_fused of at
  * most that size then allocates nothing).  Drops the current fused plan. */
 int nlmc_plan_reserve_fused(nlmc_ctx *ctx, int n_windows, int window);
+
+/* Measurement: the floor of ONE level-synchronous step on this device -- workgroup barrier, 8 byte gathers per lane from LDS (all in
+ * flight together), sum, one LDS write, barrier: the dependent chain every level of the sweep kernels contains -- in nanoseconds per
+ * round, from HIP events around `rounds` rounds of n_workgroups workgroups of `waves` waves (csrc/nlmc_probe.h).  conflict_free = 1:
+ * bank-conflict-free gather addresses (the best any placement of row entries could reach), 0: random addresses as in a sweep.
+ * bench.py prices the sweep kernel's levels per second against the conflict-free round. */
+int nlmc_probe_level_round(nlmc_ctx *ctx, int waves, int conflict_free, int rounds, int n_workgroups, double *out_ns_per_round);
 
 /* Diagnostic: the level list of planned window `window` of the selected plan slot, as chunk offsets (a chunk = 64 schedule
  * positions = one wave's items of one level): level l holds chunks [out[l], out[l+1]); out_n_levels levels (0: the window got

@@ -18,19 +18,19 @@ F32, F64 = 0, 1
 ORDER_SHARED, ORDER_PER_CHAIN = 0, 1
 SPIN_NORMAL, SPIN_SCALED, SPIN_FROZEN_UP, SPIN_FROZEN_DOWN = 0, 1, 2, 3
 MAX_N = 24576
-ABI_VERSION = 2                      # include/nlmc.h: NLMC_ABI_VERSION
+ABI_VERSION = 3                      # include/nlmc.h: NLMC_ABI_VERSION
 CHAINS_ALL, CHAINS_UNMARKED, CHAINS_MARKED = 0, 1, 2
 PHASE_ALL, PHASE_BACKBONE_HOT, PHASE_BACKBONE_FROZEN = 0, 1, 2
 
 EXPORTS = [
     "nlmc_abi_version", "nlmc_device_count", "nlmc_create", "nlmc_destroy", "nlmc_last_error", "nlmc_set_spins",
     "nlmc_get_spins", "nlmc_set_flags", "nlmc_energy", "nlmc_energy_tracked", "nlmc_energy_dev", "nlmc_set_energy_sink", "nlmc_energy_scale", "nlmc_field_scale", "nlmc_energy_of", "nlmc_sweep_stream",
-    "nlmc_sweep_philox", "nlmc_plan_philox", "nlmc_plan_philox_fused", "nlmc_plan_reserve_fused", "nlmc_pt_init", "nlmc_pt_get_slots", "nlmc_pt_set_slots",
+    "nlmc_sweep_philox", "nlmc_plan_philox", "nlmc_plan_philox_fused", "nlmc_fused_modes", "nlmc_plan_reserve_fused", "nlmc_pt_init", "nlmc_pt_get_slots", "nlmc_pt_set_slots",
     "nlmc_pt_apply_swap", "nlmc_pt_swap_philox", "nlmc_pt_plan", "nlmc_pt_check", "nlmc_pt_swap_philox_host", "nlmc_pt_log_begin", "nlmc_pt_log_read", "nlmc_icm_components", "nlmc_icm_move", "nlmc_icm_get_labels", "nlmc_icm_round_philox", "nlmc_icm_round_ladders",
     "nlmc_lbp_convexified", "nlmc_find_clusters", "nlmc_trace_layout", "nlmc_energy_of_recorded",
     "nlmc_last_timing", "nlmc_timing_reset", "nlmc_timing_total", "nlmc_last_schedule_stats",
     "nlmc_pt_mark_slots", "nlmc_select_chains", "nlmc_subset_count", "nlmc_get_subset", "nlmc_track_minimum", "nlmc_adopt_best",
-    "nlmc_backbone_clusters", "nlmc_backbone_check", "nlmc_get_cluster_mask", "nlmc_set_phase", "nlmc_plan_slot", "nlmc_overlap_subsets", "nlmc_own_stream", "nlmc_plan_get_levels", "nlmc_comm_unique_id", "nlmc_comm_init", "nlmc_pt_swap_philox_collective", "nlmc_set_cluster_mask", "nlmc_host_prefault",
+    "nlmc_backbone_clusters", "nlmc_backbone_check", "nlmc_get_cluster_mask", "nlmc_set_phase", "nlmc_plan_slot", "nlmc_overlap_subsets", "nlmc_own_stream", "nlmc_plan_get_levels", "nlmc_probe_level_round", "nlmc_comm_unique_id", "nlmc_comm_init", "nlmc_pt_swap_philox_collective", "nlmc_set_cluster_mask", "nlmc_host_prefault",
 ]
 
 
@@ -99,6 +99,10 @@ def lib():
     L.nlmc_plan_philox.argtypes = [_vp, _i, _i, _u32, _i, _u64]
     L.nlmc_plan_philox_fused.restype = _i
     L.nlmc_plan_philox_fused.argtypes = [_vp, _u32, _i, _i, _u64, _vp]
+    L.nlmc_probe_level_round.restype = _i
+    L.nlmc_probe_level_round.argtypes = [_vp, _i, _i, _i, _i, _vp]
+    L.nlmc_fused_modes.restype = _i
+    L.nlmc_fused_modes.argtypes = [_vp, _i]
     L.nlmc_plan_reserve_fused.restype = _i
     L.nlmc_plan_reserve_fused.argtypes = [_vp, _i, _i]
     L.nlmc_pt_init.restype = _i

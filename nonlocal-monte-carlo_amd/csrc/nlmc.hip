@@ -4,6 +4,7 @@
 #include "nlmc_pt_icm.h"
 #include "nlmc_lbp.h"
 #include "nlmc_nmc.h"
+#include "nlmc_probe.h"
 #include "nlmc_host.h"
 
 #include <dlfcn.h>
@@ -66,6 +67,10 @@ struct nlmc_ctx {
     bool compact16 = false;            // every Jq fits 16 bits: fused-window schedules use 4-byte entries
     bool f64_pack16 = false;           // ... and every J equals Jq 2^-qs exactly: the fp64 schedule window holds 16-bit columns / Jq
     bool sign8 = false;                // every Jq is +-1: fused-window schedules may use 2-byte entries (NLMC_FMT_ADDR)
+    bool f64_exact = false;            // every J AND every h is an exact multiple of 2^-qs: the fp64 field is the integer field times
+                                       // 2^-qs, the fp64 mode may run on fused windows (k_sweep_fused<.., F64>)
+    int xmax = 0;                      // max over rows of sum |Jq| + |hq|: the range of the integer field
+    unsigned knob_tie_mask = 0xFFFFFFFFu;   // NLMC_F64_TIE_MASK (test knob, read at nlmc_create)
     // diagnostic switches read ONCE, at nlmc_create (NLMC_NO_WARM, NLMC_FUSED_NOPRIO, NLMC_NO_DBUF, NLMC_DBG_FLAGS): not
     // looked up again on the launch path
     bool knob_no_warm = false, knob_no_prio = false, knob_no_dbuf = false;
@@ -78,8 +83,8 @@ struct nlmc_ctx {
     bool has_flags = false;
     bool has_diag = false;
     bool has_zero_vals = false;   // a stored entry is 0.0 (or underflows to 0 in fp32)
-    size_t lds_opt[48] = {};      // dynamic-LDS opt-in already granted, one slot per kernel: 0 k_levelize, 1 k_icm_components,
-                                  // 2..7 sweep-by-sweep kernels, 8 k_stream_scatter, 16 k_levelize_fused, 17..20 k_lbp_lds, 21 k_icm_round, 22..23 packed fp64 sweep kernels, 24..47 k_sweep_fused variants
+    size_t lds_opt[64] = {};      // dynamic-LDS opt-in already granted, one slot per kernel: 0 k_levelize, 1 k_icm_components,
+                                  // 2..7 sweep-by-sweep kernels, 8 k_stream_scatter, 16 k_levelize_fused, 17..20 k_lbp_lds, 21 k_icm_round, 22..23 packed fp64 sweep kernels, 24..47 k_sweep_fused variants, 48..59 its fp64 variants
 
     DevBuf<int32_t> rowptr, col;
     DevBuf<double> val64, h64;
@@ -381,8 +386,8 @@ int fused_workers(int nt)
 // LDS of k_sweep_fused: spins (+16: scratch spin of the dummy items, zero bytes) | (address format) negated spins (+16) |
 // flags (+16) | 3 threshold tables of n_pad words | (per-sweep outputs only) 3 snapshot slots of n_pad bytes | reduction
 // scratch
-struct FusedLds { int neg_off, flags_off, u_off, u_bytes, snap_off, red_off; size_t total; };
-FusedLds fused_lds(int n, int n_pad, bool has_flags, bool with_out, bool with_neg)
+struct FusedLds { int neg_off, flags_off, u_off, u_bytes, snap_off, red_off, kt_off; size_t total; };
+FusedLds fused_lds(int n, int n_pad, bool has_flags, bool with_out, bool with_neg, int kt_entries = 0)
 {
     (void)n;
     FusedLds L{};
@@ -396,7 +401,8 @@ FusedLds fused_lds(int n, int n_pad, bool has_flags, bool with_out, bool with_ne
     L.snap_off = cur;
     if (with_out) cur += 3 * n_pad + 16;
     L.red_off = cur;
-    L.total = (size_t)cur + 32;
+    L.kt_off = cur + 32;                 // fp64 mode: Khi | Klo, one 4-byte word each per value of the integer field
+    L.total = (size_t)cur + 32 + (size_t)kt_entries * 8;
     return L;
 }
 
@@ -434,10 +440,26 @@ bool fused_supported(const nlmc_ctx *c, int T)
     return L.total <= (size_t)150 * 1024;
 }
 
+// The fp64 mode on fused windows: exact dyadic couplings and fields (the field is an integer), its per-chain threshold tables in
+// LDS beside the rest, no phase flags in force (a scaled row's field is a sum of rounded quotients, not an integer).
+bool fused_f64_supported(const nlmc_ctx *c, int T)
+{
+    if (!c->f64_exact || c->xmax > 4095 || getenv("NLMC_NO_FUSED64")) return false;
+    if (!fused_supported(c, T)) return false;
+    return fused_lds(c->n, c->n_pad, false, false, fused_addr_format(c), 2 * c->xmax + 1).total <= (size_t)156 * 1024;
+}
+
 // k_sweep_fused<DIAG, FLAGS, OUT, FMT>: 24 kernels, picked by the instance (self-couplings, entry format of the plan) and the
 // call (phase flags on, per-sweep outputs)
-const void *fused_kernel(bool diag, bool flags, bool outs, int fmt)
+const void *fused_kernel(bool diag, bool flags, bool outs, int fmt, bool f64 = false)
 {
+    if (f64) {           // fp64 mode: plain chains only (12 more kernels)
+#define NLMC_K64(D, O) {reinterpret_cast<const void *>(k_sweep_fused<D, false, O, NLMC_FMT_WIDE, true>), reinterpret_cast<const void *>(k_sweep_fused<D, false, O, NLMC_FMT_COMPACT, true>), \
+                        reinterpret_cast<const void *>(k_sweep_fused<D, false, O, NLMC_FMT_ADDR, true>)}
+        static const void *const t64[2][2][3] = {{NLMC_K64(false, false), NLMC_K64(false, true)}, {NLMC_K64(true, false), NLMC_K64(true, true)}};
+#undef NLMC_K64
+        return flags ? nullptr : t64[diag][outs][fmt];
+    }
 #define NLMC_K(D, F, O) {reinterpret_cast<const void *>(k_sweep_fused<D, F, O, NLMC_FMT_WIDE>), reinterpret_cast<const void *>(k_sweep_fused<D, F, O, NLMC_FMT_COMPACT>), \
                          reinterpret_cast<const void *>(k_sweep_fused<D, F, O, NLMC_FMT_ADDR>)}
     static const void *const table[2][2][2][3] = {{{NLMC_K(false, false, false), NLMC_K(false, false, true)}, {NLMC_K(false, true, false), NLMC_K(false, true, true)}},
@@ -459,18 +481,20 @@ struct SweepOut {
 // One fused window.  `outs` (nullable): the launch also produces per-sweep outputs into the context's device buffers
 // (etrace / emin / argmin / best / strace, sized by the caller) as sweeps [t0, t0 + T) of a call of n_total sweeps.
 int run_fused(nlmc_ctx *c, int slot, int w, uint32_t sweep0, uint64_t seed, const double *tab_dev, int tab_cs, int tab_ss, bool use_slots,
-              bool outs, bool want_energy, bool want_min, bool want_state, int rec, int t0, int n_total)
+              bool outs, bool want_energy, bool want_min, bool want_state, int rec, int t0, int n_total, bool f64 = false)
 {
     const nlmc_ctx::FusedPlan &P = c->fz[slot];
     const int R = c->sub_count(), n = c->n, T = P.T;
     const size_t PS = (size_t)P.pstride;
     // per-sweep outputs: three snapshot slots in LDS when they fit beside the threshold tables, in global memory otherwise
-    const bool snap_lds = outs && fused_lds(c->n, c->n_pad, c->has_flags, true, P.fmt == NLMC_FMT_ADDR).total <= (size_t)150 * 1024;
-    const FusedLds L = fused_lds(c->n, c->n_pad, c->has_flags, snap_lds, P.fmt == NLMC_FMT_ADDR);
+    const int kt = f64 ? 2 * c->xmax + 1 : 0;
+    const bool snap_lds = outs && fused_lds(c->n, c->n_pad, c->has_flags, true, P.fmt == NLMC_FMT_ADDR, kt).total <= (size_t)150 * 1024;
+    const FusedLds L = fused_lds(c->n, c->n_pad, c->has_flags, snap_lds, P.fmt == NLMC_FMT_ADDR, kt);
     if (outs && !snap_lds) HIP_TRY(c, c->snap_g.reserve((size_t)R * (3 * (size_t)c->n_pad + 16)));
     const int variant = (outs ? 4 : 0) + (c->has_diag ? 2 : 0) + (c->has_flags ? 1 : 0);
-    const void *kfun = fused_kernel(c->has_diag, c->has_flags, outs, P.fmt);
-    { int rc = ensure_lds(c, 24 + variant * 3 + P.fmt, kfun, L.total); if (rc) return rc; }
+    const void *kfun = fused_kernel(c->has_diag, c->has_flags, outs, P.fmt, f64);
+    if (!kfun) return fail(c, NLMC_ERR_STATE, "run_fused: no fp64 fused kernel with phase flags");
+    { int rc = ensure_lds(c, f64 ? 48 + ((c->has_diag ? 2 : 0) + (outs ? 1 : 0)) * 3 + P.fmt : 24 + variant * 3 + P.fmt, kfun, L.total); if (rc) return rc; }
     // events around the launch (two stream commands) only while timings accumulate (nlmc_timing_reset): every launch or
     // every ev_every-th one.  An event record costs ~2.5 us of stream time: none on the plain product path.
     const bool timed = c->ev_accumulate && (c->ev_every <= 1 || c->launches_total % c->ev_every == 0);
@@ -533,6 +557,10 @@ int run_fused(nlmc_ctx *c, int slot, int w, uint32_t sweep0, uint64_t seed, cons
     a.lds_flags_off = L.flags_off; a.lds_u_off = L.u_off; a.lds_u_stride = L.u_bytes; a.lds_red_off = L.red_off;
     a.lds_snap_off = L.snap_off;
     a.snap_g = (outs && !snap_lds) ? c->snap_g.p : nullptr;
+    a.lds_kt_off = L.kt_off;
+    a.f64_xmax = c->xmax;
+    a.f64_tie_mask = c->knob_tie_mask;
+    a.qinv64 = std::ldexp(1.0, -c->qs);
 #ifdef NLMC_STAMPS
     HIP_TRY(c, c->dbg.reserve((size_t)R * 16 * 8 + 96));
     HIP_TRY(c, hipMemsetAsync(c->dbg.p, 0, ((size_t)R * 16 * 8 + 96) * sizeof(long long), c->cur));
@@ -657,15 +685,19 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
     // slots fit in LDS next to the rest; any whole number of planned windows per call either way.
     int fslot = -1;
     bool fused_out = false;
-    if (!stream_mode && precision == NLMC_F32 && order_mode == NLMC_ORDER_SHARED && !getenv("NLMC_NO_FUSED"))
+    // (fp64 mode: on the same windows when the field is an exact integer, no phase flags are in force and the call has one
+    // temperature per chain -- fused_f64_supported; the same bits as the sweep-by-sweep fp64 kernel)
+    const bool f64_fused = precision == NLMC_F64 && !c->has_flags && tab_ss == 0;
+    if (!stream_mode && (precision == NLMC_F32 || f64_fused) && order_mode == NLMC_ORDER_SHARED && !getenv("NLMC_NO_FUSED"))
         fslot = fused_plan_for(c, sweep0, n_sweeps, seed);
+    if (fslot >= 0 && f64_fused && !fused_f64_supported(c, c->fz[fslot].T)) fslot = -1;
     if (fslot >= 0) {
         const nlmc_ctx::FusedPlan &P = c->fz[fslot];
         const int w0 = (int)((sweep0 - P.sweep0) / (uint32_t)P.T), nw = n_sweeps / P.T;
         if (!any_out && tab_ss == 0) {
             for (int j = 0; j < nw; ++j) {
                 int rc = run_fused(c, fslot, w0 + j, sweep0 + (uint32_t)(j * P.T), seed, tab_dev, tab_cs, 0, use_slots, false, false,
-                                   false, false, 0, 0, n_sweeps);
+                                   false, false, 0, 0, n_sweeps, f64_fused);
                 if (rc) return rc;
             }
             return NLMC_OK;
@@ -685,7 +717,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         const int w0 = (int)((sweep0 - P.sweep0) / (uint32_t)P.T), nw = n_sweeps / P.T;
         for (int j = 0; j < nw; ++j) {
             int rc = run_fused(c, fslot, w0 + j, sweep0 + (uint32_t)(j * P.T), seed, tab_dev + (size_t)j * P.T * tab_ss, tab_cs,
-                               tab_ss, use_slots, true, o.out_energy != nullptr, want_min, want_state, rec, j * P.T, n_sweeps);
+                               tab_ss, use_slots, true, o.out_energy != nullptr, want_min, want_state, rec, j * P.T, n_sweeps, f64_fused);
             if (rc) return rc;
         }
         return read_sweep_outputs(c, o, n_sweeps, rec, n_rec);
@@ -1023,7 +1055,16 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
     c->knob_no_prio = getenv("NLMC_FUSED_NOPRIO") != nullptr;
     c->knob_no_dbuf = getenv("NLMC_NO_DBUF") != nullptr;
     if (const char *e = getenv("NLMC_DBG_FLAGS")) c->knob_dbg_flags = atoi(e);
-    for (int k = 0; k < n; ++k) hq[k] = (int32_t)rq(h[k], qs);
+    bool exact_h = true;
+    for (int k = 0; k < n; ++k) {
+        hq[k] = (int32_t)rq(h[k], qs);
+        if (std::ldexp((double)hq[k], -qs) != h[k]) exact_h = false;
+        int64_t row = std::llabs((int64_t)hq[k]);
+        for (int e = rowptr[k]; e < rowptr[k + 1]; ++e) row += std::llabs((int64_t)e32[e].q);
+        c->xmax = (int)std::min<int64_t>(std::max<int64_t>(c->xmax, row), INT_MAX);
+    }
+    c->f64_exact = exact_q && exact_h;
+    if (const char *e = getenv("NLMC_F64_TIE_MASK")) c->knob_tie_mask = (unsigned)strtoul(e, nullptr, 0);
 
     // +16 entries of padding behind the row arrays: fixed-width row windows are read unconditionally (never used past the row end)
     const size_t R = (size_t)std::max(n_chains, 1), npad = (size_t)c->n_pad, nz = (size_t)nnz + 16;
@@ -1465,6 +1506,39 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     P.sweep0 = sweep0; P.windows = n_windows; P.T = T; P.seed = seed;
     if (out_planned) *out_planned = ok;
     return NLMC_OK;
+}
+
+int nlmc_fused_modes(nlmc_ctx *c, int window)
+{
+    if (!c) return 0;
+    return (fused_supported(c, window) ? 1 : 0) | (fused_f64_supported(c, window) ? 2 : 0);
+}
+
+int nlmc_probe_level_round(nlmc_ctx *c, int waves, int conflict_free, int rounds, int n_workgroups, double *out_ns_per_round)
+{
+    if (!c || !out_ns_per_round || waves < 1 || waves > 16 || rounds < 1 || n_workgroups < 1)
+        return fail(c, NLMC_ERR_ARG, "nlmc_probe_level_round: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int lds_bytes = 2 * 16384;
+    int *sink = nullptr;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&sink), sizeof(int)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = NLMC_OK;
+    float ms = 0.f;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
+    if (!rc) {
+        hipLaunchKernelGGL(k_level_round_probe, dim3(n_workgroups), dim3(waves * 64), (size_t)lds_bytes, c->stream, std::min(rounds, 256), conflict_free, lds_bytes, sink);   // warm-up
+        (void)hipEventRecord(e0, c->stream);
+        hipLaunchKernelGGL(k_level_round_probe, dim3(n_workgroups), dim3(waves * 64), (size_t)lds_bytes, c->stream, rounds, conflict_free, lds_bytes, sink);
+        (void)hipEventRecord(e1, c->stream);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess)
+            rc = fail(c, NLMC_ERR_HIP, "nlmc_probe_level_round: launch failed");
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    if (!rc) *out_ns_per_round = (double)ms * 1e6 / rounds;
+    return rc;
 }
 
 int nlmc_plan_get_levels(nlmc_ctx *c, int window, int32_t *out_level_chunk_offsets, int32_t capacity, int32_t *out_n_levels)

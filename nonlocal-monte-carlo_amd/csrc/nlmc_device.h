@@ -114,6 +114,29 @@ __device__ __forceinline__ double uniform_from(const u32x4 &r, double)
 // heat-bath acceptance of s=+1 in the fp64 mode:  u < 1/(1+2^z)  <=>  fma(u, 2^z, u) < 1,   z = -2 log2(e) beta x
 __device__ __forceinline__ bool accept_up(double u, double z) { return __fma_rn(u, exp2_spec(z), u) < 1.0; }
 
+// The same test as an integer threshold (fused windows of the fp64 mode).  u = k 2^-53 with the 53-bit integer
+// k = (x >> 5) << 26 | (y >> 6) of uniform_from; for a fixed E = 2^z > 0 the correctly rounded fma(u, E, u) is monotone
+// non-decreasing in u, so  { k : fma(k 2^-53, E, k 2^-53) < 1 }  is an initial segment [0, K) and accept_up(u, z) <=> k < K.
+// K in [1, 2^53] is found by bisection on the test itself (bracketed by an estimate first: a handful of steps instead
+// of 53) -- no second arithmetic, the same bits as accept_up by construction.
+__device__ __forceinline__ unsigned long long accept_count_spec(double z)
+{
+    const double E = exp2_spec(z);
+    const unsigned long long top = 1ull << 53;
+    auto acc = [&](unsigned long long k) { const double u = (double)k * 0x1p-53; return __fma_rn(u, E, u) < 1.0; };
+    unsigned long long lo = 0ull, hi = top;                  // acc(lo) holds (fma(0, E, 0) = 0 < 1); hi: first k known to fail, or 2^53
+    const double est_d = 0x1p53 / (1.0 + E);
+    const unsigned long long est = est_d >= 0x1p53 ? top : (unsigned long long)est_d;
+    const unsigned long long a = est > 8ull ? est - 8ull : 0ull, b = est + 8ull;
+    if (acc(a)) lo = a;
+    if (b < top && !acc(b)) hi = b;
+    for (int it = 0; it < 54 && hi - lo > 1ull; ++it) {
+        const unsigned long long mid = lo + ((hi - lo) >> 1);
+        if (acc(mid)) lo = mid; else hi = mid;
+    }
+    return hi;
+}
+
 // ---- "f32" throughput mode: logistic threshold from 32 random bits --------------------------------------------
 // log2(1.5 + t) on |t| <= 0.5: degree-7 minimax fit, fma Horner (max error 3.8e-7)
 __device__ __forceinline__ float log2_15_spec(float t)

@@ -623,6 +623,11 @@ struct SweepArgs {
     int lds_snap_off;         // k_sweep_fused<.., OUT>: three snapshot slots of n_pad bytes
     int8_t *snap_g;           // ... or, when they do not fit in LDS beside the threshold tables (n > ~9000): the same three slots
                               // per block in global memory, [blocks][3 n_pad + 16]; nullptr: LDS
+    // fused windows of the fp64 mode (k_sweep_fused<.., F64 = true>): the field is the exact integer X (J = Jq 2^-qs, h = hq 2^-qs
+    // exactly), the acceptance an integer threshold per value of X (accept_count_spec), built per chain in the kernel's prologue
+    int lds_kt_off;           // LDS offset of the threshold tables: Khi u32[2 xmax + 1] | Klo u32[2 xmax + 1]
+    int f64_xmax;             // largest |X| any row can reach: max_k (sum |Jq| + |hq|)
+    unsigned f64_tie_mask;    // 0xFFFFFFFF; a test knob (NLMC_F64_TIE_MASK) clears low bits so that the rare exact path runs often
     int dbg_flags;            // -DNLMC_DEBUG_KNOBS builds only (NLMC_DBG_FLAGS): 1 = no threshold production, 2 = no updates, 4 = no item loads,
                               // 512 / 1024 = bank-conflict-free addresses for the neighbour gather / the spin's own accesses (wrong results)
 };
@@ -1192,6 +1197,19 @@ __device__ __forceinline__ void fill_uniforms(double *ur, int n, uint32_t tt, ui
     }
 }
 
+// fused fp64 windows: the table of a sweep holds the 27 HIGH bits of every spin's 53-bit uniform (word 2 (k & 1) of the call
+// k >> 1, shifted); the 26 low bits are made again in the rare update whose high bits do not decide (k_sweep_fused<.., F64>)
+__device__ __forceinline__ void fill_uniform_words(unsigned *tab, int n, uint32_t tt, uint32_t gc, uint32_t k0, uint32_t k1, int tid, int nt)
+{
+    const int nblk = (n + 1) / 2;
+    for (int b = tid; b < nblk; b += 2 * nt) {
+        u32x4 r0, r1;
+        philox4x32_10_x2((uint32_t)b, (uint32_t)(b + nt), tt, gc, NLMC_TAG_UNIFORM, k0, k1, r0, r1);
+        reinterpret_cast<uint2 *>(tab)[b] = make_uint2(r0.x >> 5, r0.z >> 5);
+        if (b + nt < nblk) reinterpret_cast<uint2 *>(tab)[b + nt] = make_uint2(r1.x >> 5, r1.z >> 5);
+    }
+}
+
 // The pipelined level loop of one sweep (see k_sweep_philox).  TAIL: this wave may hold rows longer than 8 entries and
 // therefore also loads / folds the second half of the 16-entry row window.
 struct NoGen { __device__ __forceinline__ void operator()(int) const {} };
@@ -1494,7 +1512,9 @@ struct FusedGenParams { uint32_t gc; int gtid, gnt, nblk, nj, Tn; };
 #endif
 // (plain macros over local variables: with lambdas the captured state was kept in scratch memory)
 #define NLMC_GEN_STATE int g_u = 2, g_slot = 2, g_w0 = 0, g_wend = 0, g_wlen = 1, g_acc = 0, g_sidx = 0; u32x4 g_r{0u, 0u, 0u, 0u};
-#define NLMC_GEN_NSTEP 3                    /* steps per call: Philox rounds 0-4 | rounds 5-9 | four logits + store */
+/* steps per call: Philox rounds 0-4 | rounds 5-9 | four logits + store  (fp64 mode: rounds 0-4 | rounds 5-9 + store of the two
+   27-bit high words of the call's two uniforms -- one call serves 2 spins there, 4 here) */
+#define NLMC_GEN_NSTEP (g_f64 ? 2 : 3)
 #define NLMC_GEN_ARM(a, gp)                                                                                             \
     {                                                                                                                   \
         typedef const int32_t __attribute__((address_space(4))) *const_i32_;                                            \
@@ -1513,6 +1533,10 @@ struct FusedGenParams { uint32_t gc; int gtid, gnt, nblk, nj, Tn; };
         if (ph_ == 0) {                                                                                                 \
             NLMC_GEN_DBG_PHILOX                                                                                         \
             g_r = philox4x32_rounds(u32x4{(uint32_t)b, a.sweep0 + (uint32_t)g_u, gp.gc, NLMC_TAG_UNIFORM}, a.seed_lo, a.seed_hi, 0, 5); \
+        } else if (g_f64) {                                                                                             \
+            typedef nlmc_i2 __attribute__((address_space(3))) *lds_i2_;                                                 \
+            g_r = philox4x32_rounds(g_r, a.seed_lo, a.seed_hi, 5, 5);                                                   \
+            if (b < gp.nblk) ((lds_i2_)(uintptr_t)(unsigned)(a.lds_u_off + g_slot * a.lds_u_stride))[b] = nlmc_i2{(int)(g_r.x >> 5), (int)(g_r.z >> 5)}; \
         } else if (ph_ == 1) {                                                                                          \
             NLMC_GEN_DBG_PHILOX                                                                                         \
             g_r = philox4x32_rounds(g_r, a.seed_lo, a.seed_hi, 5, 5);                                                   \
@@ -1544,10 +1568,12 @@ struct FusedGenParams { uint32_t gc; int gtid, gnt, nblk, nj, Tn; };
 // when a sweep ends its sum is reduced over the workgroup (one LDS atomic per wave, read after the level's barrier):
 // that gives E after every sweep, the strict running minimum (first argmin, like np.argmin) and, from the snapshot,
 // the argmin / recorded states -- NMC/nmc.py:386-395 -- without giving up the overlap of consecutive sweeps.
-template <bool DIAG, bool FLAGS, bool PAIR, bool GEN, int FMT, bool OUT = false>
+template <bool DIAG, bool FLAGS, bool PAIR, bool GEN, int FMT, bool OUT = false, bool F64 = false>
 __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *lds_raw, int wv, int lane, int nl, float cq0,
                                              float cq1, long long &e_loc, const FusedGenParams gp)
 {
+    constexpr bool g_f64 = F64;
+    static_assert(!(F64 && FLAGS), "fused fp64 windows: plain chains only (a scaled row's field is not an exact integer)");
     NLMC_GEN_STATE
     NLMC_GEN_ARM(a, gp)
     typedef const int32_t __attribute__((address_space(4))) *const_i32o;
@@ -1579,6 +1605,10 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
     unsigned v_u_off = (unsigned)a.lds_u_off, v_neg_off = (unsigned)a.lds_neg_off;
     int v_eshift = a.eshift;
     asm volatile("" : "+v"(v_u_off), "+v"(v_neg_off), "+v"(v_eshift));
+    // fp64 mode: LDS address of Khi[X = 0] (entry X sits 4 X bytes from it), bytes from a Khi entry to its Klo entry
+    unsigned v_kt0 = (unsigned)(a.lds_kt_off + 4 * a.f64_xmax), v_tie = a.f64_tie_mask;
+    if (F64) asm volatile("" : "+v"(v_kt0), "+v"(v_tie));
+    typedef const unsigned __attribute__((address_space(3))) *lds_u32;
     constexpr int NP = Item::NP, NE = Item::NE;
     const int plane_bytes = a.fz_pstride * 16;
     const __amdgpu_buffer_rsrc_t r_ell = __builtin_amdgcn_make_buffer_rsrc(const_cast<EdgeQ *>(a.ell32), 0, (NLMC_FZ_W / 2) * plane_bytes, 0x00020000);
@@ -1605,7 +1635,8 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
 #pragma unroll
         for (int q = 0; q < NP; ++q) it.pk[q] = __builtin_amdgcn_raw_buffer_load_b128(r_ell, v16, c * 1024 + q * plane_bytes, 0);
     };
-    auto update = [&](const Item &it) __attribute__((always_inline)) {
+    auto update = [&](const Item &it, int lv) __attribute__((always_inline)) {
+        (void)lv;
 #ifdef NLMC_DEBUG_KNOBS
         if (a.dbg_flags & 2) { asm volatile("" :: "v"(it.hd.x), "v"(it.pk[0].x), "v"(it.pk[Item::NP - 1].x)); return; }   // timing experiment: loads only
 #endif
@@ -1676,9 +1707,34 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             if (DIAG) { const int Xdp = __builtin_amdgcn_mov_dpp(Xd, 0xB1, 0xF, 0xF, true); Xd += pair ? Xdp : 0; }
             second = pair && (lane & 1);
         }
+        // fp64 mode: s' = +1 iff the 53-bit integer of the update's uniform lies below K(X) (accept_count_spec).  The table of
+        // the sweep holds the 27 high bits; they decide unless they EQUAL the high word of K(X) (probability 2^-27 per
+        // update: ~0.2 updates per launch of the bench shape) -- then the low 26 bits are made again with one Philox call.
+        bool up64 = false;
+        if (F64) {
+            const unsigned hk = __float_as_uint(wk);
+            const unsigned kaddr = ((unsigned)X << 2) + v_kt0;
+            const unsigned kh = *(lds_u32)(uintptr_t)kaddr;
+            up64 = hk < kh;
+            const bool tie = ((hk ^ kh) & v_tie) == 0u;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(tie) != 0ull, 0)) {
+                if (tie) {
+                    // sweep of the item: the first t = slot (mod 3) whose last level is not before this one (sweep t + 3
+                    // starts behind the end of sweep t + 1); a dummy item (slot 3) gets an arbitrary draw for its scratch spin
+                    typedef const int32_t __attribute__((address_space(4))) *const_i32s;
+                    const unsigned tw_ = (unsigned)hx >> 16, np_ = (unsigned)a.g.n_pad;
+                    int t_ = tw_ >= 3u * np_ ? 3 : tw_ >= 2u * np_ ? 2 : tw_ >= np_ ? 1 : 0;
+                    while (t_ + 3 < a.n_sweeps && lv > ((const_i32s)(uintptr_t)a.fsend)[t_]) t_ += 3;
+                    const u32x4 r_ = philox4x32_10(ka >> 1, a.sweep0 + (uint32_t)t_, gp.gc, NLMC_TAG_UNIFORM, a.seed_lo, a.seed_hi);
+                    const unsigned lo_ = ((ka & 1u) ? r_.w : r_.y) >> 6;
+                    const unsigned kl = *(lds_u32)(uintptr_t)(kaddr + 4u * (unsigned)(2 * a.f64_xmax + 1));
+                    up64 = hk < kh || (hk == kh && lo_ < kl);
+                }
+            }
+        }
         if (!OUT) {
             const float z = ((FLAGS && f == 1u) ? cq1 : cq0) * (float)X;
-            int sn = (z < wk) ? 1 : -1;
+            int sn = F64 ? (up64 ? 1 : -1) : (z < wk) ? 1 : -1;
             if (FLAGS) sn = (f >= 2u) ? so : sn;                                    // frozen: unchanged
             const int cv = (PAIR && second) ? 0 : (so - sn) << v_eshift;
             e_loc += (long long)(DIAG ? X - Xd : X) * (long long)cv;
@@ -1689,7 +1745,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             const bool is_old = tw - o_lo < (unsigned)o_npad;
             const float cqa = is_old ? cqo0 : cqn0, cqb = is_old ? cqo1 : cqn1;
             const float z = ((FLAGS && f == 1u) ? cqb : cqa) * (float)X;
-            int sn = (z < wk) ? 1 : -1;
+            int sn = F64 ? (up64 ? 1 : -1) : (z < wk) ? 1 : -1;
             if (FLAGS) sn = (f >= 2u) ? so : sn;
             const int cv = (PAIR && second) ? 0 : (so - sn) << v_eshift, cvo = is_old ? cv : 0;
             const long long Xt = (long long)(DIAG ? X - Xd : X);
@@ -1765,7 +1821,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
             NLMC_FW0                                                                        \
             hnxt = ((lv) + 2 < nl) && ((b2) + wv < (b3));                                   \
             if (GEN) NLMC_GEN(a, gp, lv)                                                    \
-            if (hcur) { update(cur); NLMC_FCALL }                                           \
+            if (hcur) { update(cur, lv); NLMC_FCALL }                                       \
             issue(nxt, (b2) + wv, hnxt NLMC_DBG_NOLOAD);                                    \
             const bool end_ = OUT && __builtin_expect((lv) == o_end, 0);   /* rare: once per sweep */ \
             if (end_) NLMC_OUT_PRE                                                          \
@@ -1798,9 +1854,14 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
 
 // FMT is a parameter of the KERNEL (round 3; it was a run-time switch over three inlined copies of every level-loop
 // variant: 12 copies per kernel, whose spilled scalars together took 19 vector registers of the per-sweep-output kernels)
-template <bool DIAG, bool FLAGS, bool OUT, int FMT>
+// F64: the fp64 mode (k_sweep_philox<double>) on the same windows, for instances whose couplings AND fields are exact multiples
+// of 2^-qs.  The fp64 field of the spec is then the exact integer X times 2^-qs whatever the order of the sum, z = cb x takes
+// one value per X, and the spec's test fma(u, 2^z, u) < 1 is a threshold on the 53-bit integer of u (accept_count_spec): the
+// update is the fixed-point one with `k_u < K[X]` in place of `z < W(r)`.  Same bits as the sweep-by-sweep fp64 kernel.
+template <bool DIAG, bool FLAGS, bool OUT, int FMT, bool F64 = false>
 __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
 {
+    constexpr bool g_f64 = F64;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     if ((unsigned)reinterpret_cast<size_t>(lds_raw) != 0u) __builtin_trap();   // spins at LDS offset 0: column == address
     const int n = a.g.n, n_pad = a.g.n_pad, tid = threadIdx.x, nt = blockDim.x;
@@ -1845,12 +1906,27 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
         if (tid < 4) red[tid] = 0;
     }
     // thresholds of the first two sweeps (the third table is produced inside the level loop like all later ones)
-    for (int t = 0; t < min(2, Tn) NLMC_DBG_NOPROLOGUE; ++t)
-        fill_uniforms(reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(ur) + (size_t)t * a.lds_u_stride), n,
-                      a.sweep0 + (uint32_t)t, gc, a.seed_lo, a.seed_hi, tid, nt);
+    for (int t = 0; t < min(2, Tn) NLMC_DBG_NOPROLOGUE; ++t) {
+        float *tab_t = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(ur) + (size_t)t * a.lds_u_stride);
+        if (F64) fill_uniform_words(reinterpret_cast<unsigned *>(tab_t), n, a.sweep0 + (uint32_t)t, gc, a.seed_lo, a.seed_hi, tid, nt);
+        else fill_uniforms(tab_t, n, a.sweep0 + (uint32_t)t, gc, a.seed_lo, a.seed_hi, tid, nt);
+    }
+    if (F64) {
+        // K(X) for every field value a row can reach, at this chain's temperature: z = cb (X 2^-qs) as in update_spin<double>.
+        // The trailing lanes of the workgroup take it (they have one Philox call less than the others above).
+        const int ne = 2 * a.f64_xmax + 1;
+        unsigned *kt = reinterpret_cast<unsigned *>(lds_raw + a.lds_kt_off);
+        const double cb = a.tab[(size_t)row * a.tab_cs];
+        for (int i = nt - 1 - tid; i < ne; i += nt) {
+            const double xf = (double)(i - a.f64_xmax) * a.qinv64;
+            const unsigned long long K = accept_count_spec(cb * xf);
+            kt[i] = (unsigned)(K >> 26);
+            kt[ne + i] = (unsigned)(K & 0x3FFFFFFull);
+        }
+    }
     __syncthreads();
 
-    const int g0 = a.f_gen0 * 64, nblk = (n + 3) / 4, gnt = nt - g0;
+    const int g0 = a.f_gen0 * 64, nblk = F64 ? (n + 1) / 2 : (n + 3) / 4, gnt = nt - g0;
     // calls per sweep of THIS wave: block b = (tid - g0) + call * gnt must lie below nblk for at least one of its lanes
     // (wave-uniform; the waves at the end of the producing range do one call less when gnt does not divide nblk)
     const int gwave0 = __builtin_amdgcn_readfirstlane((tid - g0) & ~63);
@@ -1863,7 +1939,7 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
     if (wv < a.f_workers) {
         const bool role_long = wv < a.hi_max[0];           // chunks that may hold lane PAIRS (rows longer than 8 entries) come first
         const int variant = (role_long ? 2 : 0) + (is_gen ? 1 : 0);
-#define NLMC_FL(P, G) fused_levels<DIAG, FLAGS, P, G, FMT, OUT>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp)
+#define NLMC_FL(P, G) fused_levels<DIAG, FLAGS, P, G, FMT, OUT, F64>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp)
         switch (variant) { case 0: NLMC_FL(false, false); break; case 1: NLMC_FL(false, true); break;
                            case 2: NLMC_FL(true, false); break; default: NLMC_FL(true, true); break; }
 #undef NLMC_FL

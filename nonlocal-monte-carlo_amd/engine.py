@@ -294,6 +294,11 @@ class Engine:
                                                 ctypes.byref(k)))
         return int(k.value)
 
+    def fused_modes(self, window):
+        """Precisions that may run on fused windows of `window` sweeps here: subset of {"f32", "f64"} (nlmc_fused_modes)."""
+        m = int(self._L.nlmc_fused_modes(self._ctx, int(window)))
+        return {p for bit, p in ((1, "f32"), (2, "f64")) if m & bit}
+
     def plan_slot(self, slot):
         """Fused-window plans live in two slots (include/nlmc.h: nlmc_plan_slot); planning calls write to the selected one."""
         self._ck(self._L.nlmc_plan_slot(self._ctx, int(slot)))
@@ -501,6 +506,13 @@ class Engine:
         self._ck(self._L.nlmc_timing_total(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)))
         return {"ms_levelize": a.value, "ms_sweep": b.value, "launches_sweep": c.value, "launches_timed": d.value}
 
+    def probe_level_round(self, waves=16, conflict_free=True, rounds=20000, n_workgroups=256):
+        """ns per level-synchronous round (barrier + 8 LDS byte gathers + write) on this device (nlmc_probe_level_round)."""
+        out = ctypes.c_double(0)
+        self._ck(self._L.nlmc_probe_level_round(self._ctx, int(waves), int(bool(conflict_free)), int(rounds), int(n_workgroups),
+                                                ctypes.byref(out)))
+        return out.value
+
     def last_schedule_stats(self):
         a, b = ctypes.c_int64(0), ctypes.c_int64(0)
         self._ck(self._L.nlmc_last_schedule_stats(self._ctx, ctypes.byref(a), ctypes.byref(b)))
@@ -609,7 +621,9 @@ class RoundPlanner:
         output variant of the kernel) when the plan covers them."""
         self.eng, self.sweep0, self.R, self.S, self.seed, self.precision = eng, int(sweep0), int(n_rounds), int(sweeps_per_round), int(seed), precision
         self.slot, self.beta, self.fused_outputs = int(slot), beta, bool(fused_outputs)
-        self.window = fused_window(self.S) if precision == "f32" else 0
+        self.window = fused_window(self.S)
+        if self.window and precision != "f32" and (not hasattr(eng, "fused_modes") or precision not in eng.fused_modes(self.window)):
+            self.window = 0              # fp64 mode: fused windows only where the field is an exact integer (nlmc_fused_modes)
         per_round = max(1, self.S * eng.n * self.BYTES_PER_UPDATE)
         self.chunk = max(1, min(self.R, int(budget_bytes // per_round)))
         if chunk_rounds:

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     # the interface version the header states, the binding expects and the library was built with are one number
     hdr = open(os.path.join(REPO, "include", "nlmc.h")).read()
     ver = int(re.search(r"#define\s+NLMC_ABI_VERSION\s+(\d+)", hdr).group(1))
-    assert L.nlmc_abi_version() == ver == P._abi.ABI_VERSION == 2
+    assert L.nlmc_abi_version() == ver == P._abi.ABI_VERSION == 3
 
 
 def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
@@ -37,8 +37,8 @@ def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
     monkeypatch.setattr(P._abi, "ABI_VERSION", 1)
     with pytest.raises(ImportError, match="ABI version"):
         P._abi.lib()
-    monkeypatch.setattr(P._abi, "ABI_VERSION", 2)
-    assert P._abi.lib().nlmc_abi_version() == 2
+    monkeypatch.setattr(P._abi, "ABI_VERSION", 3)
+    assert P._abi.lib().nlmc_abi_version() == 3
 
 
 def test_no_cpu_fallback_without_device():
