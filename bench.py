@@ -47,7 +47,8 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 N_SPINS = 10_000
 REPLICAS_PER_GPU = 256
 S_SWAP = 10
-ROUNDS_PER_STEP = 4096       # 4096 rounds x ~0.125 ms: a step is ~0.5 s, the driver's --steps 20 times ~10 s per leg (VERDICT r3 #1c)
+ROUNDS_PER_STEP = int(os.environ.get("NLMC_BENCH_ROUNDS_PER_STEP", "4096"))   # (the override is for the profiler passes of scripts/profile_round.sh)
+# 4096 rounds x ~0.125 ms: a step is ~0.5 s, the driver's --steps 20 times ~10 s per leg (VERDICT r3 #1c)
 EVENT_EVERY = int(os.environ.get("NLMC_BENCH_EVENT_EVERY", "8"))   # HIP events around every 8th sweep-kernel launch of the timed region
 PLAN_CHUNK_ROUNDS = 256      # rounds whose schedules are built together (one workgroup per window: fills the chip)
 BETA_MIN, BETA_MAX = 0.05, 4.0

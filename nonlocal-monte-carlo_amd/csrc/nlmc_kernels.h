@@ -625,6 +625,9 @@ struct SweepArgs {
                               // per block in global memory, [blocks][3 n_pad + 16]; nullptr: LDS
     // fused windows of the fp64 mode (k_sweep_fused<.., F64 = true>): the field is the exact integer X (J = Jq 2^-qs, h = hq 2^-qs
     // exactly), the acceptance an integer threshold per value of X (accept_count_spec), built per chain in the kernel's prologue
+    // random numbers keyed by (ladder, GLOBAL temperature slot) instead of by chain (nlmc_apt_shard; 0: by chain): the id of the
+    // chain on slot s of local ladder j is j rng_stride + rng_base + s, whichever chain currently sits there
+    int rng_stride, rng_base, rng_ladder_len;
     int lds_kt_off;           // LDS offset of the threshold tables: Khi u32[2 xmax + 1] | Klo u32[2 xmax + 1]
     int f64_xmax;             // largest |X| any row can reach: max_k (sum |Jq| + |hq|)
     unsigned f64_tie_mask;    // 0xFFFFFFFF; a test knob (NLMC_F64_TIE_MASK) clears low bits so that the rare exact path runs often
@@ -1325,8 +1328,9 @@ __global__ __launch_bounds__(sizeof(T) == 8 ? 512 : DIAG ? 768 : 1024) void k_sw
     const int n = x.n, tid = x.tid, nt = x.nt, c = x.c;
     T *ur = reinterpret_cast<T *>(lds_raw + a.lds_u_off);
     int *loff = reinterpret_cast<int *>(lds_raw + a.lds_loff_off);
-    const uint32_t gc = (uint32_t)(a.chain_base + c);
-    const int row = a.slot_of_chain ? a.slot_of_chain[gc] : c;
+    const uint32_t gc_chain = (uint32_t)(a.chain_base + c);
+    const int row = a.slot_of_chain ? a.slot_of_chain[gc_chain] : c;
+    const uint32_t gc = (a.rng_stride && a.slot_of_chain) ? (uint32_t)((c / a.rng_ladder_len) * a.rng_stride + a.rng_base + row) : gc_chain;
     const double esc = __longlong_as_double((long long)(1023 + a.escale) << 52);   // 2^escale
 
 #ifdef NLMC_STAMPS
@@ -1869,8 +1873,9 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     float *ur = reinterpret_cast<float *>(lds_raw + a.lds_u_off);
     long long *red = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);
-    const uint32_t gc = (uint32_t)(a.chain_base + c);
-    const int row = a.slot_of_chain ? a.slot_of_chain[gc] : c;
+    const uint32_t gc_chain = (uint32_t)(a.chain_base + c);
+    const int row = a.slot_of_chain ? a.slot_of_chain[gc_chain] : c;
+    const uint32_t gc = (a.rng_stride && a.slot_of_chain) ? (uint32_t)((c / a.rng_ladder_len) * a.rng_stride + a.rng_base + row) : gc_chain;
     const int Tn = a.n_sweeps;
 #ifdef NLMC_DEBUG_KNOBS
     const int nl = (a.dbg_flags & 128) ? 0 : a.nlev[0];      // timing experiment: prologue + epilogue only

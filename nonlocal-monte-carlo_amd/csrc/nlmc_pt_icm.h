@@ -282,6 +282,8 @@ struct IcmRoundArgs {
     double *energy_sink;      // [n_chains] or nullptr
     int eshift, escale;       // escale - qs
     int lds_cand_off, lds_sa_off, lds_sb_off;
+    int slot0;                // pairing on the fly: global index of local slot 0 (the pairing keys carry the GLOBAL slot)
+    int rng_stride, rng_base; // != 0: the pick is keyed by the (ladder, global slot) ids of the two chains instead of their chain ids
 };
 
 __global__ __launch_bounds__(1024) void k_icm_round(IcmRoundArgs a)
@@ -294,18 +296,19 @@ __global__ __launch_bounds__(1024) void k_icm_round(IcmRoundArgs a)
     __shared__ int sh_scan[17];
     __shared__ long long sh_dE[2];
     const int n = a.g.n, n_pad = a.g.n_pad, tid = threadIdx.x, nt = blockDim.x, p = blockIdx.x;
-    __shared__ int sh_pair[2];
+    __shared__ int sh_pair[2], sh_lad[2];
     if (!a.pairs) {                        // pairing on the fly (pair_K <= blockDim.x: checked by the host)
         const int half = a.pair_K / 2, r = p / half, i = p % half;
+        const uint32_t rg = (uint32_t)(r + a.slot0);
         if (tid < a.pair_K) {
-            const uint32_t kj = philox4x32_10((uint32_t)tid, a.round, (uint32_t)r, 6u /*NLMC_TAG_ICM_PAIR*/, a.seed_lo, a.seed_hi).x;
+            const uint32_t kj = philox4x32_10((uint32_t)tid, a.round, rg, 6u /*NLMC_TAG_ICM_PAIR*/, a.seed_lo, a.seed_hi).x;
             int rank = 0;
             for (int q = 0; q < a.pair_K; ++q) {
                 if (q == tid) continue;
-                const uint32_t kq = philox4x32_10((uint32_t)q, a.round, (uint32_t)r, 6u, a.seed_lo, a.seed_hi).x;
+                const uint32_t kq = philox4x32_10((uint32_t)q, a.round, rg, 6u, a.seed_lo, a.seed_hi).x;
                 rank += (kq < kj) || (kq == kj && q < tid);
             }
-            if (rank == 2 * i || rank == 2 * i + 1) sh_pair[rank & 1] = a.chain_of_slot[(size_t)tid * a.pair_R + r];
+            if (rank == 2 * i || rank == 2 * i + 1) { sh_pair[rank & 1] = a.chain_of_slot[(size_t)tid * a.pair_R + r]; sh_lad[rank & 1] = tid; }
         }
         __syncthreads();
     }
@@ -393,7 +396,13 @@ __global__ __launch_bounds__(1024) void k_icm_round(IcmRoundArgs a)
         return;
     }
     // pick component number floor(r ncomp / 2^32) in ascending-label order (NPT/apt_ICM.py:232-233)
-    const uint32_t r = philox4x32_10((uint32_t)(a.chain_base + ca), a.round, (uint32_t)(a.chain_base + cb), NLMC_TAG_ICM, a.seed_lo, a.seed_hi).x;
+    uint32_t ida = (uint32_t)(a.chain_base + ca), idb = (uint32_t)(a.chain_base + cb);
+    if (a.rng_stride && !a.pairs) {        // keyed by (ladder, global slot): the same pick whichever chains sit on the two places
+        const int rl = p / (a.pair_K / 2);
+        ida = (uint32_t)(sh_lad[0] * a.rng_stride + a.rng_base + rl);
+        idb = (uint32_t)(sh_lad[1] * a.rng_stride + a.rng_base + rl);
+    }
+    const uint32_t r = philox4x32_10(ida, a.round, idb, NLMC_TAG_ICM, a.seed_lo, a.seed_hi).x;
     const int pick = (int)(((unsigned long long)r * (unsigned long long)ncomp) >> 32);
     const int chunk = (n + nt - 1) / nt;
     const int b = min(tid * chunk, n), e = min(b + chunk, n);

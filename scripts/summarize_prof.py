@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Collect rocprofv3 outputs of one profiling round into the small CSVs kept under profiles/.
 
-    python scripts/summarize_prof.py <tag> <stats_dir> <fetch_dir> <write_dir> [<sq_dir> ...]
+    python scripts/summarize_prof.py <tag> <leg> <stats_dir> <fetch_dir> <write_dir> [<sq_dir> ...]
+
+<leg>: "f64" (the headline leg of bench.py) or "f32" (its fixed-point leg): file names and the key of current_sweep_pmc.json.
 
 <stats_dir>: rocprofv3 --kernel-trace --stats;  <fetch_dir>/<write_dir>: separate --pmc FETCH_SIZE / WRITE_SIZE passes;
 <sq_dir>: optional further --pmc passes.  Units and the gfx950 read correction follow MI355X_MICROARCH.md (HBM section).
@@ -37,27 +39,27 @@ def counters(d):
 
 
 def main():
-    tag, stats_dir, fetch_dir, write_dir, *sq_dirs = sys.argv[1:]
+    tag, leg, stats_dir, fetch_dir, write_dir, *sq_dirs = sys.argv[1:]
+    cmdline = f"NLMC_BENCH_ROUNDS_PER_STEP=512 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-second-leg --headline {leg}"
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
-    with open(find(stats_dir, "kernel_stats.csv")) as f, open(os.path.join(out, f"{tag}_bench_n1_kernel_stats.csv"), "w") as g:
+    with open(find(stats_dir, "kernel_stats.csv")) as f, open(os.path.join(out, f"{tag}_{leg}_bench_n1_kernel_stats.csv"), "w") as g:
         g.write(f.read())
     fc = counters(fetch_dir)
     kname = fc["__kernel__"]
     fs, ws = fc["FETCH_SIZE"], counters(write_dir)["WRITE_SIZE"]
     hbm = int(round((2.0 * fs[1] + ws[1]) * 1024))
-    with open(os.path.join(out, f"{tag}_sweep_hbm_traffic_pmc.csv"), "w") as g:
-        g.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE  and (separate pass)  --pmc WRITE_SIZE  -- python3 bench.py "
-                "--steps 1 --warmup 1 --no-cpu-baseline --no-f64-leg\n"
+    with open(os.path.join(out, f"{tag}_{leg}_sweep_hbm_traffic_pmc.csv"), "w") as g:
+        g.write(f"# rocprofv3 --kernel-trace --pmc FETCH_SIZE  and (separate pass)  --pmc WRITE_SIZE  -- {cmdline}\n"
                 f"# per launch of {kname} (256 chains x 1e4 spins x 10 sweeps); counter unit = KiB\n"
                 "# gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of wide coalesced reads -> "
                 "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024\n"
                 "counter,n_launches,mean_per_launch\n"
                 f"FETCH_SIZE,{fs[0]},{fs[1]:.1f}\nWRITE_SIZE,{ws[0]},{ws[1]:.1f}\n"
-                f"# hbm_bytes_per_launch,{hbm}\n# algorithmic_bytes_per_launch,{256 * 10_000 * 10 * 63}\n")
+                f"# hbm_bytes_per_launch,{hbm}\n# algorithmic_bytes_per_launch,{256 * 10_000 * 10 * (91 if leg == 'f64' else 63)}\n")
     if sq_dirs:
-        with open(os.path.join(out, f"{tag}_sweep_pmc_summary.csv"), "w") as g:
-            g.write("# rocprofv3 --kernel-trace --pmc <counters, one pass per line group> -- python3 bench.py --steps 1 "
-                    f"--warmup 1 --no-cpu-baseline --no-f64-leg\n# {kname}, per launch (256 chains x 1e4 spins x 10 sweeps)\n"
+        with open(os.path.join(out, f"{tag}_{leg}_sweep_pmc_summary.csv"), "w") as g:
+            g.write(f"# rocprofv3 --kernel-trace --pmc <counters, one pass per line group> -- {cmdline}\n"
+                    f"# {kname}, per launch (256 chains x 1e4 spins x 10 sweeps)\n"
                     "counter,mean_per_launch\n")
             for d in sq_dirs:
                 for k, val in sorted(counters(d).items()):
@@ -68,7 +70,7 @@ def main():
     allc = {}
     for d in sq_dirs:
         allc.update({k: v[1] for k, v in counters(d).items() if k != "__kernel__"})
-    cur = {"source": f"profiles/{tag}_sweep_pmc_summary.csv, profiles/{tag}_sweep_hbm_traffic_pmc.csv (rocprofv3 --pmc, separate passes)",
+    cur = {"source": f"profiles/{tag}_{leg}_sweep_pmc_summary.csv, profiles/{tag}_{leg}_sweep_hbm_traffic_pmc.csv (rocprofv3 --pmc, separate passes)",
            "kernel": kname, "hbm_bytes_per_launch": hbm}
     if "SQ_INSTS_VALU" in allc:
         cur["valu_wave_insts_per_launch"] = allc["SQ_INSTS_VALU"]
@@ -80,8 +82,17 @@ def main():
         cur["lds_bank_conflict_frac"] = allc["SQ_LDS_BANK_CONFLICT"] / allc["SQ_LDS_IDX_ACTIVE"]
     if allc.get("SQ_WAVE_CYCLES"):
         cur["wait_any_frac"] = allc["SQ_WAIT_ANY"] / allc["SQ_WAVE_CYCLES"]
-    with open(os.path.join(out, "current_sweep_pmc.json"), "w") as g:
-        json.dump(cur, g, indent=1)
+    path = os.path.join(out, "current_sweep_pmc.json")
+    try:
+        with open(path) as g:
+            both = json.load(g)
+        if "kernel" in both:               # the one-leg layout of earlier rounds
+            both = {}
+    except (OSError, ValueError):
+        both = {}
+    both[leg] = cur
+    with open(path, "w") as g:
+        json.dump(both, g, indent=1)
     print("hbm_bytes_per_launch", hbm)
 
 
