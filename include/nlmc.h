@@ -159,6 +159,39 @@ int nlmc_probe_level_round(nlmc_ctx *ctx, int waves, int conflict_free, int roun
  * no fused schedule).  capacity = entries of the caller's array (>= levels + 1; 1025 always suffices). */
 int nlmc_plan_get_levels(nlmc_ctx *ctx, int window, int32_t *out_level_chunk_offsets, int32_t capacity, int32_t *out_n_levels);
 
+/* Is librccl loadable in this process (NLMC_OK), or why not (NLMC_ERR_UNSUPPORTED + nlmc_last_error(NULL))?  Every rank asks
+ * BEFORE nlmc_comm_init and the ranks agree on the answer over the process group that is already up, so that no rank waits in
+ * ncclCommInitRank for one that could not load the library. */
+int nlmc_comm_probe(void);
+/* Asynchronous failures of the library-issued collectives: ncclCommGetAsyncError, then (timeout_ms >= 0) a BOUNDED wait for the work
+ * queued on the context's stream.  On an error or a timeout (a lost rank leaves the others inside a collective for ever) the
+ * communicator is aborted with ncclCommAbort, the context drops it, and the call returns NLMC_ERR_HIP: the caller exits non-zero
+ * ("RCCL async error -> abort").  timeout_ms < 0: the error flag only, no wait.  NLMC_OK without a communicator. */
+int nlmc_comm_check(nlmc_ctx *ctx, int timeout_ms);
+
+/* ---- APT + iso-cluster moves with the temperature ladder cut into SLOT blocks, one per GPU (NPT/apt_ICM.py:215-285; SURVEY.md
+ * section 8e: "keep all sub-replicas of a beta on the same GPU").  Rank w of `world` creates a SELF-CONTAINED context of K ladders
+ * (sub-replicas) x Rw local slots (chain_base 0, n_chains_global == n_chains = K Rw, nlmc_pt_init with ITS block
+ * beta_global[w Rw .. (w+1) Rw)) and declares it shard w of a global ladder of R_global = world Rw slots:
+ *   - random numbers of the sweeps, of the Houdayer pairing and of the cluster pick are keyed by (ladder, GLOBAL slot) instead of by
+ *     chain, so exchanging two chains' labels and exchanging their configurations are the same step of the Markov chain;
+ *   - nlmc_pt_plan plans the pair selections of the GLOBAL ladder (every rank the same ones);
+ *   - nlmc_sweep_philox(beta = NULL), nlmc_icm_round_ladders work on the block as on any context;
+ *   - the swap round is nlmc_apt_swap_collective (one process per GPU: the library issues ONE ncclAllGather of K Rw int64 tracked
+ *     energies per rank and ONE grouped ncclSend/ncclRecv of the K boundary configurations with each neighbour, on the kernels'
+ *     stream) or nlmc_apt_pack + nlmc_apt_swap_host (one process driving several contexts; the same data through host memory):
+ *     pairs inside a block are label exchanges, an accepted pair across a block boundary moves the two configurations.
+ * The states on every (ladder, global slot) are bit-identical for any `world` (world = 1 included). */
+int nlmc_apt_shard(nlmc_ctx *ctx, int R_global, int world, int rank, const double *beta_global /*[R_global]*/);
+/* Tracked energies by (ladder, local slot) in units of 2^-escale -> out_slot_efix [K][Rw]; the configurations on local slot 0 /
+ * Rw - 1 of every ladder -> out_lo / out_hi [K][n] (any of the three may be NULL). */
+int nlmc_apt_pack(nlmc_ctx *ctx, int64_t *out_slot_efix, int8_t *out_lo, int8_t *out_hi);
+/* efix_all [world][K][Rw]: every rank's nlmc_apt_pack energies; recv_lo = rank - 1's out_hi, recv_hi = rank + 1's out_lo (NULL at the
+ * ends of the ladder).  out_pairs [K][n_pairs][2] GLOBAL slots, out_accepted [K][n_pairs]: the full log, identical on every rank. */
+int nlmc_apt_swap_host(nlmc_ctx *ctx, uint32_t round, uint64_t seed, int n_pairs, const int64_t *efix_all, const int8_t *recv_lo,
+                       const int8_t *recv_hi, int32_t *out_pairs, uint8_t *out_accepted);
+int nlmc_apt_swap_collective(nlmc_ctx *ctx, uint32_t round, uint64_t seed, int n_pairs, int32_t *out_pairs, uint8_t *out_accepted);
+
 /* Replica exchange (NPT/npt.py:602-683).  Chains are grouped into ladders of ladder_len consecutive global
  * chain ids; slot r of a ladder runs at beta_list[r].  Accepted swaps exchange the beta slots of two chains
  * (label exchange) -- equivalent to the reference's exchange of the two N-blocks of m_start (NPT/npt.py:677-678). */

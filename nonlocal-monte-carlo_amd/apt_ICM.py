@@ -83,9 +83,14 @@ class APT_ICM(SweepMixin):
 
     # ------------------------------------------------------------------------------------------------
     def run(self, beta_list, num_replicas, num_sweeps_MCMC=1000, num_sweeps_read=1000, num_swap_attempts=100,
-            num_swapping_pairs=1, use_hash_table=0, num_cores=8, plot=False, icm_feedback=False, return_trace="float64"):
+            num_swapping_pairs=1, use_hash_table=0, num_cores=8, plot=False, icm_feedback=False, return_trace="float64",
+            device_ids=None):
         """NPT/apt_ICM.py:145-305.  Returns (M [R*N, S_swap*10], Energy [R]).  `return_trace` (device-resident path only):
-        "float64" (the reference's M), "int8" (same layout, 1 byte per entry) or None (M is not materialised)."""
+        "float64" (the reference's M), "int8" (same layout, 1 byte per entry) or None (M is not materialised).
+        `device_ids` (rng="philox", icm_feedback=True; the reference's knob is num_cores, NPT/apt_ICM.py:145-146): the
+        temperature ladder is cut into len(device_ids) slot blocks, one context each -- all sub-replicas of a temperature on one
+        GPU (distributed.SlotShardedAPT); random numbers are then keyed by (sub-replica, temperature slot), the results do not
+        depend on the number of blocks."""
         if return_trace not in ("float64", "int8", None):
             raise ValueError("return_trace must be 'float64', 'int8' or None")
         self.num_replicas = num_replicas
@@ -101,6 +106,10 @@ class APT_ICM(SweepMixin):
         R, K, N = num_replicas, self.num_subreplicas, inst.n
         S = self.num_sweeps_MCMC_per_swap
         beta_list = np.asarray(beta_list, dtype=np.float64)
+        if device_ids is not None and not (self.rng == "philox" and icm_feedback):
+            raise ValueError("device_ids needs rng='philox' and icm_feedback=True (the device-resident path)")
+        if self.rng == "philox" and icm_feedback and device_ids is not None:
+            return self._run_slot_sharded(inst, beta_list, plot, return_trace, list(device_ids))
         if self.rng == "philox" and icm_feedback:
             return self._run_device_resident(inst, beta_list, plot, return_trace)
         numpy_mode = self.rng == "numpy"
@@ -251,6 +260,62 @@ class APT_ICM(SweepMixin):
             self.icm_cluster_sizes = np.concatenate(icm_sizes) if icm_sizes else np.zeros(0, np.int32)
         finally:
             eng.close()
+        print(f"\nLatest energy from each replica = {Energy}")
+        if plot and M is not None:
+            self.plot_energies([self.replica_energy(M[r * N:(r + 1) * N, :], self.num_sweeps_read_per_swap)[1]
+                                for r in range(R)], beta_list)
+        return M, Energy
+
+    def _run_slot_sharded(self, inst, beta_list, plot, return_trace, device_ids):
+        """The device-resident run with the ladder cut into slot blocks over `device_ids` (NPT/apt_ICM.py:215-285):
+        per round sweeps -> Houdayer moves inside every block -> one exchange of tracked energies and boundary configurations between
+        the blocks -> identical swap decision everywhere (distributed.SlotShardedAPT)."""
+        from .distributed import SlotShardedAPT
+        R, K, N = self.num_replicas, self.num_subreplicas, inst.n
+        S, rounds = self.num_sweeps_MCMC_per_swap, int(self.num_swap_attempts)
+        host_rng = np.random.default_rng(self.seed)      # initial states only
+        own = len(device_ids) > 1
+
+        def mk(i, n, b, g, dev=0):
+            return Engine(i, None, n, device=int(dev), chain_base=b, n_chains_global=g, own_stream=own)
+        apt = SlotShardedAPT(mk, inst, beta_list, K, self.seed, self.num_swapping_pairs, precision="f32",
+                             katzgraber=self.useKatzgraber, device_ids=device_ids)
+        try:
+            apt.sweeps_done = self._sweep_counter
+            apt.set_spins_by_slot((2 * host_rng.integers(0, 2, size=(K, R, N), dtype=np.int8) - 1).astype(np.int8))
+            apt.plan(rounds, S)
+            acc_log, icm_sizes = [], []
+            log_every = max(1, rounds // 16)
+            for ii in range(rounds):
+                is_last = ii == rounds - 1
+                logged = rounds <= 16 or is_last or ii % log_every == 0
+                log, info = apt.round(S, want_log=self.num_swapping_pairs > 0, want_info=logged,
+                                      **(dict(record_stride=1) if (is_last and S > 0) else {}))
+                if log is not None and log[1] is not None:
+                    acc_log.append(log[1])
+                if logged:
+                    icm_sizes.append(np.concatenate(info)[:, 1].copy())
+            self._sweep_counter += rounds * S
+            dt = np.float64 if return_trace != "int8" else np.int8
+            M = None if return_trace is None else np.zeros((N * R, S * K), dtype=dt)
+            Energy = np.zeros(R)
+            if rounds > 0 and S > 0:
+                Rw = apt.Rw
+                E_blk = np.empty((R, K * S))
+                for w, (e, o, sl) in enumerate(zip(apt.engs, apt.last_outputs, apt.last_slots)):
+                    c = np.arange(K * Rw, dtype=np.int32)
+                    dst, cols = (w * Rw + sl).astype(np.int32), ((c // Rw) * S).astype(np.int32)
+                    if M is not None:
+                        trace_layout(o["spins"], dst, R, dt, dst_col=cols, row_len=S * K, out=M)
+                    E_blk[dst[:, None], cols[:, None] + np.arange(S)[None, :]] = e.energy_of(o["spins"].reshape(-1, N)).reshape(K * Rw, S)
+                k = self.num_sweeps_read_per_swap
+                Energy = np.min(E_blk[:, :k], axis=1) if k > 0 else np.min(np.zeros(0))
+            self.final_states, self.final_energies = apt.gather_by_slot()
+            self.swap_accepted = np.concatenate([a.reshape(-1) for a in acc_log]).astype(np.int8) if acc_log else np.zeros(0, np.int8)
+            self.icm_cluster_sizes = np.concatenate(icm_sizes) if icm_sizes else np.zeros(0, np.int32)
+            apt.check()
+        finally:
+            apt.close()
         print(f"\nLatest energy from each replica = {Energy}")
         if plot and M is not None:
             self.plot_energies([self.replica_energy(M[r * N:(r + 1) * N, :], self.num_sweeps_read_per_swap)[1]

@@ -2,6 +2,7 @@
 #include "../../include/nlmc.h"
 #include "nlmc_kernels.h"
 #include "nlmc_pt_icm.h"
+#include "nlmc_apt.h"
 #include "nlmc_lbp.h"
 #include "nlmc_nmc.h"
 #include "nlmc_probe.h"
@@ -10,6 +11,8 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -215,6 +218,13 @@ struct nlmc_ctx {
     const int32_t *stats_nlev_ptr = nullptr;
     int64_t stats_nlev_count = 0;
 
+    // APT run cut into slot blocks over ranks (nlmc_apt_shard, csrc/nlmc_apt.h)
+    int apt_R = 0, apt_world = 0, apt_rank = 0;      // global ladder length; 0: not sharded by slot
+    int rng_stride = 0, rng_base = 0;                // random numbers keyed by (ladder, global slot): SweepArgs::rng_*
+    DevBuf<double> apt_beta;                         // [apt_R] the global ladder
+    DevBuf<long long> apt_e_all;                     // [world][K][ladder_len]
+    DevBuf<int8_t> apt_send, apt_recv;               // [2][K][n_pad]
+    DevBuf<int32_t> apt_bd;                          // [2][K]
     void *comm = nullptr;              // RCCL communicator of the sharded tempering (nlmc_comm_init): the per-round all-gather of
     int comm_world = 0, comm_rank = 0; // the energies is issued by the library on the kernels' own stream
 
@@ -561,6 +571,7 @@ int run_fused(nlmc_ctx *c, int slot, int w, uint32_t sweep0, uint64_t seed, cons
     a.f64_xmax = c->xmax;
     a.f64_tie_mask = c->knob_tie_mask;
     a.qinv64 = std::ldexp(1.0, -c->qs);
+    a.rng_stride = c->rng_stride; a.rng_base = c->rng_base; a.rng_ladder_len = std::max(1, c->ladder_len);
 #ifdef NLMC_STAMPS
     HIP_TRY(c, c->dbg.reserve((size_t)R * 16 * 8 + 96));
     HIP_TRY(c, hipMemsetAsync(c->dbg.p, 0, ((size_t)R * 16 * 8 + 96) * sizeof(long long), c->cur));
@@ -825,6 +836,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         a.eshift = c->escale - c->qs;
         a.qinv = std::ldexp(1.0f, -c->qs);
         a.qinv64 = std::ldexp(1.0, -c->qs);
+        a.rng_stride = c->rng_stride; a.rng_base = c->rng_base; a.rng_ladder_len = std::max(1, c->ladder_len);
         a.etrace = o.out_energy ? c->etrace.p : nullptr;
         a.trace_sweeps = n_sweeps;
         a.t0 = t0;
@@ -876,6 +888,12 @@ struct Rccl {
     int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*CommGetAsyncError)(void *, int *) = nullptr;
+    int (*CommAbort)(void *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     bool tried = false, ok = false;
     std::string why;
@@ -896,8 +914,16 @@ bool rccl_load()
     r.AllGather = reinterpret_cast<int (*)(const void *, void *, size_t, int, void *, hipStream_t)>(dlsym(h, "ncclAllGather"));
     r.CommDestroy = reinterpret_cast<int (*)(void *)>(dlsym(h, "ncclCommDestroy"));
     r.GetErrorString = reinterpret_cast<const char *(*)(int)>(dlsym(h, "ncclGetErrorString"));
-    r.ok = r.GetUniqueId && r.CommInitRank && r.AllGather && r.CommDestroy;
-    if (!r.ok) r.why = "librccl.so.1 lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy";
+    r.Send = reinterpret_cast<int (*)(const void *, size_t, int, int, void *, hipStream_t)>(dlsym(h, "ncclSend"));
+    r.Recv = reinterpret_cast<int (*)(void *, size_t, int, int, void *, hipStream_t)>(dlsym(h, "ncclRecv"));
+    r.GroupStart = reinterpret_cast<int (*)()>(dlsym(h, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<int (*)()>(dlsym(h, "ncclGroupEnd"));
+    r.CommGetAsyncError = reinterpret_cast<int (*)(void *, int *)>(dlsym(h, "ncclCommGetAsyncError"));
+    r.CommAbort = reinterpret_cast<int (*)(void *)>(dlsym(h, "ncclCommAbort"));
+    r.ok = r.GetUniqueId && r.CommInitRank && r.AllGather && r.CommDestroy && r.Send && r.Recv && r.GroupStart && r.GroupEnd &&
+           r.CommGetAsyncError && r.CommAbort;
+    if (!r.ok) r.why = "librccl.so.1 lacks one of ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclSend / ncclRecv / ncclGroupStart / "
+                       "ncclGroupEnd / ncclCommGetAsyncError / ncclCommAbort / ncclCommDestroy";
     return r.ok;
 }
 
@@ -1144,6 +1170,7 @@ void nlmc_destroy(nlmc_ctx *c)
     c->lbp_bar.release(); c->lbp_part.release();
     c->lbp_hm.release(); c->lbp_tot.release(); c->lbp_mag.release(); c->lbp_mag_all.release();
     c->pt_tab.release(); c->pt_beta.release(); c->pt_energies_all.release();
+    c->apt_beta.release(); c->apt_e_all.release(); c->apt_send.release(); c->apt_recv.release(); c->apt_bd.release();
     c->slot_of_chain.release(); c->chain_of_slot.release(); c->pt_pairs.release(); c->pt_status.release();
     c->pt_acc.release(); c->pt_log_acc.release(); c->pt_log_pairs.release(); c->pt_plan_pairs.release(); c->pt_plan_ok.release(); c->icm_label.release(); c->icm_info.release(); c->icm_pairs.release();
     if (c->arena) (void)hipFree(c->arena);
@@ -1658,7 +1685,8 @@ int nlmc_pt_plan(nlmc_ctx *c, uint32_t round0, int n_rounds, uint64_t seed, int 
 {
     if (!c) return NLMC_ERR_ARG;
     if (c->ladder_len == 0) return fail(c, NLMC_ERR_STATE, "nlmc_pt_plan: call nlmc_pt_init first");
-    const int L = c->ladder_len, nl = c->n_chains_global / L;
+    // (a context cut by temperature slot plans the selections of the GLOBAL ladder of its K sub-replica ladders: every rank the same)
+    const int nl = c->n_chains_global / c->ladder_len, L = c->apt_R > 0 ? c->apt_R : c->ladder_len;
     if (n_rounds < 0 || n_pairs < 0 || n_pairs > std::max(0, L - 1)) return fail(c, NLMC_ERR_ARG, "Cannot find non-overlapping pairs.");
     if (L > 4096) return fail(c, NLMC_ERR_UNSUPPORTED, "nlmc_pt_plan: ladder_len > 4096");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1740,6 +1768,7 @@ int nlmc_pt_swap_philox(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs,
     if (!energies_all_dev && !whole_ladders)
         return fail(c, NLMC_ERR_ARG, "nlmc_pt_swap_philox: a context whose block cuts a ladder needs the all-gathered energies");
     if (L > 4096) return fail(c, NLMC_ERR_UNSUPPORTED, "nlmc_pt_swap_philox: ladder_len > 4096");
+    if (c->apt_R > 0 && c->apt_world > 1) return fail(c, NLMC_ERR_STATE, "nlmc_pt_swap_philox: this context is one slot block of a cut ladder (nlmc_apt_shard): use nlmc_apt_swap_*");
     HIP_TRY(c, hipSetDevice(c->device));
     if (n_pairs == 0) return NLMC_OK;
     HIP_TRY(c, c->pt_pairs.reserve((size_t)nl * n_pairs * 2));
@@ -1818,8 +1847,10 @@ int nlmc_comm_unique_id(uint8_t *out_id)
 int nlmc_comm_init(nlmc_ctx *c, const uint8_t *id, int world, int rank)
 {
     if (!c || !id || world < 1 || rank < 0 || rank >= world) return fail(c, NLMC_ERR_ARG, "nlmc_comm_init: bad argument");
-    if (c->n_chains * world != c->n_chains_global || c->chain_base != rank * c->n_chains)
-        return fail(c, NLMC_ERR_ARG, "nlmc_comm_init: the context must own block `rank` of `world` equal blocks of chains");
+    const bool apt = c->apt_R > 0;         // cut by temperature slot (nlmc_apt_shard): a self-contained block of chains per rank
+    if (apt ? (c->apt_world != world || c->apt_rank != rank)
+            : (c->n_chains * world != c->n_chains_global || c->chain_base != rank * c->n_chains))
+        return fail(c, NLMC_ERR_ARG, "nlmc_comm_init: the context must own block `rank` of `world` equal blocks of chains (or be shard `rank` of `world` of nlmc_apt_shard)");
     if (!rccl_load()) return fail(c, NLMC_ERR_UNSUPPORTED, g_rccl.why);
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->comm) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
@@ -1828,6 +1859,7 @@ int nlmc_comm_init(nlmc_ctx *c, const uint8_t *id, int world, int rank)
     const int rc = g_rccl.CommInitRank(&c->comm, world, uid, rank);
     if (rc != 0) { c->comm = nullptr; return fail(c, NLMC_ERR_HIP, "ncclCommInitRank: " + rccl_err(rc)); }
     c->comm_world = world; c->comm_rank = rank;
+    if (apt) return NLMC_OK;               // (its gathered vector is apt_e_all, filled by k_apt_pack)
     HIP_TRY(c, c->pt_energies_all.reserve((size_t)c->n_chains_global));
     HIP_TRY(c, hipMemsetAsync(c->pt_energies_all.p, 0, sizeof(double) * (size_t)c->n_chains_global, c->stream));
     // the sweep kernels store their chains' tracked energies straight into this rank's block of the gathered vector
@@ -1840,6 +1872,7 @@ int nlmc_pt_swap_philox_collective(nlmc_ctx *c, uint32_t round, uint64_t seed, i
 {
     if (!c) return NLMC_ERR_ARG;
     if (!c->comm) return fail(c, NLMC_ERR_STATE, "nlmc_pt_swap_philox_collective: call nlmc_comm_init first");
+    if (c->apt_R > 0) return fail(c, NLMC_ERR_STATE, "nlmc_pt_swap_philox_collective: this context is a slot block of nlmc_apt_shard: use nlmc_apt_swap_collective");
     HIP_TRY(c, hipSetDevice(c->device));
     double *block = c->pt_energies_all.p + c->chain_base;
     if (refresh_energies || c->energy_sink != block) {        // (no sweep since the last state change wrote the block)
@@ -1851,6 +1884,214 @@ int nlmc_pt_swap_philox_collective(nlmc_ctx *c, uint32_t round, uint64_t seed, i
     const int rc = g_rccl.AllGather(block, c->pt_energies_all.p, (size_t)c->n_chains, /*ncclDouble*/ 8, c->comm, c->stream);
     if (rc != 0) return fail(c, NLMC_ERR_HIP, "ncclAllGather: " + rccl_err(rc));
     return nlmc_pt_swap_philox(c, round, seed, n_pairs, c->pt_energies_all.p, out_pairs, out_accepted);
+}
+
+int nlmc_comm_probe(void)
+{
+    return rccl_load() ? NLMC_OK : fail(nullptr, NLMC_ERR_UNSUPPORTED, g_rccl.why);
+}
+
+// Asynchronous failures of the library-issued collectives: ncclCommGetAsyncError, and a BOUNDED wait for the stream the collectives
+// were queued on (a lost rank leaves the others spinning inside a collective kernel for ever).  On either, the communicator is
+// aborted (ncclCommAbort ends the kernels that wait for the lost peer) and the call fails; the context keeps no communicator.
+int nlmc_comm_check(nlmc_ctx *c, int timeout_ms)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (!c->comm) return NLMC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto abort_comm = [&](const std::string &why) {
+        (void)g_rccl.CommAbort(c->comm);
+        c->comm = nullptr;
+        return fail(c, NLMC_ERR_HIP, why + "; the RCCL communicator was aborted (ncclCommAbort)");
+    };
+    int async = 0;
+    int rc = g_rccl.CommGetAsyncError(c->comm, &async);
+    if (rc != 0) return abort_comm("ncclCommGetAsyncError: " + rccl_err(rc));
+    if (async != 0) return abort_comm("RCCL asynchronous error: " + rccl_err(async));
+    if (timeout_ms < 0) return NLMC_OK;                      // error flag only, no wait
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return abort_comm(std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        rc = g_rccl.CommGetAsyncError(c->comm, &async);
+        if (rc != 0 || async != 0) return abort_comm("RCCL asynchronous error: " + rccl_err(rc != 0 ? rc : async));
+        if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_ms)
+            return abort_comm("the collectives queued on the context's stream did not finish within " + std::to_string(timeout_ms) + " ms (a rank lost?)");
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    return NLMC_OK;
+}
+
+// ---- APT run cut into temperature-slot blocks over ranks (csrc/nlmc_apt.h) ---------------------------------------------------
+int nlmc_apt_shard(nlmc_ctx *c, int R_global, int world, int rank, const double *beta_global)
+{
+    if (!c || !beta_global) return fail(c, NLMC_ERR_ARG, "nlmc_apt_shard: NULL argument");
+    if (c->ladder_len == 0) return fail(c, NLMC_ERR_STATE, "nlmc_apt_shard: call nlmc_pt_init with this rank's block of the ladder first");
+    const int L = c->ladder_len;
+    if (world < 1 || rank < 0 || rank >= world || R_global != world * L)
+        return fail(c, NLMC_ERR_ARG, "nlmc_apt_shard: R_global must be world x the local ladder length");
+    if (c->chain_base != 0 || c->n_chains != c->n_chains_global)
+        return fail(c, NLMC_ERR_ARG, "nlmc_apt_shard: the context must be self-contained (K ladders of its own slots: chain_base 0, n_chains_global == n_chains)");
+    for (int i = 0; i < L; ++i)
+        if (beta_global[(size_t)rank * L + i] != c->beta_list[(size_t)i])
+            return fail(c, NLMC_ERR_ARG, "nlmc_apt_shard: nlmc_pt_init was not given block `rank` of beta_global");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t K = (size_t)(c->n_chains / L);
+    HIP_TRY(c, c->apt_beta.reserve((size_t)R_global));
+    HIP_TRY(c, c->apt_e_all.reserve((size_t)world * K * L));
+    HIP_TRY(c, c->apt_send.reserve(2 * K * (size_t)c->n_pad));
+    HIP_TRY(c, c->apt_recv.reserve(2 * K * (size_t)c->n_pad));
+    HIP_TRY(c, c->apt_bd.reserve(2 * K));
+    HIP_TRY(c, hipMemcpyAsync(c->apt_beta.p, beta_global, sizeof(double) * (size_t)R_global, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->apt_e_all.p, 0, sizeof(long long) * (size_t)world * K * L, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->apt_recv.p, 0, 2 * K * (size_t)c->n_pad, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->apt_bd.p, 0, sizeof(int32_t) * 2 * K, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->apt_R = R_global; c->apt_world = world; c->apt_rank = rank;
+    c->rng_stride = R_global; c->rng_base = rank * L;
+    c->pt_plan_valid = false;                        // (a selection planned over the local ladder is not this mode's)
+    return NLMC_OK;
+}
+
+static int apt_require(nlmc_ctx *c, const char *who)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (c->apt_R == 0) return fail(c, NLMC_ERR_STATE, std::string(who) + ": call nlmc_apt_shard first");
+    return NLMC_OK;
+}
+
+static int apt_launch_pack(nlmc_ctx *c)
+{
+    const int L = c->ladder_len, K = c->n_chains / L;
+    AptPackArgs a{};
+    a.L = L; a.K = K; a.n_pad = c->n_pad;
+    a.chain_of_slot = c->chain_of_slot.p; a.efix = c->efix.p; a.spins = c->spins.p;
+    a.e_block = c->apt_e_all.p + (size_t)c->apt_rank * K * L;
+    a.send = c->apt_send.p;
+    hipLaunchKernelGGL(k_apt_pack, dim3(2 * K + 1), dim3(256), 0, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    return NLMC_OK;
+}
+
+// decision of every selected pair + label exchanges inside the block + adoption of the accepted boundary pairs
+static int apt_launch_swap(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs, int32_t *out_pairs, uint8_t *out_accepted)
+{
+    const int L = c->ladder_len, K = c->n_chains / L;
+    HIP_TRY(c, c->pt_pairs.reserve((size_t)K * n_pairs * 2));
+    HIP_TRY(c, c->pt_acc.reserve((size_t)K * n_pairs));
+    AptSwapArgs a{};
+    a.L = L; a.R = c->apt_R; a.K = K; a.n_pairs = n_pairs; a.world = c->apt_world; a.rank = c->apt_rank;
+    a.round = round; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.beta = c->apt_beta.p; a.e_all = c->apt_e_all.p; a.escale = c->escale;
+    a.slot_of_chain = c->slot_of_chain.p; a.chain_of_slot = c->chain_of_slot.p;
+    a.out_pairs = c->pt_pairs.p; a.out_acc = c->pt_acc.p; a.status = c->pt_status.p; a.bd = c->apt_bd.p;
+    if (c->pt_log_on && c->pt_log_npairs == n_pairs && round >= c->pt_log_round0 &&
+        round < c->pt_log_round0 + (uint32_t)c->pt_log_rounds && !out_pairs && !out_accepted) {
+        const size_t r = round - c->pt_log_round0;
+        a.out_pairs = c->pt_log_pairs.p + r * (size_t)K * n_pairs * 2;
+        a.out_acc = c->pt_log_acc.p + r * (size_t)K * n_pairs;
+    }
+    if (c->pt_plan_valid && c->pt_plan_seed == seed && c->pt_plan_npairs == n_pairs && round >= c->pt_plan_round0 &&
+        round < c->pt_plan_round0 + (uint32_t)c->pt_plan_rounds) {
+        const size_t r = round - c->pt_plan_round0;
+        a.plan_pairs = c->pt_plan_pairs.p + r * (size_t)K * n_pairs * 2;
+        a.plan_ok = c->pt_plan_ok.p + r * (size_t)K;
+    }
+    const int swap_nt = a.plan_pairs ? std::min(256, (n_pairs + 63) / 64 * 64) : 64;
+    c->sub_dirty = true;
+    hipLaunchKernelGGL(k_apt_swap, dim3(K), dim3(std::max(64, swap_nt)), 0, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    if (c->apt_world > 1) {
+        AptAdoptArgs d{};
+        d.L = L; d.K = K; d.n_pad = c->n_pad; d.world = c->apt_world; d.rank = c->apt_rank; d.escale = c->escale;
+        d.bd = c->apt_bd.p; d.chain_of_slot = c->chain_of_slot.p; d.recv = c->apt_recv.p; d.e_all = c->apt_e_all.p;
+        d.spins = c->spins.p; d.efix = c->efix.p; d.energy_sink = c->energy_sink;
+        hipLaunchKernelGGL(k_apt_adopt, dim3(2 * K), dim3(256), 0, c->stream, d);
+        HIP_TRY(c, hipGetLastError());
+    }
+    if (out_pairs || out_accepted) {
+        int32_t st = 0;
+        if (out_pairs) HIP_TRY(c, hipMemcpyAsync(out_pairs, c->pt_pairs.p, sizeof(int32_t) * (size_t)K * n_pairs * 2, hipMemcpyDeviceToHost, c->stream));
+        if (out_accepted) HIP_TRY(c, hipMemcpyAsync(out_accepted, c->pt_acc.p, (size_t)K * n_pairs, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&st, c->pt_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (st != 0) {
+            HIP_TRY(c, hipMemsetAsync(c->pt_status.p, 0, sizeof(int32_t), c->stream));
+            return fail(c, NLMC_ERR_ARG, "Cannot find non-overlapping pairs.");
+        }
+    }
+    return NLMC_OK;
+}
+
+static int apt_check_pairs(nlmc_ctx *c, int n_pairs)
+{
+    if (n_pairs < 0 || n_pairs > std::max(0, c->apt_R - 1)) return fail(c, NLMC_ERR_ARG, "Cannot find non-overlapping pairs.");
+    if (c->apt_R > 4096) return fail(c, NLMC_ERR_UNSUPPORTED, "nlmc_apt_swap: ladder_len > 4096");
+    return NLMC_OK;
+}
+
+int nlmc_apt_pack(nlmc_ctx *c, int64_t *out_slot_efix, int8_t *out_lo, int8_t *out_hi)
+{
+    { int rc = apt_require(c, "nlmc_apt_pack"); if (rc) return rc; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rc = apt_launch_pack(c); if (rc) return rc; }
+    const int L = c->ladder_len, K = c->n_chains / L;
+    if (out_slot_efix)
+        HIP_TRY(c, hipMemcpyAsync(out_slot_efix, c->apt_e_all.p + (size_t)c->apt_rank * K * L, sizeof(long long) * (size_t)K * L, hipMemcpyDeviceToHost, c->stream));
+    for (int side = 0; side < 2; ++side) {
+        int8_t *dst = side ? out_hi : out_lo;
+        if (!dst) continue;
+        c->stage_out.resize((size_t)c->n_pad * K);
+        HIP_TRY(c, hipMemcpyAsync(c->stage_out.data(), c->apt_send.p + (size_t)side * K * c->n_pad, c->stage_out.size(), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        rows_to_host_finish(c, dst, K);
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NLMC_OK;
+}
+
+int nlmc_apt_swap_host(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs, const int64_t *efix_all, const int8_t *recv_lo,
+                       const int8_t *recv_hi, int32_t *out_pairs, uint8_t *out_accepted)
+{
+    { int rc = apt_require(c, "nlmc_apt_swap_host"); if (rc) return rc; }
+    { int rc = apt_check_pairs(c, n_pairs); if (rc) return rc; }
+    if (!efix_all || (c->apt_rank > 0 && !recv_lo) || (c->apt_rank + 1 < c->apt_world && !recv_hi))
+        return fail(c, NLMC_ERR_ARG, "nlmc_apt_swap_host: the gathered energies and the neighbours' boundary configurations are required");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n_pairs == 0) return NLMC_OK;
+    const int L = c->ladder_len, K = c->n_chains / L;
+    HIP_TRY(c, hipMemcpyAsync(c->apt_e_all.p, efix_all, sizeof(long long) * (size_t)c->apt_world * K * L, hipMemcpyHostToDevice, c->stream));
+    if (c->apt_rank > 0) { int rc = rows_to_device(c, c->apt_recv.p, recv_lo, K); if (rc) return rc; }
+    if (c->apt_rank + 1 < c->apt_world) { int rc = rows_to_device(c, c->apt_recv.p + (size_t)K * c->n_pad, recv_hi, K); if (rc) return rc; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));          // the caller's buffers may go away after the call
+    return apt_launch_swap(c, round, seed, n_pairs, out_pairs, out_accepted);
+}
+
+int nlmc_apt_swap_collective(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs, int32_t *out_pairs, uint8_t *out_accepted)
+{
+    { int rc = apt_require(c, "nlmc_apt_swap_collective"); if (rc) return rc; }
+    { int rc = apt_check_pairs(c, n_pairs); if (rc) return rc; }
+    if (c->apt_world > 1 && !c->comm) return fail(c, NLMC_ERR_STATE, "nlmc_apt_swap_collective: call nlmc_comm_init first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n_pairs == 0) return NLMC_OK;
+    { int rc = apt_launch_pack(c); if (rc) return rc; }
+    if (c->comm) {                          // (also with ONE rank: the in-place all-gather then rehearses the path on one GPU)
+        const int L = c->ladder_len, K = c->n_chains / L, W = c->apt_world, me = c->apt_rank;
+        const size_t blk = (size_t)K * L, rowbytes = (size_t)K * c->n_pad;
+        // all on the stream the kernels run on: stream order is the only synchronisation.  The all-gather is in place (send = this
+        // rank's block of the receive buffer); the two neighbour exchanges are one group (no deadlock whatever the order).
+        int rc = g_rccl.AllGather(c->apt_e_all.p + (size_t)me * blk, c->apt_e_all.p, blk, /*ncclInt64*/ 4, c->comm, c->stream);
+        if (rc != 0) return fail(c, NLMC_ERR_HIP, "ncclAllGather: " + rccl_err(rc));
+        rc = g_rccl.GroupStart();
+        if (rc == 0 && me > 0) rc = g_rccl.Send(c->apt_send.p, rowbytes, /*ncclInt8*/ 0, me - 1, c->comm, c->stream);
+        if (rc == 0 && me > 0) rc = g_rccl.Recv(c->apt_recv.p, rowbytes, 0, me - 1, c->comm, c->stream);
+        if (rc == 0 && me + 1 < W) rc = g_rccl.Send(c->apt_send.p + rowbytes, rowbytes, 0, me + 1, c->comm, c->stream);
+        if (rc == 0 && me + 1 < W) rc = g_rccl.Recv(c->apt_recv.p + rowbytes, rowbytes, 0, me + 1, c->comm, c->stream);
+        const int rc2 = g_rccl.GroupEnd();
+        if (rc != 0 || rc2 != 0) return fail(c, NLMC_ERR_HIP, "ncclSend / ncclRecv: " + rccl_err(rc != 0 ? rc : rc2));
+    }
+    return apt_launch_swap(c, round, seed, n_pairs, out_pairs, out_accepted);
 }
 
 int nlmc_pt_log_begin(nlmc_ctx *c, uint32_t round0, int n_rounds, int n_pairs)
@@ -1938,6 +2179,7 @@ static int icm_launch_round(nlmc_ctx *c, const int32_t *pairs_dev, int n_pairs, 
     IcmRoundArgs a{};
     a.g = c->g; a.spins = c->spins.p; a.pairs = pairs_dev; a.info = c->icm_info.p;
     a.pair_R = pair_R; a.pair_K = pair_K; a.chain_of_slot = c->chain_of_slot.p;
+    a.slot0 = c->rng_base; a.rng_stride = c->rng_stride; a.rng_base = c->rng_base;
     if (!c->has_zero_vals && c->n <= 65535) {
         int rc = ensure_adjacency(c);
         if (rc) return rc;
@@ -2074,6 +2316,7 @@ int nlmc_icm_round_ladders(nlmc_ctx *c, uint32_t round, uint64_t seed, int katzg
     HIP_TRY(c, hipSetDevice(c->device));
     const int nt_round = c->n >= 4096 ? 1024 : 256;
     const bool pair_in_kernel = K <= nt_round;          // the pairing (a sort of K Philox keys per slot) is made by the move kernel itself
+    if (!pair_in_kernel && c->rng_stride) return fail(c, NLMC_ERR_UNSUPPORTED, "nlmc_icm_round_ladders: more sub-replicas than threads with slot-keyed random numbers");
     if (!pair_in_kernel) {
         HIP_TRY(c, c->icm_pairs.reserve((size_t)n_pairs * 2));
         hipLaunchKernelGGL(k_icm_pair_ladders, dim3((R * K + 63) / 64), dim3(64), 0, c->stream, R, K, round, (uint32_t)seed,

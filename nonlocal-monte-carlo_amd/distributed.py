@@ -46,22 +46,13 @@ class ShardedTempering:
         self.rounds_done = 0
         self.collective = dist is not None          # also with a single rank: the launcher path stays exercised
         self.lib_collective = False
-        if self.collective and hasattr(self.eng, "comm_init") and dist.get_backend() == "nccl" and self.n_pairs > 0 \
-                and not os.environ.get("NLMC_TORCH_COLLECTIVE"):
-            # The all-gather of a round is issued by the LIBRARY (ncclAllGather from libnlmc_hip.so on the stream its kernels
-            # run on: no hand-over between c10d's collective stream and the kernels' stream, ~10 us per round); its
-            # communicator's unique id travels through the process group that is already up.
-            uid = torch.zeros(129, dtype=torch.uint8, device=device)       # [128] = 1: rank 0 could create an id
-            if self.rank == 0:
-                try:
-                    uid[:128].copy_(torch.from_numpy(self.eng.comm_unique_id()))
-                    uid[128] = 1
-                except (NotImplementedError, RuntimeError) as ex:          # no usable librccl: every rank takes the c10d path
-                    print(f"[nlmc] library-issued all-gather unavailable ({ex}); using torch.distributed", file=sys.stderr)
-            dist.broadcast(uid, 0)
-            if int(uid[128].item()) == 1:
-                self.eng.comm_init(uid[:128].cpu().numpy(), self.world, self.rank)
-                self.lib_collective = True
+        if self.collective:
+            # The all-gather of a round is issued by the LIBRARY (ncclAllGather from libnlmc_hip.so on the stream its kernels run on:
+            # no hand-over between c10d's collective stream and the kernels' stream, ~10 us per round).  Every rank probes librccl
+            # and the ranks agree before anybody enters ncclCommInitRank; the unique id travels through the process group.
+            self.lib_collective = agree_on_library_collectives(self.eng, torch, dist, device, want=self.n_pairs > 0)
+        self._check_every = int(os.environ.get("NLMC_COMM_CHECK_EVERY", "256"))
+        self._timeout_ms = int(float(os.environ.get("NLMC_COMM_TIMEOUT_S", "120")) * 1000)
         if self.collective and not self.lib_collective:
             self.e_local = torch.empty(self.count, dtype=torch.float64, device=device)
             self.e_all = torch.empty(self.G, dtype=torch.float64, device=device)
@@ -109,6 +100,8 @@ class ShardedTempering:
             if self.lib_collective:
                 log = self.eng.pt_swap_philox_collective(self.rounds_done, self.seed, self.n_pairs, refresh_energies=n_sweeps == 0,
                                                          want_log=want_log)
+                if self._check_every and (self.rounds_done + 1) % self._check_every == 0:
+                    self.eng.comm_check(self._timeout_ms)            # RCCL async error or a lost rank: abort, RuntimeError (never a hang)
             elif self.collective:
                 if not self._sink or n_sweeps == 0:
                     self.eng.energy_dev(self.e_local.data_ptr())       # tracked energies -> device/host buffer
@@ -133,6 +126,8 @@ class ShardedTempering:
 
     def close(self):
         try:
+            if self.lib_collective:
+                self.eng.comm_check(self._timeout_ms)
             if self.n_pairs > 0 and hasattr(self.eng, "pt_check"):
                 self.eng.pt_check()          # a swap round whose pair selection ran out raises here at the latest
         finally:
@@ -306,6 +301,208 @@ class LocalTempering:
         if self.nmc:
             for e in self.engs:
                 e.backbone_check()      # ValueError('LBP diverged at initial lambda ...') of NPT/npt.py:178-180
+
+    def close(self):
+        for e in self.engs:
+            e.close()
+        self.engs = []
+
+
+def agree_on_library_collectives(eng, torch, dist, device, want):
+    """Every rank probes librccl (nlmc_comm_probe) and the ranks agree -- an all-reduce(MIN) of the answers over the process group
+    that is already up -- BEFORE anybody calls nlmc_comm_init: a rank that cannot load the library must not leave the others
+    waiting inside ncclCommInitRank.  Returns True when the library-issued collectives are on for ALL ranks; the
+    communicator's unique id then travels through the same process group."""
+    ok = bool(want) and hasattr(eng, "comm_init") and dist.get_backend() == "nccl" and not os.environ.get("NLMC_TORCH_COLLECTIVE")
+    if ok:
+        try:
+            ok = bool(type(eng).comm_probe())
+        except Exception as ex:  # noqa: BLE001
+            print(f"[nlmc] librccl probe failed ({ex})", file=sys.stderr)
+            ok = False
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        if want and dist.get_rank() == 0 and dist.get_backend() == "nccl" and not os.environ.get("NLMC_TORCH_COLLECTIVE"):
+            print("[nlmc] library-issued collectives unavailable on some rank; using torch.distributed", file=sys.stderr)
+        return False
+    uid = torch.zeros(129, dtype=torch.uint8, device=device)           # [128] = 1: rank 0 could create an id
+    if dist.get_rank() == 0:
+        try:
+            uid[:128].copy_(torch.from_numpy(type(eng).comm_unique_id()))
+            uid[128] = 1
+        except (NotImplementedError, RuntimeError) as ex:
+            print(f"[nlmc] ncclGetUniqueId failed ({ex}); using torch.distributed", file=sys.stderr)
+    dist.broadcast(uid, 0)
+    if int(uid[128].item()) != 1:
+        return False
+    # comm_init itself may still fail on one rank (out of memory, ...): agree once more, and drop the communicator everywhere if so
+    err = None
+    try:
+        eng.comm_init(uid[:128].cpu().numpy(), dist.get_world_size(), dist.get_rank())
+    except Exception as ex:  # noqa: BLE001
+        err = ex
+    flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        raise RuntimeError(f"nlmc_comm_init failed on some rank ({err}); aborting the job") from err
+    return True
+
+
+class SlotShardedAPT:
+    """APT + iso-cluster moves (NPT/apt_ICM.py:195-285) with the temperature ladder cut into slot blocks (SURVEY.md section 8e:
+    all sub-replicas of a temperature on one GPU; include/nlmc.h: nlmc_apt_shard, csrc/nlmc_apt.h).
+
+    R temperatures x K sub-replicas; shard w of W owns the slots [w R/W, (w+1) R/W) of all K sub-replica ladders.  Per round:
+    sweeps at the slots' temperatures -> Houdayer moves between the randomly paired sub-replicas of every local slot (k_icm_round,
+    nothing leaves the GPU) -> swap round: ONE all-gather of K R/W tracked energies per shard + ONE exchange of the K boundary
+    configurations with each neighbour shard; every shard takes the identical Philox-keyed decision; pairs inside a block are label
+    exchanges, accepted pairs across a block boundary move the two configurations.  Random numbers are keyed by (sub-replica,
+    global slot): the states on every (sub-replica, slot) are bit-identical for any W.
+
+    Three transports, one protocol:
+      * `dist` (torch.distributed, one process per GPU): the library issues the collectives itself over RCCL on the kernels'
+        stream (apt_swap_collective) when every rank can; otherwise torch.distributed moves the same buffers (gloo on CPUs);
+      * `device_ids` (one process, W = len(device_ids) contexts): the same data through host memory;
+      * neither: one context, W = 1.
+    make_engine(inst, n_chains, chain_base, n_chains_global) as for ShardedTempering (tests inject the oracle-backed double)."""
+
+    def __init__(self, make_engine, inst, beta_list, n_subreplicas, seed, n_pairs, torch=None, dist=None, device=None,
+                 precision="f32", katzgraber=True, device_ids=None):
+        self.torch, self.dist, self.device = torch, dist, device
+        self.betas = np.asarray(beta_list, dtype=np.float64).reshape(-1)
+        self.R, self.K = int(self.betas.shape[0]), int(n_subreplicas)
+        self.seed, self.n_pairs, self.precision, self.katz = int(seed), int(n_pairs), precision, bool(katzgraber)
+        if dist is not None:
+            self.W, ranks = dist.get_world_size(), [dist.get_rank()]
+        else:
+            self.W = len(device_ids) if device_ids else 1
+            ranks = list(range(self.W))
+        if self.R % self.W:
+            raise ValueError(f"{self.R} temperatures do not split evenly over {self.W} shards")
+        self.Rw = self.R // self.W
+        self.ranks, self.engs = ranks, []
+        try:
+            for i, w in enumerate(ranks):
+                e = make_engine(inst, self.K * self.Rw, 0, self.K * self.Rw) if dist is not None or not device_ids else \
+                    make_engine(inst, self.K * self.Rw, 0, self.K * self.Rw, device_ids[i])
+                self.engs.append(e)
+                e.pt_init(self.betas[w * self.Rw:(w + 1) * self.Rw])
+                e.apt_shard(self.betas, self.W, w)
+        except Exception:
+            self.close()
+            raise
+        self.sweeps_done = self.rounds_done = 0
+        self._planners = None
+        self.lib_collective = False
+        if dist is not None and self.W > 1:
+            self.lib_collective = agree_on_library_collectives(self.engs[0], torch, dist, device, want=self.n_pairs > 0)
+        self._check_every = int(os.environ.get("NLMC_COMM_CHECK_EVERY", "256"))
+        self._timeout_ms = int(float(os.environ.get("NLMC_COMM_TIMEOUT_S", "120")) * 1000)
+
+    # -- states by (sub-replica, global slot) -------------------------------------------------------------------------------
+    def set_spins_by_slot(self, spins):
+        """spins [K, R, N]: the configuration on (sub-replica j, temperature slot r).  Slots are reset to the identity."""
+        s = np.asarray(spins, dtype=np.int8).reshape(self.K, self.R, -1)
+        for e, w in zip(self.engs, self.ranks):
+            e.pt_set_slots((np.arange(self.K * self.Rw) % self.Rw).astype(np.int32))
+            e.set_spins(np.ascontiguousarray(s[:, w * self.Rw:(w + 1) * self.Rw]).reshape(self.K * self.Rw, -1))
+
+    def _local_by_slot(self, e):
+        cfg, slots = e.get_spins(), e.pt_slots()
+        out = np.empty((self.K, self.Rw, cfg.shape[1]), np.int8)
+        out[np.arange(self.K * self.Rw) // self.Rw, slots] = cfg
+        en = np.empty((self.K, self.Rw))
+        en[np.arange(self.K * self.Rw) // self.Rw, slots] = e.energy_tracked()
+        return out, en
+
+    def gather_by_slot(self):
+        """(configurations [K, R, N], tracked energies [K, R]) by (sub-replica, global slot), on every process (read-out only)."""
+        loc = [self._local_by_slot(e) for e in self.engs]
+        if self.dist is None or self.W == 1:
+            return np.concatenate([x[0] for x in loc], axis=1), np.concatenate([x[1] for x in loc], axis=1)
+        t, dev = self.torch, self.device
+        cfg = t.from_numpy(loc[0][0]).to(dev)
+        en = t.from_numpy(loc[0][1]).to(dev)
+        cfgs = [t.empty_like(cfg) for _ in range(self.W)]
+        ens = [t.empty_like(en) for _ in range(self.W)]
+        self.dist.all_gather(cfgs, cfg)
+        self.dist.all_gather(ens, en)
+        return np.concatenate([x.cpu().numpy() for x in cfgs], axis=1), np.concatenate([x.cpu().numpy() for x in ens], axis=1)
+
+    # -- rounds -----------------------------------------------------------------------------------------------------------
+    def plan(self, n_rounds, sweeps_per_round, chunk_rounds=None, budget_bytes=8 << 30):
+        """Level schedules and pair selections of the next rounds (RNG only), built a chunk of rounds at a time by the round that
+        first needs them (RoundPlanner)."""
+        self._planners = [RoundPlanner(e, self.sweeps_done, n_rounds, sweeps_per_round, self.seed, precision=self.precision,
+                                       budget_bytes=budget_bytes, chunk_rounds=chunk_rounds, pt_pairs=self.n_pairs,
+                                       pt_round0=self.rounds_done) for e in self.engs]
+        self._planner_round0 = self.rounds_done
+
+    def _swap_torch(self, want_log):
+        """The round's exchange through torch.distributed (gloo on CPUs, or RCCL when the library cannot issue it itself): the same
+        buffers as the library path -- K Rw int64 per rank all-gathered, K configurations to and from each neighbour."""
+        t, dist, dev, e, w = self.torch, self.dist, self.device, self.engs[0], self.ranks[0]
+        ef, lo, hi = e.apt_pack()
+        mine = t.from_numpy(ef.reshape(-1)).to(dev)
+        parts = [t.empty_like(mine) for _ in range(self.W)]
+        dist.all_gather(parts, mine)
+        recv_lo = t.empty((self.K, e.n), dtype=t.int8, device=dev) if w > 0 else None
+        recv_hi = t.empty((self.K, e.n), dtype=t.int8, device=dev) if w + 1 < self.W else None
+        ops = []
+        if w > 0:
+            ops += [dist.P2POp(dist.isend, t.from_numpy(lo).to(dev), w - 1), dist.P2POp(dist.irecv, recv_lo, w - 1)]
+        if w + 1 < self.W:
+            ops += [dist.P2POp(dist.isend, t.from_numpy(hi).to(dev), w + 1), dist.P2POp(dist.irecv, recv_hi, w + 1)]
+        for req in (dist.batch_isend_irecv(ops) if ops else []):
+            req.wait()
+        ef_all = np.stack([p.cpu().numpy() for p in parts])
+        return e.apt_swap_host(self.rounds_done, self.seed, self.n_pairs, ef_all,
+                               None if recv_lo is None else recv_lo.cpu().numpy(), None if recv_hi is None else recv_hi.cpu().numpy(),
+                               want_log=want_log)
+
+    def round(self, n_sweeps, want_log=False, want_info=False, **outputs):
+        """Sweeps, Houdayer moves, swap round of every local shard.  Returns (swap log or None, cluster info of the local shards or
+        None).  `outputs` (record_stride / want_* of sweep_philox): the sweeps' outputs per local shard are left in
+        self.last_outputs, with the slots the chains sat on during those sweeps in self.last_slots."""
+        ii = self.rounds_done - (self._planner_round0 if self._planners else 0)
+        self.last_outputs, self.last_slots = [], []
+        for k, e in enumerate(self.engs):
+            pl = self._planners[k] if self._planners else None
+            if outputs:
+                self.last_slots.append(e.pt_slots())
+            if pl is not None and 0 <= ii < pl.R and n_sweeps == pl.S:
+                o = pl.sweep(ii, **outputs)
+            else:
+                o = e.sweep_philox(n_sweeps, self.seed, sweep0=self.sweeps_done, beta=None, precision=self.precision, **outputs)
+            self.last_outputs.append(o)
+        self.sweeps_done += n_sweeps
+        info = [e.icm_round_ladders(self.rounds_done, self.seed, self.katz, want_info=want_info) for e in self.engs]
+        log = None
+        if self.n_pairs > 0:
+            if self.lib_collective:
+                log = self.engs[0].apt_swap_collective(self.rounds_done, self.seed, self.n_pairs, want_log=want_log)
+                if self._check_every and (self.rounds_done + 1) % self._check_every == 0:
+                    self.engs[0].comm_check(self._timeout_ms)            # async error / lost rank -> abort, RuntimeError
+            elif self.dist is not None and self.W > 1:
+                log = self._swap_torch(want_log)
+            elif self.W == 1:
+                log = self.engs[0].apt_swap_collective(self.rounds_done, self.seed, self.n_pairs, want_log=want_log)
+            else:
+                packs = [e.apt_pack() for e in self.engs]
+                ef_all = np.stack([p[0] for p in packs])
+                for w, e in enumerate(self.engs):
+                    log = e.apt_swap_host(self.rounds_done, self.seed, self.n_pairs, ef_all, packs[w - 1][2] if w > 0 else None,
+                                          packs[w + 1][1] if w + 1 < self.W else None, want_log=want_log)
+        self.rounds_done += 1
+        return log, (info if want_info else None)
+
+    def check(self):
+        for e in self.engs:
+            if self.n_pairs > 0 and hasattr(e, "pt_check"):
+                e.pt_check()
+        if self.lib_collective:
+            self.engs[0].comm_check(self._timeout_ms)
 
     def close(self):
         for e in self.engs:

@@ -370,6 +370,50 @@ class Engine:
                                                         _abi.ptr(pairs), _abi.ptr(acc)))
         return pairs, acc
 
+    @staticmethod
+    def comm_probe():
+        """True when this process can load librccl (nlmc_comm_probe); every rank asks before comm_init and the ranks agree."""
+        return _abi.lib().nlmc_comm_probe() == _abi.OK
+
+    def comm_check(self, timeout_ms=-1):
+        """RCCL asynchronous error flag, and with timeout_ms >= 0 a bounded wait for the collectives queued on the context's stream;
+        RuntimeError after aborting the communicator (include/nlmc.h: nlmc_comm_check)."""
+        self._ck(self._L.nlmc_comm_check(self._ctx, int(timeout_ms)))
+
+    # -- APT run cut into temperature-slot blocks over ranks (include/nlmc.h: nlmc_apt_shard) -------------------------------
+    def apt_shard(self, beta_global, world, rank):
+        b = _abi.as_c(beta_global, np.float64).reshape(-1)
+        self._ck(self._L.nlmc_apt_shard(self._ctx, b.shape[0], int(world), int(rank), _abi.ptr(b)))
+        self.apt_world, self.apt_rank, self.apt_R = int(world), int(rank), int(b.shape[0])
+
+    def apt_pack(self, want_configs=True):
+        """(tracked energies [K, Rw] int64 in units of 2^-energy_scale by (ladder, local slot), configurations on local slot 0
+        [K, n], on local slot Rw - 1 [K, n])."""
+        K = self.n_chains // self.ladder_len
+        e = np.empty((K, self.ladder_len), np.int64)
+        lo = np.empty((K, self.n), np.int8) if want_configs else None
+        hi = np.empty((K, self.n), np.int8) if want_configs else None
+        self._ck(self._L.nlmc_apt_pack(self._ctx, _abi.ptr(e), _abi.ptr(lo), _abi.ptr(hi)))
+        return e, lo, hi
+
+    def _apt_log(self, n_pairs, want_log):
+        K = self.n_chains // self.ladder_len
+        return (np.empty((K, n_pairs, 2), np.int32), np.empty((K, n_pairs), np.uint8)) if want_log else (None, None)
+
+    def apt_swap_host(self, round_idx, seed, n_pairs, efix_all, recv_lo, recv_hi, want_log=False):
+        pairs, acc = self._apt_log(n_pairs, want_log)
+        e = _abi.as_c(efix_all, np.int64).reshape(self.apt_world, -1, self.ladder_len)
+        lo = None if recv_lo is None else _abi.as_c(recv_lo, np.int8).reshape(-1, self.n)
+        hi = None if recv_hi is None else _abi.as_c(recv_hi, np.int8).reshape(-1, self.n)
+        self._ck(self._L.nlmc_apt_swap_host(self._ctx, int(round_idx), int(seed), int(n_pairs), _abi.ptr(e), _abi.ptr(lo), _abi.ptr(hi),
+                                            _abi.ptr(pairs), _abi.ptr(acc)))
+        return pairs, acc
+
+    def apt_swap_collective(self, round_idx, seed, n_pairs, want_log=False):
+        pairs, acc = self._apt_log(n_pairs, want_log)
+        self._ck(self._L.nlmc_apt_swap_collective(self._ctx, int(round_idx), int(seed), int(n_pairs), _abi.ptr(pairs), _abi.ptr(acc)))
+        return pairs, acc
+
     def pt_plan(self, round0, n_rounds, seed, n_pairs):
         self._ck(self._L.nlmc_pt_plan(self._ctx, int(round0), int(n_rounds), int(seed), int(n_pairs)))
 
