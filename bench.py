@@ -169,6 +169,82 @@ def self_launch(a, argv):
     return subprocess.call(cmd, env=env)
 
 
+C5_BETAS_PER_GPU, C5_SUBREPLICAS, C5_ROUNDS_PER_STEP = 32, 8, 1024
+
+
+def run_c5(a, P, inst, torch, dist, world, rank, local_rank):
+    """BASELINE config 5: APT + Houdayer iso-cluster moves on the 10^4-spin instance, 32 temperatures x 8 sub-replicas = 256 chains
+    PER GPU; the ladder of 32 x n_gpus temperatures is cut into slot blocks, one per GPU (distributed.SlotShardedAPT: all
+    sub-replicas of a temperature on one GPU; per round ONE all-gather of 256 int64 tracked energies per rank and ONE exchange of
+    the 8 boundary configurations with each neighbour).  A step = 1024 rounds of (10 sweeps, 128 iso-cluster moves per GPU, one
+    swap round of round(0.3 R) pairs per sub-replica ladder).  Prints one JSON line (rank 0)."""
+    import numpy as np
+    R, K = C5_BETAS_PER_GPU * world, C5_SUBREPLICAS
+    betas = np.geomspace(BETA_MIN, BETA_MAX, R)
+    n_pairs = round(0.3 * R)
+    stream = torch.cuda.current_stream().cuda_stream
+    dev = torch.device("cuda", local_rank)
+
+    def mk(i, n, b, g, d=None):
+        return P.Engine(i, None, n, device=local_rank, stream=stream, chain_base=b, n_chains_global=g)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def leg(precision):
+        apt = P.distributed.SlotShardedAPT(mk, inst, betas, K, PHILOX_SEED, n_pairs, torch=torch, dist=dist, device=dev, precision=precision)
+        rng = np.random.default_rng(1000)
+        spins = (2 * rng.integers(0, 2, size=(K, R, N_SPINS), dtype=np.int8) - 1).astype(np.int8)
+        apt.set_spins_by_slot(spins)
+        e0 = apt.gather_by_slot()[1].min()
+        wr, tr = a.warmup * C5_ROUNDS_PER_STEP, a.steps * C5_ROUNDS_PER_STEP
+        apt.plan(wr + tr, S_SWAP, chunk_rounds=PLAN_CHUNK_ROUNDS)
+        for _ in range(wr):
+            apt.round(S_SWAP)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(tr):
+            apt.round(S_SWAP)
+        sync()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        cfg, en = apt.gather_by_slot()
+        ok = bool(np.array_equal(en[:, :C5_BETAS_PER_GPU], np.stack([apt.engs[0].energy_of(c[:C5_BETAS_PER_GPU]) for c in cfg])))
+        coll = ("rccl ncclAllGather + grouped ncclSend/ncclRecv issued by libnlmc_hip.so on the kernels' stream" if apt.lib_collective
+                else "torch.distributed all_gather + batch_isend_irecv" if (dist is not None and world > 1) else None)
+        apt.check()
+        apt.close()
+        return {"value": float(K * R) * N_SPINS * S_SWAP * tr / dt, "unit": "spin-updates/s", "precision": precision, "rounds_timed": tr,
+                "seconds_timed": dt, "ms_per_round": dt / tr * 1e3, "collective": coll,
+                "min_energy": {"start": float(e0), "end": float(en.min())}, "tracked_energies_equal_fp64_recomputation": ok}
+
+    first, second = a.headline, ("f32" if a.headline == "f64" else "f64")
+    r1 = leg(first)
+    r2 = None if a.no_second_leg else leg(second)
+    if rank == 0:
+        out = {"metric": "spin-updates/s (replicas x spins x sweeps / s), APT sweeps + iso-cluster moves + swap rounds (BASELINE config 5)",
+               "value": r1["value"], "unit": "spin-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": r1["seconds_timed"] / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f64 field + 53-bit uniform (the reference's arithmetic)" if first == "f64" else "i32 fixed-point field + f32 threshold",
+               "data": "synthetic",
+               "config": {"workload": "APT + Houdayer iso-cluster moves, sparse +-J spin glass (C5 per GPU)", "spins": N_SPINS,
+                          "temperatures_per_gpu": C5_BETAS_PER_GPU, "subreplicas": K, "replicas_per_gpu": C5_BETAS_PER_GPU * K,
+                          "sweeps_per_round": S_SWAP, "rounds_per_step": C5_ROUNDS_PER_STEP, "swap_pairs_per_round": n_pairs,
+                          "sharding": "temperature-slot blocks, all sub-replicas of a temperature on one GPU"},
+               "ranks_seen": world}
+        out.update({k: v for k, v in r1.items() if k not in ("value", "unit", "precision")})
+        if r2 is not None:
+            out["second_leg"] = r2
+        out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,6 +254,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-leg", action="store_true", help="skip the fixed-point leg")
     ap.add_argument("--headline", choices=["f64", "f32"], default="f64", help=argparse.SUPPRESS)
+    ap.add_argument("--workload", choices=["c4", "c5"], default="c4",
+                    help="c4 (default, the headline): replica-sharded NPT; c5: APT + iso-cluster moves, 32 temperatures x 8 sub-replicas "
+                         "per GPU, the temperature ladder cut into slot blocks over the GPUs (BASELINE config 5)")
     ap.add_argument("--dry-run-launch", action="store_true", help="print the launcher command of --gpus N and exit")
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)     # child of cpu_baseline_all_cores
     ap.add_argument("--cpu-chain", type=int, default=0, help=argparse.SUPPRESS)
@@ -225,6 +304,11 @@ def main():
 
     J, h = make_instance(N_SPINS, seed=INSTANCE_SEED)
     inst = P.Instance(J, h)
+    if a.workload == "c5":
+        run_c5(a, P, inst, torch, dist, world, rank, local_rank)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     positions_per_update = 1.0 + float(np.count_nonzero(np.diff(J.indptr) > 8)) / N_SPINS
     assert np.all(np.abs(J.data) == 1.0)                   # the bench instance is +-J: 2-byte schedule entries
     sched_bytes = SCHEDULE_BYTES_PER_POSITION * positions_per_update
