@@ -133,10 +133,11 @@ class SweepMixin:
         # batched path (24-bit fixed-point couplings + logistic thresholds; DESIGN.md section 2 states the tolerance: the
         # chain samples the Boltzmann law of (Jq, hq) 2^-qs with |Jq 2^-qs - J| <= 2^-(qs+1), nothing lost for +-J / integer
         # instances), on fused windows planned piece by piece within a memory budget where the instance qualifies, sweep by
-        # sweep otherwise (same bits).  Smaller instances: fp64 fields.  The argmin hand-off (NMC/nmc.py:394-395) takes the
-        # first minimum of the energies tracked by the kernel (exact integers of the quantised model in the "f32"
-        # arithmetic); o["energy_recorded"] holds the fp64 energies of the recorded configurations, computed on the device
-        # copy of the trace -- what the reference's list comprehension (NMC/nmc.py:386-387) would give for them.
+        # sweep otherwise (same bits).  Smaller instances: fp64 fields.  o["energy_recorded"] holds the fp64 energies of the
+        # recorded configurations, computed on the device copy of the trace -- what the reference's list comprehension
+        # (NMC/nmc.py:386-387) would give for them; NMC_subroutine's argmin hand-off (NMC/nmc.py:394-395) uses THEM whenever every
+        # sweep was recorded (M_skip == 1) and the kernel's tracked minimum (exact integers of the quantised model in the "f32"
+        # arithmetic) only for strided recording.
         if n >= 256:
             o = eng.sweep_philox_windows(num_sweeps, self.seed, sweep0=self._sweep_counter, beta=beta2, record_stride=rs,
                                          want_energy=True, want_min=True, want_state=True, want_recorded_energy=True)
@@ -291,7 +292,15 @@ class Common(SweepMixin):
             er = o.get("energy_recorded")                  # fp64 energies of the recorded columns (device-RNG mode, n >= 256)
             energy_overall[at:at + w] = en[::M_skip] if er is None else (er[0] if strided else er[0][::M_skip])
             at += w
-            m_init = o["argmin_state"][0].astype(np.float64)
+            if er is not None and (not strided or M_skip == 1):
+                # every sweep was recorded and its fp64 energy is at hand: the hand-off is the reference's own rule, the FIRST
+                # argmin of the fp64 energies (NMC/nmc.py:386-395) -- the same column the energies returned above point at (for
+                # couplings that are not exact in fixed point the kernel's tracked minimum can sit on another column: ADVICE r3)
+                m_init = o["spins"][0][int(np.argmin(er[0]))].astype(np.float64)
+            else:
+                # strided recording (M_skip > 1): not every column came back; the first minimum of the energies the kernel tracked
+                # over ALL sweeps (exact integers of the fixed-point model in the "f32" arithmetic, fp64 in the others)
+                m_init = o["argmin_state"][0].astype(np.float64)
             return o
 
         def detect(ms):

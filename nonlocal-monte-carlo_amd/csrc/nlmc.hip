@@ -1644,7 +1644,8 @@ int nlmc_last_schedule_stats(nlmc_ctx *c, int64_t *n_orders, int64_t *n_levels)
     int64_t lv = 0;
     if (p && cnt > 0) {
         std::vector<int32_t> hnl((size_t)cnt);
-        HIP_TRY(c, hipMemcpy(hnl.data(), p, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpyAsync(hnl.data(), p, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
         for (int32_t v : hnl) lv += v;
     }
     if (n_orders) *n_orders = cnt;
@@ -1673,11 +1674,14 @@ int nlmc_pt_init(nlmc_ctx *c, int ladder_len, const double *beta_list)
     HIP_TRY(c, c->pt_status.reserve(1));
     std::vector<int32_t> ident((size_t)G);
     for (int i = 0; i < G; ++i) ident[i] = i % ladder_len;
-    HIP_TRY(c, hipMemcpy(c->slot_of_chain.p, ident.data(), sizeof(int32_t) * G, hipMemcpyHostToDevice));
-    for (int i = 0; i < G; ++i) ident[i] = i;   // chain_of_slot[ladder*L + slot] = global chain id
-    HIP_TRY(c, hipMemcpy(c->chain_of_slot.p, ident.data(), sizeof(int32_t) * G, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->pt_beta.p, beta_list, sizeof(double) * ladder_len, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemset(c->pt_status.p, 0, sizeof(int32_t)));
+    // (stream-ordered: the context's stream may be a non-blocking one, which legacy NULL-stream copies are not ordered against)
+    std::vector<int32_t> cos((size_t)G);
+    for (int i = 0; i < G; ++i) cos[i] = i;     // chain_of_slot[ladder*L + slot] = global chain id
+    HIP_TRY(c, hipMemcpyAsync(c->slot_of_chain.p, ident.data(), sizeof(int32_t) * G, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->chain_of_slot.p, cos.data(), sizeof(int32_t) * G, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->pt_beta.p, beta_list, sizeof(double) * ladder_len, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->pt_status.p, 0, sizeof(int32_t), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return NLMC_OK;
 }
 
@@ -1813,7 +1817,7 @@ int nlmc_pt_swap_philox(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs,
         HIP_TRY(c, hipMemcpyAsync(&st, c->pt_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (st != 0) {
-            HIP_TRY(c, hipMemset(c->pt_status.p, 0, sizeof(int32_t)));
+            HIP_TRY(c, hipMemsetAsync(c->pt_status.p, 0, sizeof(int32_t), c->stream));
             return fail(c, NLMC_ERR_ARG, "Cannot find non-overlapping pairs.");
         }
     }
@@ -2133,7 +2137,7 @@ int nlmc_pt_check(nlmc_ctx *c)
     HIP_TRY(c, hipMemcpyAsync(&st, c->pt_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (st != 0) {
-        HIP_TRY(c, hipMemset(c->pt_status.p, 0, sizeof(int32_t)));
+        HIP_TRY(c, hipMemsetAsync(c->pt_status.p, 0, sizeof(int32_t), c->stream));
         return fail(c, NLMC_ERR_ARG, "Cannot find non-overlapping pairs.");
     }
     return NLMC_OK;
@@ -2506,10 +2510,10 @@ int nlmc_pt_mark_slots(nlmc_ctx *c, const uint8_t *marks)
     HIP_TRY(c, c->sub_list_buf.reserve((size_t)std::max(c->n_chains, 1)));
     HIP_TRY(c, c->cmask.reserve((size_t)std::max(c->n_chains, 1) * c->n_pad));
     HIP_TRY(c, c->nmc_status.reserve(1));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(c->slot_mark.p, m.data(), (size_t)L, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemset(c->nmc_status.p, 0, sizeof(int32_t)));
-    HIP_TRY(c, hipMemset(c->cmask.p, 0, (size_t)std::max(c->n_chains, 1) * c->n_pad));
+    HIP_TRY(c, hipMemcpyAsync(c->slot_mark.p, m.data(), (size_t)L, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->nmc_status.p, 0, sizeof(int32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->cmask.p, 0, (size_t)std::max(c->n_chains, 1) * c->n_pad, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));          // (`m` goes away)
     c->n_marked_local = k * (c->n_chains / L);
     c->subset = 0;
     c->sub_dirty = true;
@@ -2634,7 +2638,8 @@ int nlmc_backbone_clusters(nlmc_ctx *c, const double *epsilon, const double *lam
     if (thr != c->nmc_thr_host) {
         HIP_TRY(c, c->nmc_thr.reserve((size_t)n_thresholds));
         HIP_TRY(c, hipStreamSynchronize(c->cur));
-        HIP_TRY(c, hipMemcpy(c->nmc_thr.p, thr.data(), sizeof(double) * thr.size(), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpyAsync(c->nmc_thr.p, thr.data(), sizeof(double) * thr.size(), hipMemcpyHostToDevice, c->cur));
+        HIP_TRY(c, hipStreamSynchronize(c->cur));
         c->nmc_thr_host = thr;
     }
     hipLaunchKernelGGL(k_lbp_seeds, dim3(P), dim3(256), 0, c->cur, c->n, c->n_pad, c->sub_list(), c->spins.p, c->lbp_ms.p);
@@ -2655,7 +2660,7 @@ int nlmc_backbone_check(nlmc_ctx *c)
     HIP_TRY(c, hipMemcpyAsync(&st, c->nmc_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (st != 0) {
-        HIP_TRY(c, hipMemset(c->nmc_status.p, 0, sizeof(int32_t)));
+        HIP_TRY(c, hipMemsetAsync(c->nmc_status.p, 0, sizeof(int32_t), c->stream));
         if (st & 2) return fail(c, NLMC_ERR_HIP, "nlmc_backbone_clusters: the workgroups of a problem lost each other (group barrier timed out)");
         return fail(c, NLMC_ERR_ARG, "LBP diverged at initial lambda, please try a larger lambda_start or increase max_iterations or beta");
     }

@@ -16,6 +16,12 @@ import numpy as np
 from .engine import Engine, RoundPlanner
 
 
+# Sweep indices (Philox counters) of the NMC phases that marked slots run inside a round: a range of their own, disjoint from the
+# plain sweeps' whatever the number of rounds -- so rounds driven with and without a plan draw the same numbers (the
+# unplanned fallback used to reuse the next round's plain indices).
+NMC_SWEEP_SPACE = 1 << 31
+
+
 def block_partition(n_global, world, rank):
     """Contiguous block of chains owned by `rank` (first `n_global % world` ranks get one extra)."""
     q, r = divmod(int(n_global), int(world))
@@ -41,7 +47,9 @@ class ShardedTempering:
             raise ValueError("all_gather_into_tensor needs equal shards: n_chains_global % world_size != 0")
         self.seed, self.n_pairs, self.precision = int(seed), int(n_pairs), precision
         self.eng = make_engine(inst, self.count, self.base, self.G)
-        self.eng.pt_init(np.asarray(beta_list, dtype=np.float64))
+        self.eng_betas = np.asarray(beta_list, dtype=np.float64)
+        self.eng.pt_init(self.eng_betas)
+        self._lt = None
         self.sweeps_done = 0
         self.rounds_done = 0
         self.collective = dist is not None          # also with a single rank: the launcher path stays exercised
@@ -72,6 +80,10 @@ class ShardedTempering:
         inside the sweep loop, NMC/nmc.py:62-71).  `reserve_rounds`: allocate (only allocate) plan buffers for chunks of
         that many rounds now."""
         self._planner = None
+        if self._lt is not None:
+            self._lt.sweeps_done, self._lt.rounds_done = self.sweeps_done, self.rounds_done
+            self._lt.plan(n_sweeps, n_rounds, chunk_rounds=chunk_rounds)
+            return
         if n_rounds > 0 and n_sweeps % n_rounds == 0 and hasattr(self.eng, "plan_philox_fused"):
             # rounds of equal length: fused-window level lists where the instance qualifies (same bits, fuller levels)
             self._planner = RoundPlanner(self.eng, self.sweeps_done, n_rounds, n_sweeps // n_rounds, self.seed,
@@ -87,13 +99,31 @@ class ShardedTempering:
         if n_rounds > 0 and self.n_pairs > 0 and hasattr(self.eng, "pt_plan"):
             self.eng.pt_plan(self.rounds_done, n_rounds, self.seed, self.n_pairs)
 
-    def round(self, n_sweeps, want_log=False):
-        """`n_sweeps` sweeps of every local chain at its ladder temperature, then one swap attempt round."""
+    def configure_nmc(self, *args, **kw):
+        """NMC_task slots (NPT/npt.py:622-647) under the one-process-per-GPU driver: every rank must own WHOLE ladders (restarts
+        sharded over the ranks) -- the chains on marked slots are then a fixed number per rank, each rank decides its own ladders'
+        swaps on the device (same Philox keys as one context holding everything) and a round needs no collective at all.  The
+        rounds are driven by a LocalTempering over this rank's engine: same bits as LocalTempering over all contexts in one process."""
+        L = self.eng.ladder_len
+        if self.base % L or self.count % L:
+            raise NotImplementedError("NMC slots under a ladder that is cut across ranks: shard whole ladders (restarts % ranks == 0)")
+        self._lt = LocalTempering(None, self.eng_betas, self.G, self.seed, self.n_pairs, [0], precision=self.precision,
+                                  engines=[self.eng], parts=[(self.base, self.count)])
+        self._lt.sweeps_done, self._lt.rounds_done = self.sweeps_done, self.rounds_done
+        self._lt.configure_nmc(*args, **kw)
+
+    def round(self, n_sweeps, want_log=False, **outputs):
+        """`n_sweeps` sweeps of every local chain at its ladder temperature, then one swap attempt round.  `outputs` (record_stride /
+        want_* of sweep_philox): the sweeps' outputs are left in self.last_outputs."""
+        if getattr(self, "_lt", None) is not None:           # rounds with NMC slots (whole ladders per rank): no collective
+            self.last_outputs = self._lt.round(n_sweeps, **outputs)[0]
+            self.sweeps_done, self.rounds_done = self._lt.sweeps_done, self._lt.rounds_done
+            return None
         pl = getattr(self, "_planner", None)
         if pl is not None and n_sweeps == pl.S and 0 <= self.rounds_done - self._planner_round0 < pl.R:
-            pl.sweep(self.rounds_done - self._planner_round0)
+            self.last_outputs = pl.sweep(self.rounds_done - self._planner_round0, **outputs)
         else:
-            self.eng.sweep_philox(n_sweeps, self.seed, sweep0=self.sweeps_done, beta=None, precision=self.precision)
+            self.last_outputs = self.eng.sweep_philox(n_sweeps, self.seed, sweep0=self.sweeps_done, beta=None, precision=self.precision, **outputs)
         self.sweeps_done += n_sweeps
         log = None
         if self.n_pairs > 0:
@@ -128,7 +158,9 @@ class ShardedTempering:
         try:
             if self.lib_collective:
                 self.eng.comm_check(self._timeout_ms)
-            if self.n_pairs > 0 and hasattr(self.eng, "pt_check"):
+            if self._lt is not None:
+                self._lt.check()
+            elif self.n_pairs > 0 and hasattr(self.eng, "pt_check"):
                 self.eng.pt_check()          # a swap round whose pair selection ran out raises here at the latest
         finally:
             self.eng.close()
@@ -144,17 +176,22 @@ class LocalTempering:
     decision.  Either way the trajectory equals the single-context one bit for bit.  For one GPU per process over RCCL use
     ShardedTempering."""
 
-    def __init__(self, inst, beta_list, n_chains_global, seed, n_pairs, device_ids, precision="f32", engine_factory=None):
+    def __init__(self, inst, beta_list, n_chains_global, seed, n_pairs, device_ids, precision="f32", engine_factory=None,
+                 engines=None, parts=None):
+        """`parts` (optional): the blocks [(chain_base, count)] this process drives instead of an even cut over device_ids -- one
+        rank's share under a launcher; `engines`: contexts that exist already (they must have had pt_init; not closed here... they
+        ARE closed by close(): hand over ownership)."""
         self.G, self.seed, self.n_pairs, self.precision = int(n_chains_global), int(seed), int(n_pairs), precision
         devs = list(device_ids)
-        self.parts = [block_partition(self.G, len(devs), r) for r in range(len(devs))]
+        self.parts = list(parts) if parts is not None else [block_partition(self.G, len(devs), r) for r in range(len(devs))]
         L = len(np.asarray(beta_list).reshape(-1))
         # every context owns whole ladders: each decides its own ladders' swaps from its own tracked energies (same Philox keys
         # as one context holding everything), nothing passes through the host and the contexts run out of step with each other
         self.whole_ladders = all(base % L == 0 and count % L == 0 for base, count in self.parts)
-        self.engs = []
+        self.engs = list(engines) if engines is not None else []
+        self.nmc_sweeps_done = 0
         try:
-            for d, (base, count) in zip(devs, self.parts):
+            for d, (base, count) in (zip(devs, self.parts) if engines is None else []):
                 if engine_factory is not None:           # (tests: the CPU double of tests/fake_engine.py)
                     e = engine_factory(inst, count, base, self.G)
                 else:
@@ -193,8 +230,9 @@ class LocalTempering:
                         thresholds=np.asarray(thresholds, dtype=np.float64))
 
     def sweeps_per_round(self, n_sweeps):
-        """Sweep indices (RNG counters) one round of `n_sweeps` plain sweeps consumes: the plain chains' plus the NMC phases'."""
-        return n_sweeps + (len(self.nmc["phases"]) * self.nmc["S"] if self.nmc else 0)
+        """Plain sweep indices (RNG counters) one round of `n_sweeps` sweeps consumes.  The NMC phases of the marked slots draw from
+        a range of their own (NMC_SWEEP_SPACE + nmc_sweeps_done, advanced by phases x sweeps_per_phase per round)."""
+        return n_sweeps
 
     def plan(self, n_sweeps, n_rounds, chunk_rounds=None):
         S = n_sweeps // max(1, n_rounds)
@@ -207,7 +245,7 @@ class LocalTempering:
             # the NMC phases draw from their own range of sweep indices, behind the plain sweeps of all planned rounds: both
             # ranges are contiguous over the rounds, so each is served by one fused-window plan (slots 0 and 1)
             n_ph = len(self.nmc["phases"])
-            self._nmc_sweep0 = self.sweeps_done + n_rounds * S
+            self._nmc_sweep0 = NMC_SWEEP_SPACE + self.nmc_sweeps_done
             self._nmc_planners = [RoundPlanner(e, self._nmc_sweep0, n_rounds * n_ph, self.nmc["S"], self.seed,
                                                precision=self.precision, budget_bytes=4 << 30,
                                                chunk_rounds=None if chunk_rounds is None else chunk_rounds * n_ph,
@@ -257,13 +295,15 @@ class LocalTempering:
                 if planned:
                     rec["nmc"].append(self._nmc_planners[k].sweep(ii * n_ph + p, **outputs))
                 else:
-                    rec["nmc"].append(e.sweep_philox(q["S"], self.seed, sweep0=self.sweeps_done + n_sweeps + p * q["S"],
+                    rec["nmc"].append(e.sweep_philox(q["S"], self.seed, sweep0=NMC_SWEEP_SPACE + self.nmc_sweeps_done + p * q["S"],
                                                      beta=q["beta"], precision=self.precision, **outputs))
             e.track_minimum(False)
             e.set_phase("ALL")
             e.select("all")
             outs.append(rec)
         self.sweeps_done += n_sweeps
+        if self.nmc:
+            self.nmc_sweeps_done += len(self.nmc["phases"]) * self.nmc["S"]
         if self.n_pairs > 0:
             if len(self.engs) == 1 or self.whole_ladders:
                 for e in self.engs:
@@ -508,3 +548,87 @@ class SlotShardedAPT:
         for e in self.engs:
             e.close()
         self.engs = []
+
+
+class ShardedAsLocal:
+    """The slice of the LocalTempering interface NPT.run drives, over a ShardedTempering (one process per GPU, a ladder cut across
+    the ranks: ONE all-gather of the energies per round).  `gather(x)`: rows of every rank's local array, in chain order."""
+
+    def __init__(self, st):
+        self.st, self.G, self.engs, self.parts, self.nmc = st, st.G, [st.eng], [(st.base, st.count)], None
+        self.nmc_sweeps_done = 0
+
+    sweeps_done = property(lambda self: self.st.sweeps_done, lambda self, v: setattr(self.st, "sweeps_done", v))
+    rounds_done = property(lambda self: self.st.rounds_done)
+
+    def configure_nmc(self, *a, **k):
+        raise NotImplementedError("NMC slots under a ladder that is cut across ranks: shard whole ladders (num_restarts % ranks == 0)")
+
+    def set_spins(self, spins_global):
+        self.st.set_spins(spins_global)
+
+    def sweeps_per_round(self, n_sweeps):
+        return n_sweeps
+
+    def plan(self, n_sweeps, n_rounds, chunk_rounds=None):
+        self.st.plan(n_sweeps, n_rounds, chunk_rounds=chunk_rounds)
+
+    def log_begin(self, n_rounds):
+        self.st.eng.pt_log_begin(self.st.rounds_done, n_rounds, self.st.n_pairs)
+
+    def round(self, n_sweeps, energy_columns=0, **outputs):
+        self.st.round(n_sweeps, **outputs)
+        return [self.st.last_outputs]
+
+    def slots(self):
+        return self.st.eng.pt_slots()              # the replicated table: every rank applied every decision
+
+    def swap_log(self):
+        return self.st.eng.pt_log_read()
+
+    def gather(self, x):
+        t, dist = self.st.torch, self.st.dist
+        dev = t.device("cuda", t.cuda.current_device())
+        loc = t.from_numpy(np.ascontiguousarray(x)).to(dev)
+        out = t.empty((self.st.world * loc.shape[0],) + tuple(loc.shape[1:]), dtype=loc.dtype, device=dev)
+        dist.all_gather_into_tensor(out, loc)
+        return out.cpu().numpy()
+
+    def check(self):
+        if self.st.n_pairs > 0:
+            self.st.eng.pt_check()
+        if self.st.lib_collective:
+            self.st.eng.comm_check(self.st._timeout_ms)
+
+    def close(self):
+        self.st.eng.close()
+
+
+def launcher_context():
+    """(torch, torch.distributed, world, rank, local_rank) when this process is one rank of a `torch.distributed.run` job (RANK /
+    WORLD_SIZE in the environment; a job of ONE rank counts: it takes the same path), else None.  The process group (backend "nccl"
+    = RCCL) is brought up here if the caller has not done so; call this -- i.e. NPT.run -- before other GPU work of the process
+    where possible."""
+    try:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+    except ValueError:
+        return None
+    if world < 1 or "RANK" not in os.environ:
+        return None
+    import torch
+    import torch.distributed as dist
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    return torch, dist, dist.get_world_size(), dist.get_rank(), local_rank
+
+
+def all_reduce_np(torch, dist, arr):
+    """Sum of a NumPy array over the ranks (read-out bookkeeping of NPT.run under a launcher); the tensor lives where the process
+    group's backend wants it."""
+    dev = "cpu" if dist.get_backend() == "gloo" else torch.device("cuda", torch.cuda.current_device())
+    t = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+    dist.all_reduce(t)
+    return t.cpu().numpy()

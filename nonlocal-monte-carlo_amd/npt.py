@@ -17,6 +17,8 @@ for the return value.
 """
 import random as _pyrandom
 
+import os
+
 import numpy as np
 
 from . import hostlogic
@@ -289,7 +291,7 @@ class NPT(Common):
         swap log is kept on the device and read once; only the last round's trace comes back (as int8 until the
         reference-shaped float64 M is asked for).  `nmc`: NMC_task parameters when some slots have doNMC set -- those
         chains run backbone inference + the NMC phases inside every round, on the device (distributed.LocalTempering)."""
-        from .distributed import LocalTempering
+        from .distributed import LocalTempering, ShardedTempering, ShardedAsLocal, block_partition, launcher_context, all_reduce_np
         from .lbp import lambda_list, _SAT, EPS as _EPS
         inst = self._cache.instance(self.J, self.h)
         R, N = self.num_replicas, inst.n
@@ -298,6 +300,24 @@ class NPT(Common):
         rounds = self.num_swap_attempts
         G = R * n_restarts
         devs = [self._cache.device] if not device_ids else [int(d) for d in device_ids]
+        # One rank of a torch.distributed.run job (RANK / WORLD_SIZE set, device_ids not given): the chains are sharded over the
+        # RANKS, one GPU each.  Whole ladders per rank (num_restarts % ranks == 0): every rank decides its own ladders' swaps, no
+        # collective, NMC slots allowed.  A ladder cut across ranks: ONE all-gather of the energies per round, issued by the
+        # library over RCCL (distributed.ShardedTempering).  M / Energy describe the first restart of the rank (rank 0: restart
+        # 0; with a cut ladder every rank returns restart 0, gathered); self.restart_energies holds all restarts on every rank.
+        ctx = launcher_context() if device_ids is None else None
+        cut = False
+        if ctx is not None:
+            torch_, dist_, W_, rank_, lrank_ = ctx
+            if G % W_:
+                raise ValueError("num_replicas * num_restarts must be a multiple of the number of ranks")
+            base_, count_ = block_partition(G, W_, rank_)
+            # (NLMC_NPT_FORCE_COLLECTIVE: take the cut-ladder driver although the blocks are whole ladders -- rehearses the collective path
+            # with fewer ranks than a real cut needs)
+            cut = base_ % R != 0 or count_ % R != 0 or (bool(os.environ.get("NLMC_NPT_FORCE_COLLECTIVE")) and not nmc)
+            if nmc and cut:
+                raise ValueError("with NMC replicas every ladder must lie on one rank: num_restarts % ranks != 0")
+            devs = [lrank_]
         if G % len(devs):
             raise ValueError("num_replicas * num_restarts must be a multiple of len(device_ids)")
         if nmc and n_restarts % len(devs):
@@ -315,7 +335,15 @@ class NPT(Common):
             while t > nmc["threshold_cutoff"]:
                 thr.append(float(t))
                 t -= 0.01
-        lt = LocalTempering(inst, beta_list, G, self.seed, self.num_swapping_pairs, devs)
+        if ctx is None:
+            lt = LocalTempering(inst, beta_list, G, self.seed, self.num_swapping_pairs, devs)
+        elif not cut:
+            lt = LocalTempering(inst, beta_list, G, self.seed, self.num_swapping_pairs, devs, parts=[(base_, count_)])
+        else:
+            lt = ShardedAsLocal(ShardedTempering(
+                lambda i, n, b, g: Engine(i, None, n, device=lrank_, chain_base=b, n_chains_global=g), inst, beta_list, G, self.seed,
+                self.num_swapping_pairs, torch=torch_, dist=dist_, device=torch_.device("cuda", lrank_)))
+        lo_, hi_ = (0, G) if (ctx is None or cut) else (base_, base_ + count_)       # global chains the arrays below cover
         M_buf = M_touch = None
         if return_trace == "float64" and R * N * S * 8 >= (32 << 20):
             # the reference-shaped float64 M of the return value: allocated now, its pages faulted in by a background thread
@@ -329,6 +357,7 @@ class NPT(Common):
             m0 = (2 * np.random.default_rng(self.seed).integers(0, 2, size=(G, N), dtype=np.int8) - 1).astype(np.int8)
             lt.set_spins(m0)
             lt.sweeps_done = self._sweep_counter
+            lt.nmc_sweeps_done = getattr(self, "_nmc_sweep_counter", 0)
             lt.plan(rounds * S, rounds)
             if self.num_swapping_pairs > 0:
                 lt.log_begin(rounds)
@@ -356,14 +385,25 @@ class NPT(Common):
                         e_last, _ = self._assemble_mixed(lt, outs, S, N, 0, "energy")
                     else:
                         e_last = np.concatenate([o["energy"] for o in outs])   # [G, S] tracked
+            if cut:                                      # every rank assembles the whole ladder's read-out
+                last = None if last is None else lt.gather(last)
+                E_cols = None if E_cols is None else lt.gather(E_cols)
+                e_last = None if e_last is None else lt.gather(e_last)
+            elif ctx is not None and nmc:                # (_assemble_mixed lays its rows out by global chain id)
+                last = None if last is None else last[lo_:hi_]
+                E_cols = None if E_cols is None else E_cols[lo_:hi_]
+                e_last = None if e_last is None else e_last[lo_:hi_]
+            gch = np.arange(lo_, hi_)                    # global ids of the chains the arrays cover
+            sl_ = slots_last[lo_:hi_]
             self._sweep_counter += rounds * lt.sweeps_per_round(S)
+            self._nmc_sweep_counter = lt.nmc_sweeps_done          # (the NMC phases draw from a counter range of their own)
             lt.check()
             Energy = np.zeros(R)
             E_all = np.zeros((n_restarts, R))
             if last is not None and S > 0:
                 if k > 0:
-                    E_all[np.arange(G) // R, slots_last] = E_cols.min(axis=1)
-                    Energy = E_all[0].copy()
+                    E_all[gch // R, sl_] = E_cols.min(axis=1)
+                    Energy = E_all[lo_ // R].copy()
                 else:
                     Energy[0] = np.min(np.zeros(0))                              # np.min of nothing: ValueError (NPT/npt.py:43)
             elif return_trace is None and S > 0 and rounds > 0:
@@ -371,26 +411,31 @@ class NPT(Common):
                 # fixed-point couplings, within 2^-(qs+1) per coupling of the fp64 ones)
                 if k <= 0:
                     Energy[0] = np.min(np.zeros(0))
-                E_all[np.arange(G) // R, slots_last] = e_last[:, :k].min(axis=1)
-                Energy = E_all[0].copy()
+                E_all[gch // R, sl_] = e_last[:, :k].min(axis=1)
+                Energy = E_all[lo_ // R].copy()
             M = None
             if return_trace is not None:
                 dt = np.float64 if return_trace == "float64" else np.int8
                 if M_touch is not None:
                     M_touch.join()
                 if last is not None:                     # restart 0 is the one returned in the reference's shape:
-                    M = trace_layout(last[:R], slots_last[:R], R, dt, out=M_buf)   # block r = the replica at temperature slot r
+                    M = trace_layout(last[:R], sl_[:R], R, dt, out=M_buf)   # block r = the replica at temperature slot r
                 else:
                     M = np.zeros((R * N, S), dtype=dt)
             if self.num_swapping_pairs > 0 and rounds > 0:
                 p, a = lt.swap_log()                     # [rounds, ladders, pairs, 2] / [rounds, ladders, pairs]
-                self.swap_pairs = p[:, 0].reshape(-1, 2) + 1
-                self.swap_accepted = a[:, 0].reshape(-1).astype(np.int8)
+                if ctx is not None and not cut:          # every rank logged its own ladders: all restarts on every rank
+                    p = all_reduce_np(torch_, dist_, np.where(p < 0, 0, p + 1).astype(np.int32)) - 1
+                    a = all_reduce_np(torch_, dist_, a.astype(np.int32)).astype(np.uint8)
+                self.swap_pairs = p[:, lo_ // R].reshape(-1, 2) + 1
+                self.swap_accepted = a[:, lo_ // R].reshape(-1).astype(np.int8)
                 self.swap_acceptance_per_restart = a.reshape(rounds, n_restarts, -1).mean(axis=(0, 2))
                 self.swap_log_all = (p, a)               # slots (0-based) / decisions of every restart
             else:
                 self.swap_pairs, self.swap_accepted = np.zeros((0, 2), np.int32), np.zeros(0, np.int8)
             self.final_slots = lt.slots()
+            if ctx is not None and not cut:              # the other ranks' restarts
+                E_all = all_reduce_np(torch_, dist_, E_all)
             self.restart_energies = E_all
         finally:
             lt.close()

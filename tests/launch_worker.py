@@ -1,0 +1,40 @@
+"""Worker of tests/test_gpu_launcher.py: one rank of a (small) torch.distributed job that calls the drop-in NPT.run.  Started as a
+child process with RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* set; torch is imported first (before the engine's HIP runtime)."""
+import json
+import os
+import sys
+
+import torch                    # noqa: F401  (first: see DESIGN.md section 10)
+import torch.distributed as dist
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def main():
+    out, backend, mode = sys.argv[1], sys.argv[2], sys.argv[3]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    from conftest import load_product
+    from helpers import make_instance
+    P = load_product()
+    torch.cuda.set_device(0)
+    if backend == "gloo":
+        dist.init_process_group("gloo", rank=rank, world_size=world)     # (two ranks on ONE GPU: RCCL refuses that, gloo does not care)
+    N, R = 300, 6
+    J, h = make_instance(N, seed=4)
+    betas = np.geomspace(0.3, 2.5, R)
+    doNMC = [False] * (R - 2) + [True, True] if mode == "nmc" else [False] * R
+    obj = P.NPT(J.toarray(), h, rng="philox", seed=11)
+    M, E = obj.run(betas, R, doNMC, num_sweeps_MCMC=60, num_sweeps_read=60, num_swap_attempts=6, num_swapping_pairs=2, num_cycles=1,
+                   num_restarts=2, global_beta=2.5, lambda_start=3.0, lambda_end=0.05, lambda_reduction_factor=0.8, threshold_initial=0.9999,
+                   threshold_cutoff=0.97)
+    np.savez(out + f".rank{rank}.npz", M=M, E=E, restart_energies=obj.restart_energies, swap_accepted=obj.swap_accepted)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    print(json.dumps({"rank": rank, "ok": True}))
+
+
+if __name__ == "__main__":
+    main()

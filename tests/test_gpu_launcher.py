@@ -1,0 +1,78 @@
+"""NPT.run as one rank of a torch.distributed.run job: restarts sharded over the ranks with NMC_task slots (whole
+ladders per rank: no collective), and the cut-ladder driver with the library-issued all-gather (rehearsed with one rank).  The
+workers are child processes (tests/launch_worker.py); results must equal the single-process run bit for bit."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import make_instance
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(tmp_path, world, backend, mode, extra_env=None):
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "launch_worker.py"), str(tmp_path / "o"), backend, mode],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-3000:]
+    return [np.load(str(tmp_path / "o") + f".rank{r}.npz") for r in range(world)]
+
+
+def reference(product, mode):
+    N, R = 300, 6
+    J, h = make_instance(N, seed=4)
+    betas = np.geomspace(0.3, 2.5, R)
+    doNMC = [False] * (R - 2) + [True, True] if mode == "nmc" else [False] * R
+    obj = product.NPT(J.toarray(), h, rng="philox", seed=11)
+    M, E = obj.run(betas, R, doNMC, num_sweeps_MCMC=60, num_sweeps_read=60, num_swap_attempts=6, num_swapping_pairs=2, num_cycles=1,
+                   num_restarts=2, global_beta=2.5, lambda_start=3.0, lambda_end=0.05, lambda_reduction_factor=0.8, threshold_initial=0.9999,
+                   threshold_cutoff=0.97)
+    return M, E, obj.restart_energies, obj.swap_accepted, obj.swap_log_all[1]
+
+
+@pytest.mark.parametrize("mode", ["plain", "nmc"])
+def test_two_ranks_share_the_restarts(product, tmp_path, mode):
+    """Two ranks (gloo group, both on the one GPU of the box), one restart each: rank 0 returns restart 0, rank 1 restart 1, both
+    know every restart's energies -- equal to the single-process run with num_restarts = 2.  mode "nmc": the two coldest slots
+    run NMC_task inside every round (device-resident, distributed.ShardedTempering-style whole ladders per rank)."""
+    M, E, RE, acc, acc_all = reference(product, mode)
+    got = launch(tmp_path, 2, "gloo", mode)
+    assert np.array_equal(got[0]["M"], M) and np.array_equal(got[0]["E"], E)
+    assert np.array_equal(got[0]["swap_accepted"], acc)
+    for r in (0, 1):
+        assert np.array_equal(got[r]["restart_energies"], RE)
+        assert np.array_equal(got[r]["E"], RE[r])
+    assert np.array_equal(got[1]["swap_accepted"], acc_all[:, 1].reshape(-1))
+    assert not np.array_equal(got[1]["M"], M)
+
+
+def test_one_rank_cut_ladder_driver_with_the_library_collective(product, tmp_path):
+    """A one-rank RCCL job forced onto the cut-ladder driver (ShardedTempering: energies all-gathered by the library on the kernels'
+    stream, read-out gathered over the ranks): the same M, Energy and swap decisions as the plain call."""
+    M, E, RE, acc, _ = reference(product, "plain")
+    try:
+        got = launch(tmp_path, 1, "nccl", "plain", {"NLMC_NPT_FORCE_COLLECTIVE": "1"})
+    except AssertionError as ex:
+        if "librccl" in str(ex) or "NCCL" in str(ex):
+            pytest.skip(str(ex)[-300:])
+        raise
+    assert np.array_equal(got[0]["M"], M) and np.array_equal(got[0]["E"], E)
+    assert np.array_equal(got[0]["restart_energies"], RE) and np.array_equal(got[0]["swap_accepted"], acc)

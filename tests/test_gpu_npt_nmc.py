@@ -96,7 +96,7 @@ def test_rounds_with_nmc_slots_match_the_oracle_at_c3_size(product):
                 cb = np.tile(np.array(oracle.cb_pair(gbeta, temp_x)), (S_nmc, 1))
                 for p, kind in enumerate(phases):
                     e0 = int(np.rint(oracle.energy(csr, h, s) * 2.0 ** esc))
-                    M, s_fin, tr = oracle.sweeps_philox(csr, h, s, cb, seed, c, sweep0=rounds * S + (ii * 3 + p) * S_nmc,
+                    M, s_fin, tr = oracle.sweeps_philox(csr, h, s, cb, seed, c, sweep0=(1 << 31) + (ii * 3 + p) * S_nmc,
                                                         flags=_phase_flags(mask[c], kind), escale=esc, efix0=e0)
                     assert np.array_equal(M, outs["nmc"][p]["spins"][j]), f"round {ii}: NMC chain {c}, phase {kind}"
                     assert np.array_equal(tr * 2.0 ** -esc, outs["nmc"][p]["energy"][j])
@@ -229,3 +229,39 @@ def test_npt_with_nmc_replicas_on_chimera128_against_the_known_ground_state(prod
         assert best[n_nmc] >= e_gs - 1e-3, (n_nmc, best[n_nmc], e_gs)
     assert best[2] <= e_gs * (1 - 0.01), (best, e_gs)
     assert abs(best[0] - e_gs) < 1e-3, (best, e_gs)
+
+
+def test_rounds_with_nmc_slots_planned_and_unplanned_draw_the_same_numbers(product):
+    """without a plan the NMC phases of round i used sweep indices that round i + 1's plain sweeps (and phases) used
+    again.  The phases now draw from a counter range of their own (distributed.NMC_SWEEP_SPACE), the same with and without a plan:
+    planned rounds, unplanned rounds and a plan that covers only the first rounds give the same states and slots."""
+    N, R, n_restarts, n_nmc, S, rounds, seed = 600, 8, 2, 3, 6, 4, 0xBEEF
+    G = R * n_restarts
+    J, h = make_instance(N, seed=3)
+    inst = product.Instance(J, h)
+    betas = np.geomspace(0.2, 2.5, R)
+    doNMC = np.array([False] * (R - n_nmc) + [True] * n_nmc)
+    graph = product.lbp.EdgeGraph(inst)
+    args = (doNMC, ["C", "NC", "ALL"], 5, 2.5, 20.0, graph.epsilon(inst.h), product.lbp.lambda_list(3.0, 0.05, 0.8), EPS, 100,
+            float(np.tanh(19.06)) - EPS, _thresholds(0.9999, 0.97))
+    from nlmc_amd.distributed import LocalTempering
+    m0 = (2 * np.random.default_rng(5).integers(0, 2, size=(G, N), dtype=np.int8) - 1).astype(np.int8)
+
+    def drive(planned_rounds):
+        lt = LocalTempering(inst, betas, G, seed, 2, [0])
+        try:
+            lt.configure_nmc(*args)
+            lt.set_spins(m0)
+            if planned_rounds:
+                lt.plan(planned_rounds * S, planned_rounds)
+            for _ in range(rounds):
+                lt.round(S)
+            lt.check()
+            return lt.gather_spins(), lt.slots(), lt.sweeps_done, lt.nmc_sweeps_done
+        finally:
+            lt.close()
+    a, b, c = drive(rounds), drive(0), drive(2)
+    assert a[2:] == (rounds * S, rounds * 3 * 5) == b[2:] == c[2:]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+    assert not np.array_equal(a[0], m0)
