@@ -343,15 +343,15 @@ def main():
         if wr:
             # (buffers for a full chunk are allocated here: memory allocation is not part of a round's work)
             st.plan(wr * S_SWAP, wr, chunk_rounds=chunk, lazy=True, reserve_rounds=chunk)
-            for _ in range(wr):
-                st.round(S_SWAP)
+            st.run_rounds(wr, S_SWAP)
         tr = steps * ROUNDS_PER_STEP
         st.plan(tr * S_SWAP, tr, chunk_rounds=chunk, lazy=True)     # a fresh, EMPTY planner: nothing is built yet
         st.eng.timing_reset(True, every=EVENT_EVERY if fused else 1)
         sync()
         t0 = time.perf_counter()
-        for _ in range(tr):
-            st.round(S_SWAP)
+        # (one process, one ladder per context: a planned chunk of rounds per launch -- k_rounds_fused, the chains stay in LDS between
+        # the rounds; ranks that exchange energies over RCCL: one sweep launch + one swap launch per round)
+        st.run_rounds(tr, S_SWAP)
         sync()
         dt = time.perf_counter() - t0
         tm = st.eng.timing_total()
@@ -371,6 +371,7 @@ def main():
         st.close()
         return {"dt": dt, "tm": tm, "rounds": tr, "count": count, "e_start": e_start, "e_end": e_end, "sched": sched,
                 "chunks": chunks, "collective": coll, "fused": fused, "probe": probe, "precision": precision,
+                "persistent_rounds": getattr(st, "persistent_rounds", 0),
                 "tracked_equals_recomputed": bool(np.array_equal(e_end, e_exact))}
 
     KERNEL = {("f64", True): "k_sweep_fused<DIAG=false,FLAGS=false,OUT=false,FMT_ADDR,F64=true>", ("f64", False): "k_sweep_philox<double,false,PK=true>",
@@ -394,13 +395,18 @@ def main():
         pmc = load_pmc().get(r["precision"], {}) if (world == 1 and count == REPLICAS_PER_GPU and r["fused"]) else {}
         levels_launch = r["sched"]["levels"] if r["fused"] else r["sched"]["levels"] / max(1, r["sched"]["orders"]) * S_SWAP / max(1.0, launches_per_round)
         ach_lv = levels_launch / sec_launch if ms_launch > 0 else 0.0
+        kernel = KERNEL[(r["precision"], r["fused"])]
+        if r["persistent_rounds"]:
+            # rounds run inside k_rounds_fused: "launch" below = one ROUND of it (10 sweeps of every chain + the in-kernel swap round;
+            # events around every chunk launch, divided by its rounds)
+            kernel = kernel.replace("k_sweep_fused", "k_rounds_fused (per round of)")
         peak_lv = 1e9 / r["probe"]["conflict_free_ns"]
         achieved = upd_launch * bpu / sec_launch / 1e9 if ms_launch > 0 else 0.0
         out = {
             "value": updates / dt, "unit": "spin-updates/s", "dtype": DTYPE[r["precision"]], "rounds_timed": tr,
             "seconds_timed": dt, "ms_per_round": dt / tr * 1e3,
             "value_kernel_loop": (upd_launch / sec_launch / launches_per_round) * world if ms_launch > 0 else None,
-            "kernel": KERNEL[(r["precision"], r["fused"])], "us_per_launch": ms_launch * 1e3,
+            "kernel": kernel, "us_per_launch": ms_launch * 1e3, "rounds_in_persistent_launches": r["persistent_rounds"],
             "sweep_launches": tm["launches_sweep"], "sweep_launches_with_events": tm["launches_timed"],
             "ms_levelize": tm["ms_levelize"], "ms_sweep_kernels": ms_launch * tm["launches_sweep"],
             "plan_chunks_in_timed_region": r["chunks"],
@@ -416,7 +422,7 @@ def main():
                                         "flight + 1 LDS write per round, bank-conflict-free addresses",
                          "random_gather_round_ns": r["probe"]["random_gather_ns"],
                          "frac_vs_random_gather_round": ach_lv * r["probe"]["random_gather_ns"] * 1e-9,
-                         "kernel": KERNEL[(r["precision"], r["fused"])], "us_per_launch": ms_launch * 1e3,
+                         "kernel": kernel, "us_per_launch": ms_launch * 1e3,
                          "launches_timed": tm["launches_timed"], "launches_total": tm["launches_sweep"],
                          "note": "a chain is one workgroup that advances one level of its schedule per barrier round; the level's "
                                  "dependent chain (barrier -> LDS gather -> sum -> decide -> LDS write -> barrier) is the floor of a "

@@ -232,6 +232,19 @@ int nlmc_pt_swap_philox_collective(nlmc_ctx *ctx, uint32_t round, uint64_t seed,
  * computed ahead of time (one wave per round and ladder).  Later nlmc_pt_swap_philox calls in that range with the same
  * seed and n_pairs are left with the parallel acceptance test.  Results are identical with or without a plan. */
 int nlmc_pt_plan(nlmc_ctx *ctx, uint32_t round0, int n_rounds, uint64_t seed, int n_pairs);
+/* n_rounds whole rounds -- sweeps_per_round sweeps of every chain at its ladder temperature, then the swap round of
+ * nlmc_pt_swap_philox -- in ONE cooperative launch (k_rounds_fused): the chains stay in LDS from round to round, between two
+ * rounds every chain publishes its tracked energy, all workgroups of the launch meet once (bounded wait), and the two chains of a
+ * selected pair each evaluate the identical decision.  Bit-identical to nlmc_sweep_philox(beta = NULL) + nlmc_pt_swap_philox round
+ * by round (the rounds' decisions go to the device-side swap log when one is open); what a launch per round pays again and again
+ * (kernel launches, spins HBM -> LDS -> HBM) is paid once per call.  Needs: a fused-window plan of ONE window per round covering
+ * sweeps [sweep0, sweep0 + n_rounds sweeps_per_round) (nlmc_plan_philox_fused, window == sweeps_per_round), the pair selections of
+ * rounds [round0, round0 + n_rounds) planned (nlmc_pt_plan, same seed and n_pairs), a context of whole ladders without a
+ * communicator, no phase flags / chain subset, one workgroup per chain resident at once (n_chains <= CUs for large n).
+ * NLMC_ERR_UNSUPPORTED (nothing was run) when a condition is not met: the caller runs the rounds one by one.  Asynchronous: a grid
+ * wait that times out is reported by nlmc_pt_check / nlmc_pt_log_read (NLMC_ERR_HIP). */
+int nlmc_pt_rounds_fused(nlmc_ctx *ctx, int precision, int n_rounds, int sweeps_per_round, uint32_t sweep0, uint32_t round0,
+                         uint64_t seed, int n_pairs);
 /* Device-side swap log of rounds [round0, round0 + n_rounds): rounds of nlmc_pt_swap_philox(_host) called WITHOUT host
  * output pointers keep their pairs and decisions on the device; nlmc_pt_log_read copies the whole log in one go
  * (out_pairs [n_rounds][n_ladders][n_pairs][2], -1 where a round did not run; out_accepted [n_rounds][n_ladders][n_pairs])

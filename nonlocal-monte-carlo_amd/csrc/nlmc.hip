@@ -86,8 +86,8 @@ struct nlmc_ctx {
     bool has_flags = false;
     bool has_diag = false;
     bool has_zero_vals = false;   // a stored entry is 0.0 (or underflows to 0 in fp32)
-    size_t lds_opt[64] = {};      // dynamic-LDS opt-in already granted, one slot per kernel: 0 k_levelize, 1 k_icm_components,
-                                  // 2..7 sweep-by-sweep kernels, 8 k_stream_scatter, 16 k_levelize_fused, 17..20 k_lbp_lds, 21 k_icm_round, 22..23 packed fp64 sweep kernels, 24..47 k_sweep_fused variants, 48..59 its fp64 variants
+    size_t lds_opt[80] = {};      // dynamic-LDS opt-in already granted, one slot per kernel: 0 k_levelize, 1 k_icm_components,
+                                  // 2..7 sweep-by-sweep kernels, 8 k_stream_scatter, 16 k_levelize_fused, 17..20 k_lbp_lds, 21 k_icm_round, 22..23 packed fp64 sweep kernels, 24..47 k_sweep_fused variants, 48..59 its fp64 variants, 60..71 k_rounds_fused
 
     DevBuf<int32_t> rowptr, col;
     DevBuf<double> val64, h64;
@@ -225,6 +225,11 @@ struct nlmc_ctx {
     DevBuf<long long> apt_e_all;                     // [world][K][ladder_len]
     DevBuf<int8_t> apt_send, apt_recv;               // [2][K][n_pad]
     DevBuf<int32_t> apt_bd;                          // [2][K]
+    DevBuf<double> rounds_ebuf;                      // k_rounds_fused: [2][n_chains_global] published energies
+    DevBuf<unsigned> rounds_bar;                     // its arrival counter
+    DevBuf<unsigned char> rounds_args;               // its argument structs (read through constant-memory pointers), 2 slots
+    std::vector<unsigned char> rounds_args_host[2];  // ... as uploaded (kept until the next call of the same slot)
+    int rounds_args_slot = 0;
     void *comm = nullptr;              // RCCL communicator of the sharded tempering (nlmc_comm_init): the per-round all-gather of
     int comm_world = 0, comm_rank = 0; // the energies is issued by the library on the kernels' own stream
 
@@ -1170,6 +1175,7 @@ void nlmc_destroy(nlmc_ctx *c)
     c->lbp_bar.release(); c->lbp_part.release();
     c->lbp_hm.release(); c->lbp_tot.release(); c->lbp_mag.release(); c->lbp_mag_all.release();
     c->pt_tab.release(); c->pt_beta.release(); c->pt_energies_all.release();
+    c->rounds_ebuf.release(); c->rounds_bar.release(); c->rounds_args.release();
     c->apt_beta.release(); c->apt_e_all.release(); c->apt_send.release(); c->apt_recv.release(); c->apt_bd.release();
     c->slot_of_chain.release(); c->chain_of_slot.release(); c->pt_pairs.release(); c->pt_status.release();
     c->pt_acc.release(); c->pt_log_acc.release(); c->pt_log_pairs.release(); c->pt_plan_pairs.release(); c->pt_plan_ok.release(); c->icm_label.release(); c->icm_info.release(); c->icm_pairs.release();
@@ -2098,6 +2104,122 @@ int nlmc_apt_swap_collective(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_p
     return apt_launch_swap(c, round, seed, n_pairs, out_pairs, out_accepted);
 }
 
+// n_rounds rounds (sweeps_per_round sweeps at the ladder temperatures + the swap round) in ONE cooperative launch (k_rounds_fused).
+int nlmc_pt_rounds_fused(nlmc_ctx *c, int precision, int n_rounds, int sweeps_per_round, uint32_t sweep0, uint32_t round0, uint64_t seed,
+                         int n_pairs)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (n_rounds < 0 || sweeps_per_round < 1 || (precision != NLMC_F32 && precision != NLMC_F64) || n_pairs < 0)
+        return fail(c, NLMC_ERR_ARG, "nlmc_pt_rounds_fused: bad argument");
+    if (c->ladder_len == 0) return fail(c, NLMC_ERR_STATE, "nlmc_pt_rounds_fused: call nlmc_pt_init first");
+    if (n_rounds == 0 || c->n_chains == 0) return NLMC_OK;
+    const int L = c->ladder_len, T = sweeps_per_round;
+    auto no = [&](const char *why) { return fail(c, NLMC_ERR_UNSUPPORTED, std::string("nlmc_pt_rounds_fused: ") + why); };
+    if (getenv("NLMC_NO_PERSISTENT")) return no("switched off (NLMC_NO_PERSISTENT)");
+    if (c->chain_base % L != 0 || c->n_chains % L != 0) return no("the context's block cuts a ladder (the swap needs other contexts' energies)");
+    if (c->comm || (c->apt_R > 0 && c->apt_world > 1)) return no("the context takes part in a collective swap round");
+    if (c->has_flags || c->subset != 0 || c->cur != c->stream) return no("phase flags or a chain subset are in force");
+    if (n_pairs > std::max(0, L - 1)) return fail(c, NLMC_ERR_ARG, "Cannot find non-overlapping pairs.");
+    const int fslot = fused_plan_for(c, sweep0, n_rounds * T, seed);
+    if (fslot < 0 || c->fz[fslot].T != T) return no("no fused-window plan of one window per round covers these sweeps");
+    if (precision == NLMC_F64 && !fused_f64_supported(c, T)) return no("the fp64 mode does not run on fused windows for this instance");
+    if (n_pairs > 0 && !(c->pt_plan_valid && c->pt_plan_seed == seed && c->pt_plan_npairs == n_pairs && round0 >= c->pt_plan_round0 &&
+                         (uint64_t)round0 + (uint64_t)n_rounds <= (uint64_t)c->pt_plan_round0 + (uint64_t)c->pt_plan_rounds))
+        return no("the pair selections of these rounds are not planned (nlmc_pt_plan)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const nlmc_ctx::FusedPlan &P = c->fz[fslot];
+    const bool f64 = precision == NLMC_F64;
+    const int kt = f64 ? 2 * c->xmax + 1 : 0;
+    const FusedLds Lds = fused_lds(c->n, c->n_pad, false, false, P.fmt == NLMC_FMT_ADDR, kt);
+#define NLMC_KR(D, F64_) {reinterpret_cast<const void *>(k_rounds_fused<D, NLMC_FMT_WIDE, F64_>), reinterpret_cast<const void *>(k_rounds_fused<D, NLMC_FMT_COMPACT, F64_>), \
+                          reinterpret_cast<const void *>(k_rounds_fused<D, NLMC_FMT_ADDR, F64_>)}
+    static const void *const table[2][2][3] = {{NLMC_KR(false, false), NLMC_KR(false, true)}, {NLMC_KR(true, false), NLMC_KR(true, true)}};
+#undef NLMC_KR
+    const void *kfun = table[c->has_diag][f64][P.fmt];
+    { int rc = ensure_lds(c, 60 + ((c->has_diag ? 2 : 0) + (f64 ? 1 : 0)) * 3 + P.fmt, kfun, Lds.total); if (rc) return rc; }
+    const int nt = fused_block(c->n);
+    // every workgroup must be resident at once (they wait for each other): asked of the runtime, which also refuses the launch
+    int per_cu = 0, n_cu = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfun, nt, Lds.total));
+    HIP_TRY(c, hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
+    if ((long long)per_cu * n_cu < c->n_chains) return no("more chains than workgroups the device holds at once");
+    const int w0 = (int)((sweep0 - P.sweep0) / (uint32_t)T), nl = c->n_chains_global / L;
+    const size_t G = (size_t)c->n_chains_global, PS = (size_t)P.pstride;
+    HIP_TRY(c, c->rounds_ebuf.reserve(2 * G));
+    HIP_TRY(c, c->rounds_bar.reserve(1));
+    HIP_TRY(c, hipMemsetAsync(c->rounds_bar.p, 0, sizeof(unsigned), c->stream));
+    if (!c->pt_tab_valid || c->pt_tab_temp_x != c->temp_x) {
+        std::vector<double> tab((size_t)L * 2);
+        for (int r = 0; r < L; ++r) { tab[2 * r] = -2.0 * LOG2E * c->beta_list[r]; tab[2 * r + 1] = -2.0 * LOG2E * (c->beta_list[r] / c->temp_x); }
+        HIP_TRY(c, hipMemcpyAsync(c->pt_tab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->pt_tab_valid = true; c->pt_tab_temp_x = c->temp_x;
+    }
+    SweepArgs a{};
+    a.g = c->g; a.chain_base = c->chain_base; a.spins = c->spins.p; a.temp_x = c->temp_x;
+    a.fz_pstride = P.pstride; a.fz_fmt = P.fmt;
+    a.f_workers = P.workers; a.f_gen0 = P.gen0; a.f_gen_prio = c->knob_no_prio ? 0 : 1;
+#ifdef NLMC_DEBUG_KNOBS
+    a.dbg_flags = c->knob_dbg_flags;
+#endif
+    a.n_sweeps = T; a.sweep0 = sweep0; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.tab = c->pt_tab.p; a.tab_cs = 2; a.tab_ss = 0; a.slot_of_chain = c->slot_of_chain.p;
+    a.efix = c->efix.p; a.escale = c->escale; a.eshift = c->escale - c->qs; a.qinv = std::ldexp(1.0f, -c->qs);
+    a.trace_sweeps = T; a.rec_stride = 1; a.argmin = c->argmin.p;
+    a.lds_neg_off = Lds.neg_off; a.lds_flags_off = Lds.flags_off; a.lds_u_off = Lds.u_off; a.lds_u_stride = Lds.u_bytes; a.lds_red_off = Lds.red_off;
+    a.lds_snap_off = Lds.snap_off; a.lds_kt_off = Lds.kt_off; a.f64_xmax = c->xmax; a.f64_tie_mask = c->knob_tie_mask;
+    a.qinv64 = std::ldexp(1.0, -c->qs);
+    a.rng_stride = c->rng_stride; a.rng_base = c->rng_base; a.rng_ladder_len = std::max(1, L);
+    RoundsArgs q{};
+    q.n_rounds = n_rounds; q.n_windows_avail = c->knob_no_warm ? n_rounds : P.windows - w0;
+    q.loff = P.loff.p + (size_t)w0 * (NLMC_LCAP + 1); q.nlev = P.nlev.p + w0; q.himax = P.himax.p + w0; q.send = P.send.p + (size_t)w0 * T;
+    q.npos = P.npos.p + w0; q.head = P.head.p + (size_t)w0 * PS; q.ell = P.ell.p + (size_t)w0 * PS * NLMC_FZ_W;
+    q.ladder_len = L; q.n_pairs = n_pairs; q.n_ladders = nl; q.round0 = round0;
+    q.plan_pairs = n_pairs > 0 ? c->pt_plan_pairs.p + (size_t)(round0 - c->pt_plan_round0) * nl * n_pairs * 2 : nullptr;
+    q.beta = c->pt_beta.p; q.slot_of_chain = c->slot_of_chain.p; q.chain_of_slot = c->chain_of_slot.p;
+    q.ebuf = c->rounds_ebuf.p; q.bar = c->rounds_bar.p; q.status = c->pt_status.p;
+    q.timeout_ticks = 100000000ll * 20;                   // 20 s of the 100 MHz wall clock
+    if (c->pt_log_on && c->pt_log_npairs == n_pairs && n_pairs > 0 && round0 >= c->pt_log_round0 &&
+        (uint64_t)round0 + (uint64_t)n_rounds <= (uint64_t)c->pt_log_round0 + (uint64_t)c->pt_log_rounds) {
+        const size_t r = round0 - c->pt_log_round0;
+        q.log_pairs = c->pt_log_pairs.p + r * (size_t)nl * n_pairs * 2;
+        q.log_acc = c->pt_log_acc.p + r * (size_t)nl * n_pairs;
+    }
+    const bool timed = c->ev_accumulate;
+    hipEvent_t e0 = nullptr, e2 = nullptr;
+    if (timed) {
+        e0 = next_event(c);
+        hipEvent_t e1 = next_event(c);
+        e2 = next_event(c);
+        if (!e0 || !e1 || !e2) return fail(c, NLMC_ERR_HIP, "hipEventCreate failed");
+        tag_triple(c, 1);
+        HIP_TRY(c, hipEventRecord(e0, c->stream));
+    }
+    // the two argument structs travel through device memory (k_rounds_fused reads them through laundered constant-memory pointers);
+    // two slots, so that a launch still running never sees the next one's arguments
+    const size_t a_bytes = (sizeof(SweepArgs) + 255) & ~(size_t)255, slot_bytes = a_bytes + ((sizeof(RoundsArgs) + 255) & ~(size_t)255);
+    HIP_TRY(c, c->rounds_args.reserve(2 * slot_bytes));
+    const int as = c->rounds_args_slot ^= 1;
+    std::vector<unsigned char> &hb = c->rounds_args_host[as];
+    hb.assign(slot_bytes, 0);
+    std::memcpy(hb.data(), &a, sizeof(SweepArgs));
+    std::memcpy(hb.data() + a_bytes, &q, sizeof(RoundsArgs));
+    unsigned char *dargs = c->rounds_args.p + (size_t)as * slot_bytes;
+    HIP_TRY(c, hipMemcpyAsync(dargs, hb.data(), slot_bytes, hipMemcpyHostToDevice, c->stream));
+    const SweepArgs *ap_dev = reinterpret_cast<const SweepArgs *>(dargs);
+    const RoundsArgs *qp_dev = reinterpret_cast<const RoundsArgs *>(dargs + a_bytes);
+    void *kargs[] = {&ap_dev, &qp_dev};
+    HIP_TRY(c, hipLaunchCooperativeKernel(kfun, dim3(c->n_chains), dim3(nt), kargs, (unsigned)Lds.total, c->stream));
+    HIP_TRY(c, hipGetLastError());
+    if (timed) { HIP_TRY(c, hipEventRecord(e2, c->stream)); c->launches_timed += n_rounds; }
+    c->launches_sweep += n_rounds;
+    c->launches_total += n_rounds;
+    c->stat_fused_window = w0 + n_rounds - 1;
+    c->stat_fused_slot = fslot;
+    c->sub_dirty = true;
+    return NLMC_OK;
+}
+
 int nlmc_pt_log_begin(nlmc_ctx *c, uint32_t round0, int n_rounds, int n_pairs)
 {
     if (!c) return NLMC_ERR_ARG;
@@ -2138,6 +2260,7 @@ int nlmc_pt_check(nlmc_ctx *c)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (st != 0) {
         HIP_TRY(c, hipMemsetAsync(c->pt_status.p, 0, sizeof(int32_t), c->stream));
+        if (st == 3) return fail(c, NLMC_ERR_HIP, "nlmc_pt_rounds_fused: the workgroups of a launch lost each other (grid wait timed out); the chains' states are not valid");
         return fail(c, NLMC_ERR_ARG, "Cannot find non-overlapping pairs.");
     }
     return NLMC_OK;

@@ -1505,6 +1505,19 @@ __device__ __forceinline__ float4 thresholds4(const u32x4 &r)
 // slowest wave.  The state is a set of LOCAL variables of the function that runs the level loop (a struct handed
 // around by reference ended up in scratch memory: two global-memory round trips per level).
 struct FusedGenParams { uint32_t gc; int gtid, gnt, nblk, nj, Tn; };
+// What changes from one planned window to the next (everything else of a launch is in SweepArgs): k_sweep_fused runs one window,
+// k_rounds_fused a run of consecutive ones.
+struct FusedWin {
+    const int32_t *lvl_off;       // [nl + 1] chunk offsets of the levels
+    const int32_t *fsend;         // [T] last level of every sweep
+    const EdgeQ *ell;             // row-entry planes
+    const int2 *head;             // item heads
+    const int2 *warm_head;        // the NEXT window's arrays (or nullptr)
+    const EdgeQ *warm_ell;
+    int npos_next;
+    int nl, hi_max;
+    uint32_t sweep0;              // global index of the window's first sweep
+};
 #ifdef NLMC_DEBUG_KNOBS
 #define NLMC_GEN_DBG_OFF_COND (a.dbg_flags & 1)
 #define NLMC_GEN_DBG_PHILOX if (a.dbg_flags & 8) g_r = u32x4{(uint32_t)b * 2654435761u, (uint32_t)b ^ gp.gc, (uint32_t)g_u * 40503u + (uint32_t)b, ~(uint32_t)b}; else
@@ -1524,7 +1537,7 @@ struct FusedGenParams { uint32_t gc; int gtid, gnt, nblk, nj, Tn; };
         typedef const int32_t __attribute__((address_space(4))) *const_i32_;                                            \
         g_sidx = 0; g_acc = 0;                                                                                          \
         if (g_u < gp.Tn) {                                                                                              \
-            const const_i32_ send_ = (const_i32_)(uintptr_t)a.fsend;                                                    \
+            const const_i32_ send_ = (const_i32_)(uintptr_t)W.fsend;                                                    \
             g_w0 = g_u >= 3 ? __builtin_amdgcn_readfirstlane(send_[g_u - 3]) : -1;                                      \
             g_wend = __builtin_amdgcn_readfirstlane(send_[g_u - 2]);                                                    \
             g_wlen = max(1, g_wend - g_w0);              /* levels (w0, wend] are the production window of sweep u */   \
@@ -1536,7 +1549,7 @@ struct FusedGenParams { uint32_t gc; int gtid, gnt, nblk, nj, Tn; };
         const int b = gp.gtid + call_ * gp.gnt;                                                                         \
         if (ph_ == 0) {                                                                                                 \
             NLMC_GEN_DBG_PHILOX                                                                                         \
-            g_r = philox4x32_rounds(u32x4{(uint32_t)b, a.sweep0 + (uint32_t)g_u, gp.gc, NLMC_TAG_UNIFORM}, a.seed_lo, a.seed_hi, 0, 5); \
+            g_r = philox4x32_rounds(u32x4{(uint32_t)b, W.sweep0 + (uint32_t)g_u, gp.gc, NLMC_TAG_UNIFORM}, a.seed_lo, a.seed_hi, 0, 5); \
         } else if (g_f64) {                                                                                             \
             typedef nlmc_i2 __attribute__((address_space(3))) *lds_i2_;                                                 \
             g_r = philox4x32_rounds(g_r, a.seed_lo, a.seed_hi, 5, 5);                                                   \
@@ -1573,7 +1586,7 @@ struct FusedGenParams { uint32_t gc; int gtid, gnt, nblk, nj, Tn; };
 // that gives E after every sweep, the strict running minimum (first argmin, like np.argmin) and, from the snapshot,
 // the argmin / recorded states -- NMC/nmc.py:386-395 -- without giving up the overlap of consecutive sweeps.
 template <bool DIAG, bool FLAGS, bool PAIR, bool GEN, int FMT, bool OUT = false, bool F64 = false>
-__device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *lds_raw, int wv, int lane, int nl, float cq0,
+__device__ __forceinline__ void fused_levels(const SweepArgs &a, const FusedWin &W, unsigned char *lds_raw, int wv, int lane, int nl, float cq0,
                                              float cq1, long long &e_loc, const FusedGenParams gp)
 {
     constexpr bool g_f64 = F64;
@@ -1597,7 +1610,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
     // (wave-uniform 64-bit values are pinned into scalar registers: a uniform value in a vector register costs 64 lanes, a
     // spilled scalar one lane)
     if (OUT) {
-        o_end = ((const_i32o)(uintptr_t)a.fsend)[0];
+        o_end = ((const_i32o)(uintptr_t)W.fsend)[0];
         E_run = uniform64(a.efix[o_c]);
         E_min = a.emin ? uniform64(a.emin[o_c]) : 0x7FFFFFFFFFFFFFFFll;
         a_min = a.emin ? __builtin_amdgcn_readfirstlane(a.argmin[o_c]) : 0;
@@ -1615,13 +1628,13 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
     typedef const unsigned __attribute__((address_space(3))) *lds_u32;
     constexpr int NP = Item::NP, NE = Item::NE;
     const int plane_bytes = a.fz_pstride * 16;
-    const __amdgpu_buffer_rsrc_t r_ell = __builtin_amdgcn_make_buffer_rsrc(const_cast<EdgeQ *>(a.ell32), 0, (NLMC_FZ_W / 2) * plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_head = __builtin_amdgcn_make_buffer_rsrc(const_cast<int2 *>(a.head32), 0, a.fz_pstride * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_ell = __builtin_amdgcn_make_buffer_rsrc(const_cast<EdgeQ *>(W.ell), 0, (NLMC_FZ_W / 2) * plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_head = __builtin_amdgcn_make_buffer_rsrc(const_cast<int2 *>(W.head), 0, a.fz_pstride * 8, 0x00020000);
     // level offsets in chunks, read with SCALAR loads (uniform index): no VGPR, no VALU, no vector-memory slot
     // (constant address space: the plan is read-only while sweep kernels run, and a uniform index then gives s_load_dword;
     // a register-resident window of offsets picked with v_readlane measured slower)
     typedef const int32_t __attribute__((address_space(4))) *const_i32;
-    const const_i32 loffp = (const_i32)(uintptr_t)a.lvl_off;
+    const const_i32 loffp = (const_i32)(uintptr_t)W.lvl_off;
     auto lo = [&](int i) __attribute__((always_inline)) { return loffp[min(i, nl)]; };
     const int lane16 = lane * 16, oob = 0x7FF00000;        // oob: past both buffers (the hardware range check drops the load)
     typedef const int8_t __attribute__((address_space(3))) *lds_i8;
@@ -1728,8 +1741,8 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
                     typedef const int32_t __attribute__((address_space(4))) *const_i32s;
                     const unsigned tw_ = (unsigned)hx >> 16, np_ = (unsigned)a.g.n_pad;
                     int t_ = tw_ >= 3u * np_ ? 3 : tw_ >= 2u * np_ ? 2 : tw_ >= np_ ? 1 : 0;
-                    while (t_ + 3 < a.n_sweeps && lv > ((const_i32s)(uintptr_t)a.fsend)[t_]) t_ += 3;
-                    const u32x4 r_ = philox4x32_10(ka >> 1, a.sweep0 + (uint32_t)t_, gp.gc, NLMC_TAG_UNIFORM, a.seed_lo, a.seed_hi);
+                    while (t_ + 3 < a.n_sweeps && lv > ((const_i32s)(uintptr_t)W.fsend)[t_]) t_ += 3;
+                    const u32x4 r_ = philox4x32_10(ka >> 1, W.sweep0 + (uint32_t)t_, gp.gc, NLMC_TAG_UNIFORM, a.seed_lo, a.seed_hi);
                     const unsigned lo_ = ((ka & 1u) ? r_.w : r_.y) >> 6;
                     const unsigned kl = *(lds_u32)(uintptr_t)(kaddr + 4u * (unsigned)(2 * a.f64_xmax + 1));
                     up64 = hk < kh || (hk == kh && lo_ < kl);
@@ -1800,7 +1813,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
         e_loc = e_new; e_new = 0;                                                                                       \
         ++o_t;                                                                                                          \
         o_lo = (unsigned)((o_t % 3) * o_npad);                                                                          \
-        o_end = o_t < a.n_sweeps ? ((const_i32o)(uintptr_t)a.fsend)[o_t] : 0x7FFFFFFF;                                   \
+        o_end = o_t < a.n_sweeps ? ((const_i32o)(uintptr_t)W.fsend)[o_t] : 0x7FFFFFFF;                                   \
         cqo0 = cqn0; cqo1 = cqn1;                                                                                       \
         cqn0 = NLMC_OCQ(o_t + 1, 0); cqn1 = NLMC_OCQ(o_t + 1, 1);                                                       \
     }
@@ -1858,36 +1871,12 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, unsigned char *
 
 // FMT is a parameter of the KERNEL (round 3; it was a run-time switch over three inlined copies of every level-loop
 // variant: 12 copies per kernel, whose spilled scalars together took 19 vector registers of the per-sweep-output kernels)
-// F64: the fp64 mode (k_sweep_philox<double>) on the same windows, for instances whose couplings AND fields are exact multiples
-// of 2^-qs.  The fp64 field of the spec is then the exact integer X times 2^-qs whatever the order of the sum, z = cb x takes
-// one value per X, and the spec's test fma(u, 2^z, u) < 1 is a threshold on the 53-bit integer of u (accept_count_spec): the
-// update is the fixed-point one with `k_u < K[X]` in place of `z < W(r)`.  Same bits as the sweep-by-sweep fp64 kernel.
-template <bool DIAG, bool FLAGS, bool OUT, int FMT, bool F64 = false>
-__global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
+// ---- the pieces of a fused-window launch: state in, one window, state out ---------------------------------------------------
+template <bool FLAGS>
+__device__ __forceinline__ void fused_state_load(const SweepArgs &a, unsigned char *lds_raw, int c)
 {
-    constexpr bool g_f64 = F64;
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    if ((unsigned)reinterpret_cast<size_t>(lds_raw) != 0u) __builtin_trap();   // spins at LDS offset 0: column == address
-    const int n = a.g.n, n_pad = a.g.n_pad, tid = threadIdx.x, nt = blockDim.x;
-    const int c = a.chain_list ? a.chain_list[blockIdx.x] : (int)blockIdx.x;      // local chain id (state rows, RNG)
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    float *ur = reinterpret_cast<float *>(lds_raw + a.lds_u_off);
+    const int n_pad = a.g.n_pad, tid = threadIdx.x, nt = blockDim.x;
     long long *red = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);
-    const uint32_t gc_chain = (uint32_t)(a.chain_base + c);
-    const int row = a.slot_of_chain ? a.slot_of_chain[gc_chain] : c;
-    const uint32_t gc = (a.rng_stride && a.slot_of_chain) ? (uint32_t)((c / a.rng_ladder_len) * a.rng_stride + a.rng_base + row) : gc_chain;
-    const int Tn = a.n_sweeps;
-#ifdef NLMC_DEBUG_KNOBS
-    const int nl = (a.dbg_flags & 128) ? 0 : a.nlev[0];      // timing experiment: prologue + epilogue only
-#else
-    const int nl = a.nlev[0];
-#endif
-#ifdef NLMC_STAMPS
-    const long long st_begin = (long long)__builtin_readcyclecounter();
-#endif
-    // "f32" mode: z = cb * (X 2^-qs) with the int32 field X -> the exact power of two is folded into the coefficient
-    const float cq0 = (float)a.tab[(size_t)row * a.tab_cs] * a.qinv, cq1 = (float)a.tab[(size_t)row * a.tab_cs + 1] * a.qinv;
-
     // spins (+ the scratch spin of the dummy items behind them), phase flags
     {
         const int4 *src = reinterpret_cast<const int4 *>(a.spins + (size_t)c * n_pad);
@@ -1910,11 +1899,36 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
         }
         if (tid < 4) red[tid] = 0;
     }
+}
+
+// One planned window on the chain whose state sits in LDS: threshold tables of its first two sweeps (+ the fp64 mode's K tables at
+// the chain's temperature `row`), then the level loop.  Energy deltas of this thread come back in e_loc (plain variant).
+template <bool DIAG, bool FLAGS, bool OUT, int FMT, bool F64>
+__device__ __forceinline__ void fused_window(const SweepArgs &a, const FusedWin &W, unsigned char *lds_raw, int row, uint32_t gc, long long &e_loc)
+{
+    constexpr bool g_f64 = F64;
+    const int n = a.g.n, tid = threadIdx.x, nt = blockDim.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    float *ur = reinterpret_cast<float *>(lds_raw + a.lds_u_off);
+    const int Tn = a.n_sweeps;
+#ifdef NLMC_DEBUG_KNOBS
+    const int nl = (a.dbg_flags & 128) ? 0 : W.nl;      // timing experiment: prologue + epilogue only
+#else
+    const int nl = W.nl;
+#endif
+    // "f32" mode: z = cb * (X 2^-qs) with the int32 field X -> the exact power of two is folded into the coefficient
+    const float cq0 = (float)a.tab[(size_t)row * a.tab_cs] * a.qinv, cq1 = (float)a.tab[(size_t)row * a.tab_cs + 1] * a.qinv;
     // thresholds of the first two sweeps (the third table is produced inside the level loop like all later ones)
+#ifdef NLMC_DEBUG_KNOBS
+    // (timing experiments that switch the in-loop production off or down: every table holds valid words, so that stale entries
+    // do not send the fp64 mode into its exact path)
+    for (int t = 0; t < ((a.dbg_flags & (1 | 2048)) ? 3 : min(2, Tn)) NLMC_DBG_NOPROLOGUE; ++t) {
+#else
     for (int t = 0; t < min(2, Tn) NLMC_DBG_NOPROLOGUE; ++t) {
+#endif
         float *tab_t = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(ur) + (size_t)t * a.lds_u_stride);
-        if (F64) fill_uniform_words(reinterpret_cast<unsigned *>(tab_t), n, a.sweep0 + (uint32_t)t, gc, a.seed_lo, a.seed_hi, tid, nt);
-        else fill_uniforms(tab_t, n, a.sweep0 + (uint32_t)t, gc, a.seed_lo, a.seed_hi, tid, nt);
+        if (F64) fill_uniform_words(reinterpret_cast<unsigned *>(tab_t), n, W.sweep0 + (uint32_t)t, gc, a.seed_lo, a.seed_hi, tid, nt);
+        else fill_uniforms(tab_t, n, W.sweep0 + (uint32_t)t, gc, a.seed_lo, a.seed_hi, tid, nt);
     }
     if (F64) {
         // K(X) for every field value a row can reach, at this chain's temperature: z = cb (X 2^-qs) as in update_spin<double>.
@@ -1931,7 +1945,11 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
     }
     __syncthreads();
 
+#ifdef NLMC_DEBUG_KNOBS
+    const int g0 = a.f_gen0 * 64, nblk = (F64 && !(a.dbg_flags & 2048)) ? (n + 1) / 2 : (n + 3) / 4, gnt = nt - g0;   // 2048: timing experiment, half the Philox calls of the fp64 mode (wrong results)
+#else
     const int g0 = a.f_gen0 * 64, nblk = F64 ? (n + 1) / 2 : (n + 3) / 4, gnt = nt - g0;
+#endif
     // calls per sweep of THIS wave: block b = (tid - g0) + call * gnt must lie below nblk for at least one of its lanes
     // (wave-uniform; the waves at the end of the producing range do one call less when gnt does not divide nblk)
     const int gwave0 = __builtin_amdgcn_readfirstlane((tid - g0) & ~63);
@@ -1940,11 +1958,10 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
     // The producing waves are the youngest of their SIMDs and would get the issue slots the older worker waves leave
     // over (measured: a 150-instruction call stretched to ~3000 cycles while the workers waited at the barrier).
     if (is_gen && a.f_gen_prio) __builtin_amdgcn_s_setprio(2);
-    long long e_loc = 0;
     if (wv < a.f_workers) {
-        const bool role_long = wv < a.hi_max[0];           // chunks that may hold lane PAIRS (rows longer than 8 entries) come first
+        const bool role_long = wv < W.hi_max;           // chunks that may hold lane PAIRS (rows longer than 8 entries) come first
         const int variant = (role_long ? 2 : 0) + (is_gen ? 1 : 0);
-#define NLMC_FL(P, G) fused_levels<DIAG, FLAGS, P, G, FMT, OUT, F64>(a, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp)
+#define NLMC_FL(P, G) fused_levels<DIAG, FLAGS, P, G, FMT, OUT, F64>(a, W, lds_raw, wv, lane, nl, cq0, cq1, e_loc, gp)
         switch (variant) { case 0: NLMC_FL(false, false); break; case 1: NLMC_FL(false, true); break;
                            case 2: NLMC_FL(true, false); break; default: NLMC_FL(true, true); break; }
 #undef NLMC_FL
@@ -1958,9 +1975,9 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
         NLMC_GEN_STATE
         NLMC_GEN_ARM(a, gp)
         const int hid = tid - a.f_workers * 64, hcnt = nt - a.f_workers * 64;
-        const unsigned warm_lines = a.warm_head ? (unsigned)(((size_t)a.fz_npos_next * 8 + 127) / 128) : 0u;       // head
-        const unsigned warm_lines_p = a.warm_head ? (unsigned)(((size_t)a.fz_pstride * 16 + 127) / 128) : 0u;     // lines per plane
-        const unsigned warm_used_p = a.warm_head ? (unsigned)(((size_t)a.fz_npos_next * 16 + 127) / 128) : 0u;     // touched lines per plane
+        const unsigned warm_lines = W.warm_head ? (unsigned)(((size_t)W.npos_next * 8 + 127) / 128) : 0u;       // head
+        const unsigned warm_lines_p = W.warm_head ? (unsigned)(((size_t)a.fz_pstride * 16 + 127) / 128) : 0u;     // lines per plane
+        const unsigned warm_used_p = W.warm_head ? (unsigned)(((size_t)W.npos_next * 16 + 127) / 128) : 0u;     // touched lines per plane
         const unsigned warm_total = warm_lines + (FMT == NLMC_FMT_ADDR ? 1u : FMT == NLMC_FMT_COMPACT ? 2u : 4u) * warm_used_p;
         unsigned warm_at = (unsigned)blockIdx.x * (unsigned)hcnt + (unsigned)hid;
         const unsigned warm_step = gridDim.x * (unsigned)hcnt;
@@ -1970,11 +1987,11 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
         auto warm_addr = [&]() __attribute__((always_inline)) -> const unsigned * {
             // (always a load, so that the number of loads in flight is static: past the end, or with nothing to warm, the
             // lane re-reads a line of this window's own level offsets)
-            const char *p = reinterpret_cast<const char *>(a.lvl_off);
-            if (warm_at < warm_lines) p = reinterpret_cast<const char *>(a.warm_head) + (size_t)warm_at * 128;
+            const char *p = reinterpret_cast<const char *>(W.lvl_off);
+            if (warm_at < warm_lines) p = reinterpret_cast<const char *>(W.warm_head) + (size_t)warm_at * 128;
             else if (warm_at < warm_total) {
                 const unsigned r = warm_at - warm_lines, q = r / warm_used_p, i = r - q * warm_used_p;
-                p = reinterpret_cast<const char *>(a.warm_ell) + ((size_t)q * warm_lines_p + i) * 128;
+                p = reinterpret_cast<const char *>(W.warm_ell) + ((size_t)q * warm_lines_p + i) * 128;
             }
             warm_at = warm_at < warm_total ? warm_at + warm_step : warm_at;
             return reinterpret_cast<const unsigned *>(p);
@@ -2006,6 +2023,13 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
 #undef NLMC_WARM
     }
 
+}
+
+template <bool OUT>
+__device__ __forceinline__ void fused_state_store(const SweepArgs &a, unsigned char *lds_raw, int c, long long e_loc)
+{
+    const int n_pad = a.g.n_pad, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
+    long long *red = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);
     // energy of the final state, spins back to HBM
     {
         const long long w = OUT ? 0ll : wave_sum_i64(e_loc);
@@ -2020,9 +2044,193 @@ __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
             if (a.energy_sink) a.energy_sink[c] = (double)E * __longlong_as_double((long long)(1023 - a.escale) << 52);
         }
     }
+}
+
+// F64: the fp64 mode (k_sweep_philox<double>) on the same windows, for instances whose couplings AND fields are exact multiples
+// of 2^-qs.  The fp64 field of the spec is then the exact integer X times 2^-qs whatever the order of the sum, z = cb x takes
+// one value per X, and the spec's test fma(u, 2^z, u) < 1 is a threshold on the 53-bit integer of u (accept_count_spec): the
+// update is the fixed-point one with `k_u < K[X]` in place of `z < W(r)`.  Same bits as the sweep-by-sweep fp64 kernel.
+template <bool DIAG, bool FLAGS, bool OUT, int FMT, bool F64 = false>
+__global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    if ((unsigned)reinterpret_cast<size_t>(lds_raw) != 0u) __builtin_trap();   // spins at LDS offset 0: column == address
+    const int c = a.chain_list ? a.chain_list[blockIdx.x] : (int)blockIdx.x;      // local chain id (state rows, RNG)
+    const uint32_t gc_chain = (uint32_t)(a.chain_base + c);
+    const int row = a.slot_of_chain ? a.slot_of_chain[gc_chain] : c;
+    const uint32_t gc = (a.rng_stride && a.slot_of_chain) ? (uint32_t)((c / a.rng_ladder_len) * a.rng_stride + a.rng_base + row) : gc_chain;
 #ifdef NLMC_STAMPS
-    if (a.dbg && lane == 0) a.dbg[((size_t)blockIdx.x * 16 + wv) * 8 + 7] = (long long)__builtin_readcyclecounter() - st_begin;
+    const long long st_begin = (long long)__builtin_readcyclecounter();
 #endif
+    const FusedWin W{a.lvl_off, a.fsend, a.ell32, a.head32, a.warm_head, a.warm_ell, a.fz_npos_next, a.nlev[0], a.hi_max[0], a.sweep0};
+    fused_state_load<FLAGS>(a, lds_raw, c);
+    long long e_loc = 0;
+    fused_window<DIAG, FLAGS, OUT, FMT, F64>(a, W, lds_raw, row, gc, e_loc);
+    fused_state_store<OUT>(a, lds_raw, c, e_loc);
+#ifdef NLMC_STAMPS
+    if (a.dbg && (threadIdx.x & 63) == 0) a.dbg[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + 7] = (long long)__builtin_readcyclecounter() - st_begin;
+#endif
+}
+
+// ---- persistent rounds: sweeps AND replica exchange of many rounds in one launch --------------------------------------------
+// A context that owns whole ladders needs nothing from outside between two rounds: the chains stay in LDS, a round's swap
+// decision needs only the energies of the two chains of a pair.  k_rounds_fused runs n_rounds consecutive planned windows (one
+// window = the sweeps of one round) and, between them, the swap round of k_pt_swap -- same selection (planned), same Philox keys,
+// same arithmetic, same label exchange -- with ONE grid-wide arrive-and-wait per round: every chain publishes its tracked energy
+// (double-buffered by round parity), waits until all chains of the launch have, then the two chains of a selected pair each
+// evaluate the identical decision and each updates its OWN entries of the slot maps (chain_of_slot[new slot] is written by the
+// chain that moves there and read, before that, only by the same chain).  What a launch per round pays again and again -- kernel
+// launch, spins HBM -> LDS -> HBM, the swap kernel's launch -- is paid once per chunk of rounds.  Launched cooperatively (all
+// workgroups resident); the wait is bounded all the same (status 3 on a timeout, every workgroup leaves).  Bit-identical to
+// k_sweep_fused + k_pt_swap round by round.
+struct RoundsArgs {
+    int n_rounds, n_windows_avail;   // rounds of this launch; planned windows from the first one on (>= n_rounds: the one behind the last is warmed)
+    const int32_t *loff, *nlev, *himax, *send, *npos;      // plan arrays AT the first window; window r lies r strides further
+    const int2 *head;
+    const EdgeQ *ell;
+    int ladder_len, n_pairs, n_ladders;
+    uint32_t round0;
+    const int32_t *plan_pairs;       // [n_rounds][n_ladders][n_pairs][2] at round0
+    const double *beta;              // [ladder_len]
+    int32_t *slot_of_chain, *chain_of_slot;
+    double *ebuf;                    // [2][n_chains_global]
+    int32_t *log_pairs;              // [n_rounds][n_ladders][n_pairs][2] at round0, or nullptr
+    uint8_t *log_acc;
+    unsigned *bar;                   // arrival counter, zero at launch
+    int32_t *status;                 // sticky pt status: 3 = the grid wait timed out
+    long long timeout_ticks;         // of the 100 MHz wall clock
+};
+
+// (no static LDS in these kernels: the spins sit at LDS offset 0; `flag` is a word of the reduction scratch)
+// Everything the workgroups tell each other -- energies, slot maps, the counter -- is written and read by THREAD 0 with agent-scope
+// atomics (coherent across the XCDs' L2s by themselves): no fence.  A __threadfence() here would write back and INVALIDATE the L2
+// of every XCD once per wave and round -- and with it the window schedules every level streams from L2 (measured: 236 instead of
+// 117 us per round).
+__device__ __forceinline__ bool grid_arrive_and_wait(unsigned *bar, unsigned target, int32_t *status, long long t_end, volatile int *flag)
+{
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's published stores have been acknowledged
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int good = 1;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3 || (long long)wall_clock64() > t_end) {
+                __hip_atomic_store(status, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                good = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        *flag = good;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
+// The arguments come through POINTERS into constant memory, laundered once per round: as by-value kernel arguments the window
+// body's loop-invariant scalar loads were hoisted out of the loop over the rounds and kept alive across it (176 spilled scalars
+// instead of 31, a level loop ~15 % slower than the one-window kernel's); behind an opaque pointer they stay where they are used.
+typedef const SweepArgs __attribute__((address_space(4))) *sweep_args_cptr;
+typedef const RoundsArgs __attribute__((address_space(4))) *rounds_args_cptr;
+
+template <bool DIAG, int FMT, bool F64>
+__global__ __launch_bounds__(1024) void k_rounds_fused(const SweepArgs *ap_g, const RoundsArgs *qp_g)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    if ((unsigned)reinterpret_cast<size_t>(lds_raw) != 0u) __builtin_trap();
+    const sweep_args_cptr ap = (sweep_args_cptr)(uintptr_t)ap_g;
+    const rounds_args_cptr qp = (rounds_args_cptr)(uintptr_t)qp_g;
+    const int c = (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t gc = (uint32_t)(ap->chain_base + c);
+    const int L = qp->ladder_len, g = (int)gc / L;
+    const int n_rounds = qp->n_rounds;
+    long long *red = reinterpret_cast<long long *>(lds_raw + ap->lds_red_off);   // [3] energy sum; [0] (two ints) new slot | barrier flag
+    volatile int *sh = reinterpret_cast<volatile int *>(red);
+    const long long t_end = (long long)wall_clock64() + qp->timeout_ticks;
+    int slot = ap->slot_of_chain[gc];
+    {
+        const SweepArgs &a0 = *(const SweepArgs *)ap;
+        fused_state_load<false>(a0, lds_raw, c);
+    }
+    long long E = uniform64(ap->efix[c]);
+    for (int r = 0; r < n_rounds; ++r) {
+        sweep_args_cptr a_r = ap;
+        rounds_args_cptr q_r = qp;
+        asm volatile("" : "+s"(a_r), "+s"(q_r));                  // opaque per round: nothing of the body moves out of the loop
+        const SweepArgs &a = *(const SweepArgs *)a_r;
+        const RoundsArgs &q = *(const RoundsArgs *)q_r;
+        const size_t PS = (size_t)a.fz_pstride, G = (size_t)q.n_ladders * L;
+        const bool has_next = r + 1 < q.n_windows_avail && q.nlev[r + 1] > 0;
+        const FusedWin W{q.loff + (size_t)r * (NLMC_LCAP + 1), q.send + (size_t)r * a.n_sweeps, q.ell + (size_t)r * PS * NLMC_FZ_W, q.head + (size_t)r * PS,
+                         has_next ? q.head + (size_t)(r + 1) * PS : nullptr, has_next ? q.ell + (size_t)(r + 1) * PS * NLMC_FZ_W : nullptr,
+                         has_next ? q.npos[r + 1] : 0, q.nlev[r], q.himax[r], a.sweep0 + (uint32_t)(r * a.n_sweeps)};
+        const uint32_t gcr = a.rng_stride ? (uint32_t)((c / a.rng_ladder_len) * a.rng_stride + a.rng_base + slot) : gc;
+        long long e_loc = 0;
+        fused_window<DIAG, false, false, FMT, F64>(a, W, lds_raw, slot, gcr, e_loc);
+        {
+            const long long w = wave_sum_i64(e_loc);
+            if (lane == 0 && w != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&red[3]), (unsigned long long)w);
+            __syncthreads();
+            E += uniform64(red[3]);
+        }
+        const double Ed = (double)E * __longlong_as_double((long long)(1023 - a.escale) << 52);
+        double *eb = q.ebuf + (size_t)(r & 1) * G;
+        if (tid == 0) __hip_atomic_store(&eb[gc], Ed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef NLMC_DEBUG_KNOBS
+        const bool ok = (a.dbg_flags & 4096) ? true : grid_arrive_and_wait(q.bar, (unsigned)(r + 1) * gridDim.x, q.status, t_end, sh + 1);   // 4096: timing experiment, nobody waits (wrong results)
+#else
+        const bool ok = grid_arrive_and_wait(q.bar, (unsigned)(r + 1) * gridDim.x, q.status, t_end, sh + 1);
+#endif
+        if (tid == 0) { red[3] = 0; sh[0] = slot; }              // (everybody has read the sum; next added to a whole window from here)
+        if (!ok) break;
+#ifdef NLMC_DEBUG_KNOBS
+        if (wv == 0 && !(a.dbg_flags & 8192)) {      // 8192: timing experiment, no swap step
+#else
+        if (wv == 0) {
+#endif
+            // the pair this chain's slot belongs to in this round's selection, if any: one lane per selected pair
+            const int32_t *sel = q.plan_pairs + ((size_t)r * q.n_ladders + g) * q.n_pairs * 2;
+            int fp = -1, fi = 0;
+            for (int p0 = 0; p0 < q.n_pairs; p0 += 64) {
+                const int p = p0 + lane;
+                const int i = p < q.n_pairs ? sel[2 * p] : -5;
+                const unsigned long long m = __ballot(i == slot || i + 1 == slot);
+                if (m) { const int src = __ffsll((long long)m) - 1; fp = p0 + src; fi = __shfl(i, src, 64); break; }
+            }
+            if (fp >= 0 && lane == 0) {
+                const int i = fi, ps = slot == i ? i + 1 : i;
+                const int partner = __hip_atomic_load(&q.chain_of_slot[(size_t)g * L + ps], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double Ep = __hip_atomic_load(&eb[partner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double Ea = slot == i ? Ed : Ep, Eb = slot == i ? Ep : Ed;
+                const double dE = Eb - Ea, dB = q.beta[i + 1] - q.beta[i];
+                const u32x4 rr = philox4x32_10((uint32_t)fp, q.round0 + (uint32_t)r, (uint32_t)g, NLMC_TAG_SWAP, a.seed_lo, a.seed_hi);
+                const double u = uniform_from(rr, 0.0);
+                const double z = (dB * dE) * 1.4426950408889634;
+                const bool acc = u < exp2_spec(z);
+                if (slot == i && q.log_pairs) {                   // the chain on the lower slot keeps the round's log entry
+                    const size_t at = ((size_t)r * q.n_ladders + g) * q.n_pairs + fp;
+                    q.log_pairs[2 * at] = i; q.log_pairs[2 * at + 1] = i + 1;
+                    q.log_acc[at] = acc ? 1 : 0;
+                }
+                if (acc) {
+                    __hip_atomic_store(&q.slot_of_chain[gc], ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&q.chain_of_slot[(size_t)g * L + ps], (int)gc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sh[0] = ps;
+                }
+            }
+        }
+        __syncthreads();
+        slot = sh[0];
+    }
+    // state out: spins, tracked energy (the level loop's deltas are in E already)
+    {
+        const int n_pad = ap->g.n_pad, nt = blockDim.x;
+        __syncthreads();
+        int4 *dst = reinterpret_cast<int4 *>(ap->spins + (size_t)c * n_pad);
+        const int4 *src = reinterpret_cast<const int4 *>(lds_raw);
+        for (int i = tid; i < n_pad / 16; i += nt) dst[i] = src[i];
+        if (tid == 0) ap->efix[c] = E;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------

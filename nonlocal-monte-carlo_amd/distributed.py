@@ -143,6 +143,33 @@ class ShardedTempering:
         self.rounds_done += 1
         return log
 
+    def run_rounds(self, n_rounds, n_sweeps):
+        """`n_rounds` rounds of `n_sweeps` sweeps + one swap round each.  A context that owns whole ladders and needs no collective
+        runs a planned chunk of rounds per launch (k_rounds_fused: the chains stay in LDS between the rounds, one grid-wide meeting per
+        round; include/nlmc.h: nlmc_pt_rounds_fused) -- same bits as round() called n_rounds times, which is what everything else falls
+        back to."""
+        done = 0
+        pl = getattr(self, "_planner", None)
+        can = (pl is not None and self._lt is None and not self.collective and self.n_pairs > 0 and pl.window == n_sweeps == pl.S
+               and hasattr(self.eng, "pt_rounds_fused") and not getattr(self, "_persistent_refused", False))
+        while done < n_rounds:
+            ii = self.rounds_done - (self._planner_round0 if pl is not None else 0)
+            if can and 0 <= ii < pl.R:
+                if not (pl._fused_from <= ii < pl._fused_to):
+                    pl._plan(ii, True)                      # this chunk's schedules and pair selections (inside whatever is timed)
+                if pl._fused_from <= ii < pl._fused_to:
+                    k = min(pl._fused_to - ii, n_rounds - done)
+                    if self.eng.pt_rounds_fused(k, n_sweeps, self.seed, self.sweeps_done, self.rounds_done, self.n_pairs, precision=self.precision):
+                        self.sweeps_done += k * n_sweeps
+                        self.rounds_done += k
+                        done += k
+                        self.persistent_rounds = getattr(self, "persistent_rounds", 0) + k
+                        continue
+                    self._persistent_refused = True          # stop asking; the reason is in eng.rounds_fused_refusal
+                can = False
+            self.round(n_sweeps)
+            done += 1
+
     def gather_spins(self):
         """All chains' configurations on every rank (read-out only; not part of a round)."""
         loc = self.eng.get_spins()

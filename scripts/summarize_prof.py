@@ -14,7 +14,7 @@ import os
 import sys
 from collections import defaultdict
 
-KERNELS = ("k_sweep_fused", "k_sweep_philox")     # dominant kernel: the first of these that appears in the trace
+KERNELS = ("k_sweep_fused", "k_rounds_fused", "k_sweep_philox")     # dominant kernel: the first of these that appears in the trace
 
 
 def find(d, suffix):
