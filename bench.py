@@ -254,6 +254,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-leg", action="store_true", help="skip the fixed-point leg")
     ap.add_argument("--headline", choices=["f64", "f32"], default="f64", help=argparse.SUPPRESS)
+    ap.add_argument("--persistent", action="store_true", help="a planned chunk of rounds per launch (k_rounds_fused) instead of a launch per round")
     ap.add_argument("--workload", choices=["c4", "c5"], default="c4",
                     help="c4 (default, the headline): replica-sharded NPT; c5: APT + iso-cluster moves, 32 temperatures x 8 sub-replicas "
                          "per GPU, the temperature ladder cut into slot blocks over the GPUs (BASELINE config 5)")
@@ -343,15 +344,15 @@ def main():
         if wr:
             # (buffers for a full chunk are allocated here: memory allocation is not part of a round's work)
             st.plan(wr * S_SWAP, wr, chunk_rounds=chunk, lazy=True, reserve_rounds=chunk)
-            st.run_rounds(wr, S_SWAP)
+            st.run_rounds(wr, S_SWAP, persistent=a.persistent)
         tr = steps * ROUNDS_PER_STEP
         st.plan(tr * S_SWAP, tr, chunk_rounds=chunk, lazy=True)     # a fresh, EMPTY planner: nothing is built yet
         st.eng.timing_reset(True, every=EVENT_EVERY if fused else 1)
         sync()
         t0 = time.perf_counter()
-        # (one process, one ladder per context: a planned chunk of rounds per launch -- k_rounds_fused, the chains stay in LDS between
-        # the rounds; ranks that exchange energies over RCCL: one sweep launch + one swap launch per round)
-        st.run_rounds(tr, S_SWAP)
+        # one sweep launch + one swap launch per round (--persistent: a planned chunk of rounds per launch, k_rounds_fused -- same bits,
+        # and measured the same speed)
+        st.run_rounds(tr, S_SWAP, persistent=a.persistent)
         sync()
         dt = time.perf_counter() - t0
         tm = st.eng.timing_total()

@@ -1528,7 +1528,12 @@ struct FusedWin {
 #define NLMC_GEN_DBG_LOGIT
 #endif
 // (plain macros over local variables: with lambdas the captured state was kept in scratch memory)
-#define NLMC_GEN_STATE int g_u = 2, g_slot = 2, g_w0 = 0, g_wend = 0, g_wlen = 1, g_acc = 0, g_sidx = 0; u32x4 g_r{0u, 0u, 0u, 0u};
+/* (the launch constants the producer needs are read ONCE, up front: inside the level loop they sit behind conditions, and a load
+   through the persistent kernel's argument pointer is not hoisted out of a condition -- 27 instructions and a scalar-memory
+   wait per stage) */
+#define NLMC_GEN_STATE int g_u = 2, g_slot = 2, g_w0 = 0, g_wend = 0, g_wlen = 1, g_acc = 0, g_sidx = 0; u32x4 g_r{0u, 0u, 0u, 0u}; \
+    const uint32_t g_seed_lo = a.seed_lo, g_seed_hi = a.seed_hi, g_sweep0 = W.sweep0; const int g_u_off = a.lds_u_off, g_u_stride = a.lds_u_stride; \
+    const int32_t *const g_fsend = W.fsend;
 /* steps per call: Philox rounds 0-4 | rounds 5-9 | four logits + store  (fp64 mode: rounds 0-4 | rounds 5-9 + store of the two
    27-bit high words of the call's two uniforms -- one call serves 2 spins there, 4 here) */
 #define NLMC_GEN_NSTEP (g_f64 ? 2 : 3)
@@ -1537,7 +1542,7 @@ struct FusedWin {
         typedef const int32_t __attribute__((address_space(4))) *const_i32_;                                            \
         g_sidx = 0; g_acc = 0;                                                                                          \
         if (g_u < gp.Tn) {                                                                                              \
-            const const_i32_ send_ = (const_i32_)(uintptr_t)W.fsend;                                                    \
+            const const_i32_ send_ = (const_i32_)(uintptr_t)g_fsend;                                                    \
             g_w0 = g_u >= 3 ? __builtin_amdgcn_readfirstlane(send_[g_u - 3]) : -1;                                      \
             g_wend = __builtin_amdgcn_readfirstlane(send_[g_u - 2]);                                                    \
             g_wlen = max(1, g_wend - g_w0);              /* levels (w0, wend] are the production window of sweep u */   \
@@ -1549,17 +1554,17 @@ struct FusedWin {
         const int b = gp.gtid + call_ * gp.gnt;                                                                         \
         if (ph_ == 0) {                                                                                                 \
             NLMC_GEN_DBG_PHILOX                                                                                         \
-            g_r = philox4x32_rounds(u32x4{(uint32_t)b, W.sweep0 + (uint32_t)g_u, gp.gc, NLMC_TAG_UNIFORM}, a.seed_lo, a.seed_hi, 0, 5); \
+            g_r = philox4x32_rounds(u32x4{(uint32_t)b, g_sweep0 + (uint32_t)g_u, gp.gc, NLMC_TAG_UNIFORM}, g_seed_lo, g_seed_hi, 0, 5); \
         } else if (g_f64) {                                                                                             \
             typedef nlmc_i2 __attribute__((address_space(3))) *lds_i2_;                                                 \
-            g_r = philox4x32_rounds(g_r, a.seed_lo, a.seed_hi, 5, 5);                                                   \
-            if (b < gp.nblk) ((lds_i2_)(uintptr_t)(unsigned)(a.lds_u_off + g_slot * a.lds_u_stride))[b] = nlmc_i2{(int)(g_r.x >> 5), (int)(g_r.z >> 5)}; \
+            g_r = philox4x32_rounds(g_r, g_seed_lo, g_seed_hi, 5, 5);                                                   \
+            if (b < gp.nblk) ((lds_i2_)(uintptr_t)(unsigned)(g_u_off + g_slot * g_u_stride))[b] = nlmc_i2{(int)(g_r.x >> 5), (int)(g_r.z >> 5)}; \
         } else if (ph_ == 1) {                                                                                          \
             NLMC_GEN_DBG_PHILOX                                                                                         \
-            g_r = philox4x32_rounds(g_r, a.seed_lo, a.seed_hi, 5, 5);                                                   \
+            g_r = philox4x32_rounds(g_r, g_seed_lo, g_seed_hi, 5, 5);                                                   \
         } else if (b < gp.nblk) {                                                                                       \
             typedef nlmc_f4 __attribute__((address_space(3))) *lds_f4_;    /* LDS offsets, no generic pointers */         \
-            const lds_f4_ dst = (lds_f4_)(uintptr_t)(unsigned)(a.lds_u_off + g_slot * a.lds_u_stride);                  \
+            const lds_f4_ dst = (lds_f4_)(uintptr_t)(unsigned)(g_u_off + g_slot * g_u_stride);                  \
             NLMC_GEN_DBG_LOGIT                                                                                          \
             { const float4 t4 = thresholds4(g_r); dst[b] = nlmc_f4{t4.x, t4.y, t4.z, t4.w}; }                           \
         }                                                                                                               \
@@ -2139,56 +2144,69 @@ __global__ __launch_bounds__(1024) void k_rounds_fused(const SweepArgs *ap_g, co
     if ((unsigned)reinterpret_cast<size_t>(lds_raw) != 0u) __builtin_trap();
     const sweep_args_cptr ap = (sweep_args_cptr)(uintptr_t)ap_g;
     const rounds_args_cptr qp = (rounds_args_cptr)(uintptr_t)qp_g;
-    const int c = (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t gc = (uint32_t)(ap->chain_base + c);
-    const int L = qp->ladder_len, g = (int)gc / L;
-    const int n_rounds = qp->n_rounds;
-    long long *red = reinterpret_cast<long long *>(lds_raw + ap->lds_red_off);   // [3] energy sum; [0] (two ints) new slot | barrier flag
-    volatile int *sh = reinterpret_cast<volatile int *>(red);
-    const long long t_end = (long long)wall_clock64() + qp->timeout_ticks;
-    int slot = ap->slot_of_chain[gc];
+    // State that lives from round to round sits in LDS (reduction scratch: [0] = {slot, barrier flag}, [1] = tracked energy, [3] =
+    // energy sum of the round), NOT in registers: the level loop has no scalar register to spare (every value kept alive across it is
+    // one more spill or reload inside it).
     {
         const SweepArgs &a0 = *(const SweepArgs *)ap;
-        fused_state_load<false>(a0, lds_raw, c);
+        fused_state_load<false>(a0, lds_raw, (int)blockIdx.x);
+        long long *red0 = reinterpret_cast<long long *>(lds_raw + a0.lds_red_off);
+        if (threadIdx.x == 0) {
+            reinterpret_cast<volatile int *>(red0)[0] = a0.slot_of_chain[a0.chain_base + (int)blockIdx.x];
+            red0[1] = a0.efix[blockIdx.x];
+        }
+        __syncthreads();
     }
-    long long E = uniform64(ap->efix[c]);
+    const int n_rounds = qp->n_rounds;
     for (int r = 0; r < n_rounds; ++r) {
         sweep_args_cptr a_r = ap;
         rounds_args_cptr q_r = qp;
         asm volatile("" : "+s"(a_r), "+s"(q_r));                  // opaque per round: nothing of the body moves out of the loop
         const SweepArgs &a = *(const SweepArgs *)a_r;
         const RoundsArgs &q = *(const RoundsArgs *)q_r;
-        const size_t PS = (size_t)a.fz_pstride, G = (size_t)q.n_ladders * L;
-        const bool has_next = r + 1 < q.n_windows_avail && q.nlev[r + 1] > 0;
-        const FusedWin W{q.loff + (size_t)r * (NLMC_LCAP + 1), q.send + (size_t)r * a.n_sweeps, q.ell + (size_t)r * PS * NLMC_FZ_W, q.head + (size_t)r * PS,
-                         has_next ? q.head + (size_t)(r + 1) * PS : nullptr, has_next ? q.ell + (size_t)(r + 1) * PS * NLMC_FZ_W : nullptr,
-                         has_next ? q.npos[r + 1] : 0, q.nlev[r], q.himax[r], a.sweep0 + (uint32_t)(r * a.n_sweeps)};
-        const uint32_t gcr = a.rng_stride ? (uint32_t)((c / a.rng_ladder_len) * a.rng_stride + a.rng_base + slot) : gc;
-        long long e_loc = 0;
-        fused_window<DIAG, false, false, FMT, F64>(a, W, lds_raw, slot, gcr, e_loc);
+        long long *red = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);
+        volatile int *sh = reinterpret_cast<volatile int *>(red);
         {
+            const int c = (int)blockIdx.x, slot = sh[0];
+            const size_t PS = (size_t)a.fz_pstride;
+            const bool has_next = r + 1 < q.n_windows_avail && q.nlev[r + 1] > 0;
+            const FusedWin W{q.loff + (size_t)r * (NLMC_LCAP + 1), q.send + (size_t)r * a.n_sweeps, q.ell + (size_t)r * PS * NLMC_FZ_W, q.head + (size_t)r * PS,
+                             has_next ? q.head + (size_t)(r + 1) * PS : nullptr, has_next ? q.ell + (size_t)(r + 1) * PS * NLMC_FZ_W : nullptr,
+                             has_next ? q.npos[r + 1] : 0, q.nlev[r], q.himax[r], a.sweep0 + (uint32_t)(r * a.n_sweeps)};
+            const uint32_t gcr = a.rng_stride ? (uint32_t)((c / a.rng_ladder_len) * a.rng_stride + a.rng_base + slot) : (uint32_t)(a.chain_base + c);
+            long long e_loc = 0;
+            fused_window<DIAG, false, false, FMT, F64>(a, W, lds_raw, slot, gcr, e_loc);
             const long long w = wave_sum_i64(e_loc);
-            if (lane == 0 && w != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&red[3]), (unsigned long long)w);
+            if ((threadIdx.x & 63) == 0 && w != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&red[3]), (unsigned long long)w);
             __syncthreads();
-            E += uniform64(red[3]);
         }
-        const double Ed = (double)E * __longlong_as_double((long long)(1023 - a.escale) << 52);
+        // ---- the swap round: thread 0 publishes, everybody meets, wave 0 decides
+        const int tid = threadIdx.x, lane = tid & 63;
+        const uint32_t gc = (uint32_t)(a.chain_base + (int)blockIdx.x);
+        const int L = q.ladder_len, g = (int)gc / L;
+        const size_t G = (size_t)q.n_ladders * L;
         double *eb = q.ebuf + (size_t)(r & 1) * G;
-        if (tid == 0) __hip_atomic_store(&eb[gc], Ed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double Ed = 0.0;
+        if (tid < 64) {
+            const long long E = red[1] + red[3];
+            Ed = (double)E * __longlong_as_double((long long)(1023 - a.escale) << 52);
+            if (tid == 0) __hip_atomic_store(&eb[gc], Ed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const long long t_end = (long long)wall_clock64() + q.timeout_ticks;       // (bounded per round)
 #ifdef NLMC_DEBUG_KNOBS
         const bool ok = (a.dbg_flags & 4096) ? true : grid_arrive_and_wait(q.bar, (unsigned)(r + 1) * gridDim.x, q.status, t_end, sh + 1);   // 4096: timing experiment, nobody waits (wrong results)
 #else
         const bool ok = grid_arrive_and_wait(q.bar, (unsigned)(r + 1) * gridDim.x, q.status, t_end, sh + 1);
 #endif
-        if (tid == 0) { red[3] = 0; sh[0] = slot; }              // (everybody has read the sum; next added to a whole window from here)
+        if (tid == 0) { red[1] += red[3]; red[3] = 0; }          // (wave 0 has read both; the sum is next added to a whole window from here)
         if (!ok) break;
 #ifdef NLMC_DEBUG_KNOBS
-        if (wv == 0 && !(a.dbg_flags & 8192)) {      // 8192: timing experiment, no swap step
+        if (tid < 64 && !(a.dbg_flags & 8192)) {     // 8192: timing experiment, no swap step
 #else
-        if (wv == 0) {
+        if (tid < 64) {
 #endif
             // the pair this chain's slot belongs to in this round's selection, if any: one lane per selected pair
+            const int slot = sh[0];
             const int32_t *sel = q.plan_pairs + ((size_t)r * q.n_ladders + g) * q.n_pairs * 2;
             int fp = -1, fi = 0;
             for (int p0 = 0; p0 < q.n_pairs; p0 += 64) {
@@ -2220,16 +2238,16 @@ __global__ __launch_bounds__(1024) void k_rounds_fused(const SweepArgs *ap_g, co
             }
         }
         __syncthreads();
-        slot = sh[0];
     }
-    // state out: spins, tracked energy (the level loop's deltas are in E already)
+    // state out: spins, tracked energy
     {
-        const int n_pad = ap->g.n_pad, nt = blockDim.x;
+        const int n_pad = ap->g.n_pad, nt = blockDim.x, tid = threadIdx.x, c = (int)blockIdx.x;
+        const long long *red = reinterpret_cast<const long long *>(lds_raw + ap->lds_red_off);
         __syncthreads();
         int4 *dst = reinterpret_cast<int4 *>(ap->spins + (size_t)c * n_pad);
         const int4 *src = reinterpret_cast<const int4 *>(lds_raw);
         for (int i = tid; i < n_pad / 16; i += nt) dst[i] = src[i];
-        if (tid == 0) ap->efix[c] = E;
+        if (tid == 0) ap->efix[c] = red[1];
     }
 }
 

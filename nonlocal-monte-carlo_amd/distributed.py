@@ -143,14 +143,18 @@ class ShardedTempering:
         self.rounds_done += 1
         return log
 
-    def run_rounds(self, n_rounds, n_sweeps):
-        """`n_rounds` rounds of `n_sweeps` sweeps + one swap round each.  A context that owns whole ladders and needs no collective
-        runs a planned chunk of rounds per launch (k_rounds_fused: the chains stay in LDS between the rounds, one grid-wide meeting per
-        round; include/nlmc.h: nlmc_pt_rounds_fused) -- same bits as round() called n_rounds times, which is what everything else falls
-        back to."""
+    def run_rounds(self, n_rounds, n_sweeps, persistent=None):
+        """`n_rounds` rounds of `n_sweeps` sweeps + one swap round each.  `persistent` (default: the environment variable
+        NLMC_PERSISTENT): a context that owns whole ladders and needs no collective runs a planned chunk of rounds per launch
+        (k_rounds_fused: the chains stay in LDS between the rounds, one grid-wide meeting per round; include/nlmc.h:
+        nlmc_pt_rounds_fused) -- same bits as round() called n_rounds times, which is what everything else falls back to.  Off by
+        default: measured at the bench shape it costs what a launch per round costs (117.3 vs 117.6 us per round: what it saves in
+        launches and spin I/O the grid-wide meeting and the per-round bookkeeping take back)."""
         done = 0
         pl = getattr(self, "_planner", None)
-        can = (pl is not None and self._lt is None and not self.collective and self.n_pairs > 0 and pl.window == n_sweeps == pl.S
+        if persistent is None:
+            persistent = bool(os.environ.get("NLMC_PERSISTENT"))
+        can = (persistent and pl is not None and self._lt is None and not self.collective and self.n_pairs > 0 and pl.window == n_sweeps == pl.S
                and hasattr(self.eng, "pt_rounds_fused") and not getattr(self, "_persistent_refused", False))
         while done < n_rounds:
             ii = self.rounds_done - (self._planner_round0 if pl is not None else 0)

@@ -12,18 +12,12 @@ export NLMC_BENCH_ROUNDS_PER_STEP=512
 for LEG in f64 f32; do
   B="python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-second-leg --headline $LEG"
   timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_$LEG" -o s -- $B > "$OUT/stats_$LEG.log" 2>&1
-  cp "$OUT/stats_$LEG"/*/*kernel_stats.csv "$REPO/profiles/${TAG}_${LEG}_bench_n1_persistent_kernel_stats.csv" 2>/dev/null || cp "$OUT/stats_$LEG"/*kernel_stats.csv "$REPO/profiles/${TAG}_${LEG}_bench_n1_persistent_kernel_stats.csv" 2>/dev/null || true
-  # the counters (and the per-launch table the roofline objects quote) are those of the launch-per-round kernel k_sweep_fused: one
-  # launch = one round, the unit bench.py prices; the persistent kernel's stats of the default command are kept beside them
-  export NLMC_NO_PERSISTENT=1
-  timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_$LEG" -o s -- $B > "$OUT/stats_$LEG.log" 2>&1
   timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch_$LEG" -o f -- $B > "$OUT/fetch_$LEG.log" 2>&1
   timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d "$OUT/write_$LEG" -o w -- $B > "$OUT/write_$LEG.log" 2>&1
   timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d "$OUT/sq1_$LEG" -o q -- $B > "$OUT/sq1_$LEG.log" 2>&1
   timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -d "$OUT/sq2_$LEG" -o q -- $B > "$OUT/sq2_$LEG.log" 2>&1
   timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES -d "$OUT/sq3_$LEG" -o q -- $B > "$OUT/sq3_$LEG.log" 2>&1
   python3 "$REPO/scripts/summarize_prof.py" "$TAG" "$LEG" "$OUT/stats_$LEG" "$OUT/fetch_$LEG" "$OUT/write_$LEG" "$OUT/sq1_$LEG" "$OUT/sq2_$LEG" "$OUT/sq3_$LEG"
-  unset NLMC_NO_PERSISTENT
   echo "leg $LEG profiled"
 done
 unset NLMC_BENCH_ROUNDS_PER_STEP

@@ -104,7 +104,7 @@ def test_persistent_rounds_refusals_and_the_driver(product):
         st.set_spins(m0)
         st.plan(11 * T, 11, chunk_rounds=4, lazy=True)
         if persistent:
-            st.run_rounds(11, T)
+            st.run_rounds(11, T, persistent=True)
             assert st.persistent_rounds == 11
         else:
             for _ in range(11):
