@@ -116,7 +116,7 @@ int nlmc_sweep_stream(nlmc_ctx *ctx, int n_sweeps, const int32_t *perm, const do
 
 /* PHILOX mode (throughput): same Markov kernel, counter-based RNG generated on the device.  Sweep t of the run
  * (global index sweep0 + t) visits spins in ascending order of philox(k, t, group, ORDER) and spin k of chain c
- * draws one word of philox(k>>2, t, c, UNIFORM) (f32: 32 bits -> logistic threshold; k>>1 and two words -> 53-bit uniform in f64); results are a pure function of (seed, global chain id, sweep index, spin) and
+ * draws one word of philox(k>>2, t, c, UNIFORM) (f32: 32 bits -> logistic threshold; f64: its high 27 bits + the high 26 bits of the same word of philox(k>>2, t, c, UNIFORM_LO) -> 53-bit uniform); results are a pure function of (seed, global chain id, sweep index, spin) and
  * therefore independent of how chains are sharded over GPUs.
  *   beta : as above, or NULL to take each chain's beta from the PT ladder (nlmc_pt_init). */
 int nlmc_sweep_philox(nlmc_ctx *ctx, int precision, int order_mode, int n_sweeps, uint32_t sweep0, uint64_t seed,

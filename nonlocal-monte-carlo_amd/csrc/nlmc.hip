@@ -767,7 +767,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
     int cur = c->n_pad * (c->has_flags ? 2 : 1);
     cur = (cur + 15) / 16 * 16;
     const int lds_u_off = cur;
-    const int u_bytes = stream_mode ? 0 : ((f64 ? ((n + 1) / 2 * 2) * 8 : ((n + 3) / 4 * 4) * 4) + 15) / 16 * 16;
+    const int u_bytes = stream_mode ? 0 : ((f64 ? ((n + 3) / 4 * 4) * 8 : ((n + 3) / 4 * 4) * 4) + 15) / 16 * 16;
     // second copy of the per-sweep uniforms / level offsets when it fits: lets the idle waves prepare sweep t+1 while
     // wave 0 runs the narrow tail of sweep t
     const bool dbuf = !stream_mode && (size_t)cur + 2 * (size_t)u_bytes + 2 * NLMC_LCAP * 4 + 32 <= (size_t)150 * 1024 &&

@@ -10,6 +10,7 @@
 #define NLMC_TAG_SWAP 3u
 #define NLMC_TAG_PAIR 4u
 #define NLMC_TAG_ICM 5u
+#define NLMC_TAG_UNIFORM_LO 7u        // (6: the Houdayer pairing keys, csrc/nlmc_pt_icm.h)
 
 struct u32x4 { uint32_t x, y, z, w; };
 
@@ -114,8 +115,17 @@ __device__ __forceinline__ double uniform_from(const u32x4 &r, double)
 // heat-bath acceptance of s=+1 in the fp64 mode:  u < 1/(1+2^z)  <=>  fma(u, 2^z, u) < 1,   z = -2 log2(e) beta x
 __device__ __forceinline__ bool accept_up(double u, double z) { return __fma_rn(u, exp2_spec(z), u) < 1.0; }
 
+// The 53-bit uniform of spin k in the fp64 mode (round 4): the 27 high bits come from word k & 3 of the call (k >> 2, sweep, chain,
+// UNIFORM) -- the call the "f32" mode takes its 32 random bits from --, the 26 low bits from the same word of the call with the tag
+// UNIFORM_LO.  High and low half are separate calls because the fused-window kernel decides an update from the high bits alone
+// (2^-27 of the updates excepted): it then makes ONE call per four spins instead of one per two.
+__device__ __forceinline__ double uniform53_spec(uint32_t hi_word, uint32_t lo_word)
+{
+    return ((double)(hi_word >> 5) * 67108864.0 + (double)(lo_word >> 6)) / 9007199254740992.0;
+}
+
 // The same test as an integer threshold (fused windows of the fp64 mode).  u = k 2^-53 with the 53-bit integer
-// k = (x >> 5) << 26 | (y >> 6) of uniform_from; for a fixed E = 2^z > 0 the correctly rounded fma(u, E, u) is monotone
+// k = (hi >> 5) << 26 | (lo >> 6) of uniform53_spec; for a fixed E = 2^z > 0 the correctly rounded fma(u, E, u) is monotone
 // non-decreasing in u, so  { k : fma(k 2^-53, E, k 2^-53) < 1 }  is an initial segment [0, K) and accept_up(u, z) <=> k < K.
 // K in [1, 2^53] is found by bisection on the test itself (bracketed by an estimate first: a handful of steps instead
 // of 53) -- no second arithmetic, the same bits as accept_up by construction.

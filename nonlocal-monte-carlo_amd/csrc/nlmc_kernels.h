@@ -1176,9 +1176,9 @@ __device__ __forceinline__ void update_spin_q(const SweepArgs &a, ChainCtx &x, c
 
 __device__ __forceinline__ float4 thresholds4(const u32x4 &r);
 
-// uniforms of one sweep for every spin of this chain -> LDS.  One Philox4x32-10 call serves 4 (f32) / 2 (f64) spins:
+// uniforms of one sweep for every spin of this chain -> LDS.  One block of 4 spins = one Philox4x32-10 call (f32) / two (f64):
 //   f32: W(k) = threshold_spec(word (k & 3) of philox(k >> 2, t, chain, UNIFORM))
-//   f64: u(k) = 53 bits from words (2(k&1), 2(k&1)+1) of philox(k >> 1, t, chain, UNIFORM)
+//   f64: u(k) = uniform53_spec(word (k & 3) of philox(k >> 2, t, chain, UNIFORM), word (k & 3) of philox(k >> 2, t, chain, UNIFORM_LO))
 __device__ __forceinline__ void fill_uniforms(float *ur, int n, uint32_t tt, uint32_t gc, uint32_t k0, uint32_t k1, int tid, int nt)
 {
     const int nblk = (n + 3) / 4;                    // "f32" mode: the table holds the logistic thresholds W(r)
@@ -1191,25 +1191,28 @@ __device__ __forceinline__ void fill_uniforms(float *ur, int n, uint32_t tt, uin
 }
 __device__ __forceinline__ void fill_uniforms(double *ur, int n, uint32_t tt, uint32_t gc, uint32_t k0, uint32_t k1, int tid, int nt)
 {
-    for (int b = tid; b < (n + 1) / 2; b += nt) {
+    for (int b = tid; b < (n + 3) / 4; b += nt) {
         const u32x4 r = philox4x32_10((uint32_t)b, tt, gc, NLMC_TAG_UNIFORM, k0, k1);
-        double2 v;
-        v.x = ((double)(r.x >> 5) * 67108864.0 + (double)(r.y >> 6)) / 9007199254740992.0;
-        v.y = ((double)(r.z >> 5) * 67108864.0 + (double)(r.w >> 6)) / 9007199254740992.0;
-        reinterpret_cast<double2 *>(ur)[b] = v;    // ur has (n+1)/2*2 entries
+        const u32x4 q = philox4x32_10((uint32_t)b, tt, gc, NLMC_TAG_UNIFORM_LO, k0, k1);
+        double2 v0, v1;
+        v0.x = uniform53_spec(r.x, q.x); v0.y = uniform53_spec(r.y, q.y);
+        v1.x = uniform53_spec(r.z, q.z); v1.y = uniform53_spec(r.w, q.w);
+        reinterpret_cast<double2 *>(ur)[2 * b] = v0;    // ur has (n+3)/4*4 entries
+        reinterpret_cast<double2 *>(ur)[2 * b + 1] = v1;
     }
 }
 
-// fused fp64 windows: the table of a sweep holds the 27 HIGH bits of every spin's 53-bit uniform (word 2 (k & 1) of the call
-// k >> 1, shifted); the 26 low bits are made again in the rare update whose high bits do not decide (k_sweep_fused<.., F64>)
+// fused fp64 windows: the table of a sweep holds the 27 HIGH bits of every spin's 53-bit uniform (word k & 3 of the UNIFORM call
+// k >> 2, shifted: one call per four spins); the 26 low bits (UNIFORM_LO call) are made only in the rare update whose high bits do
+// not decide (k_sweep_fused<.., F64>)
 __device__ __forceinline__ void fill_uniform_words(unsigned *tab, int n, uint32_t tt, uint32_t gc, uint32_t k0, uint32_t k1, int tid, int nt)
 {
-    const int nblk = (n + 1) / 2;
+    const int nblk = (n + 3) / 4;
     for (int b = tid; b < nblk; b += 2 * nt) {
         u32x4 r0, r1;
         philox4x32_10_x2((uint32_t)b, (uint32_t)(b + nt), tt, gc, NLMC_TAG_UNIFORM, k0, k1, r0, r1);
-        reinterpret_cast<uint2 *>(tab)[b] = make_uint2(r0.x >> 5, r0.z >> 5);
-        if (b + nt < nblk) reinterpret_cast<uint2 *>(tab)[b + nt] = make_uint2(r1.x >> 5, r1.z >> 5);
+        reinterpret_cast<uint4 *>(tab)[b] = make_uint4(r0.x >> 5, r0.y >> 5, r0.z >> 5, r0.w >> 5);
+        if (b + nt < nblk) reinterpret_cast<uint4 *>(tab)[b + nt] = make_uint4(r1.x >> 5, r1.y >> 5, r1.z >> 5, r1.w >> 5);
     }
 }
 
@@ -1534,8 +1537,8 @@ struct FusedWin {
 #define NLMC_GEN_STATE int g_u = 2, g_slot = 2, g_w0 = 0, g_wend = 0, g_wlen = 1, g_acc = 0, g_sidx = 0; u32x4 g_r{0u, 0u, 0u, 0u}; \
     const uint32_t g_seed_lo = a.seed_lo, g_seed_hi = a.seed_hi, g_sweep0 = W.sweep0; const int g_u_off = a.lds_u_off, g_u_stride = a.lds_u_stride; \
     const int32_t *const g_fsend = W.fsend;
-/* steps per call: Philox rounds 0-4 | rounds 5-9 | four logits + store  (fp64 mode: rounds 0-4 | rounds 5-9 + store of the two
-   27-bit high words of the call's two uniforms -- one call serves 2 spins there, 4 here) */
+/* steps per call: Philox rounds 0-4 | rounds 5-9 | four logits + store  (fp64 mode: rounds 0-4 | rounds 5-9 + store of the four
+   27-bit high words: one call serves 4 spins in both modes, the fp64 mode has no logit to evaluate) */
 #define NLMC_GEN_NSTEP (g_f64 ? 2 : 3)
 #define NLMC_GEN_ARM(a, gp)                                                                                             \
     {                                                                                                                   \
@@ -1556,9 +1559,9 @@ struct FusedWin {
             NLMC_GEN_DBG_PHILOX                                                                                         \
             g_r = philox4x32_rounds(u32x4{(uint32_t)b, g_sweep0 + (uint32_t)g_u, gp.gc, NLMC_TAG_UNIFORM}, g_seed_lo, g_seed_hi, 0, 5); \
         } else if (g_f64) {                                                                                             \
-            typedef nlmc_i2 __attribute__((address_space(3))) *lds_i2_;                                                 \
+            typedef nlmc_i4 __attribute__((address_space(3))) *lds_i4_;                                                 \
             g_r = philox4x32_rounds(g_r, g_seed_lo, g_seed_hi, 5, 5);                                                   \
-            if (b < gp.nblk) ((lds_i2_)(uintptr_t)(unsigned)(g_u_off + g_slot * g_u_stride))[b] = nlmc_i2{(int)(g_r.x >> 5), (int)(g_r.z >> 5)}; \
+            if (b < gp.nblk) ((lds_i4_)(uintptr_t)(unsigned)(g_u_off + g_slot * g_u_stride))[b] = nlmc_i4{(int)(g_r.x >> 5), (int)(g_r.y >> 5), (int)(g_r.z >> 5), (int)(g_r.w >> 5)}; \
         } else if (ph_ == 1) {                                                                                          \
             NLMC_GEN_DBG_PHILOX                                                                                         \
             g_r = philox4x32_rounds(g_r, g_seed_lo, g_seed_hi, 5, 5);                                                   \
@@ -1747,8 +1750,9 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, const FusedWin 
                     const unsigned tw_ = (unsigned)hx >> 16, np_ = (unsigned)a.g.n_pad;
                     int t_ = tw_ >= 3u * np_ ? 3 : tw_ >= 2u * np_ ? 2 : tw_ >= np_ ? 1 : 0;
                     while (t_ + 3 < a.n_sweeps && lv > ((const_i32s)(uintptr_t)W.fsend)[t_]) t_ += 3;
-                    const u32x4 r_ = philox4x32_10(ka >> 1, W.sweep0 + (uint32_t)t_, gp.gc, NLMC_TAG_UNIFORM, a.seed_lo, a.seed_hi);
-                    const unsigned lo_ = ((ka & 1u) ? r_.w : r_.y) >> 6;
+                    const u32x4 r_ = philox4x32_10(ka >> 2, W.sweep0 + (uint32_t)t_, gp.gc, NLMC_TAG_UNIFORM_LO, a.seed_lo, a.seed_hi);
+                    const unsigned lw_ = (ka & 2u) ? ((ka & 1u) ? r_.w : r_.z) : ((ka & 1u) ? r_.y : r_.x);
+                    const unsigned lo_ = lw_ >> 6;
                     const unsigned kl = *(lds_u32)(uintptr_t)(kaddr + 4u * (unsigned)(2 * a.f64_xmax + 1));
                     up64 = hk < kh || (hk == kh && lo_ < kl);
                 }
@@ -1927,7 +1931,7 @@ __device__ __forceinline__ void fused_window(const SweepArgs &a, const FusedWin 
 #ifdef NLMC_DEBUG_KNOBS
     // (timing experiments that switch the in-loop production off or down: every table holds valid words, so that stale entries
     // do not send the fp64 mode into its exact path)
-    for (int t = 0; t < ((a.dbg_flags & (1 | 2048)) ? 3 : min(2, Tn)) NLMC_DBG_NOPROLOGUE; ++t) {
+    for (int t = 0; t < ((a.dbg_flags & 1) ? 3 : min(2, Tn)) NLMC_DBG_NOPROLOGUE; ++t) {
 #else
     for (int t = 0; t < min(2, Tn) NLMC_DBG_NOPROLOGUE; ++t) {
 #endif
@@ -1950,11 +1954,7 @@ __device__ __forceinline__ void fused_window(const SweepArgs &a, const FusedWin 
     }
     __syncthreads();
 
-#ifdef NLMC_DEBUG_KNOBS
-    const int g0 = a.f_gen0 * 64, nblk = (F64 && !(a.dbg_flags & 2048)) ? (n + 1) / 2 : (n + 3) / 4, gnt = nt - g0;   // 2048: timing experiment, half the Philox calls of the fp64 mode (wrong results)
-#else
-    const int g0 = a.f_gen0 * 64, nblk = F64 ? (n + 1) / 2 : (n + 3) / 4, gnt = nt - g0;
-#endif
+    const int g0 = a.f_gen0 * 64, nblk = (n + 3) / 4, gnt = nt - g0;
     // calls per sweep of THIS wave: block b = (tid - g0) + call * gnt must lie below nblk for at least one of its lanes
     // (wave-uniform; the waves at the end of the producing range do one call less when gnt does not divide nblk)
     const int gwave0 = __builtin_amdgcn_readfirstlane((tid - g0) & ~63);

@@ -133,6 +133,7 @@ void nlo_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
 
 /* Stream tags (counter word 3).  Must match nonlocal-monte-carlo_amd/csrc/nlmc_device.h */
 #define NLMC_TAG_UNIFORM 1u
+#define NLMC_TAG_UNIFORM_LO 7u
 #define NLMC_TAG_ORDER 2u
 #define NLMC_TAG_SWAP 3u
 #define NLMC_TAG_PAIR 4u
@@ -346,8 +347,11 @@ int nlo_sweeps_philox(int n, const int32_t *rowptr, const int32_t *col, const do
             const int k = ord[i].idx;
             const unsigned fl = flags ? flags[k] : 0u;
             if (fl >= 2u) continue;
-            /* one Philox call serves 4 (f32) / 2 (f64) consecutive spins */
-            philox4x32_10((uint32_t)(use_f64 ? (k >> 1) : (k >> 2)), tt, chain_id, NLMC_TAG_UNIFORM, seed_lo, seed_hi, r);
+            /* one Philox call serves 4 consecutive spins; the fp64 mode takes the 26 low bits of its 53-bit uniform from the same
+             * word of a second call (tag UNIFORM_LO) */
+            uint32_t r2[4] = {0u, 0u, 0u, 0u};
+            philox4x32_10((uint32_t)(k >> 2), tt, chain_id, NLMC_TAG_UNIFORM, seed_lo, seed_hi, r);
+            if (use_f64) philox4x32_10((uint32_t)(k >> 2), tt, chain_id, NLMC_TAG_UNIFORM_LO, seed_lo, seed_hi, r2);
             int accept;
             double xd = 0.0;
             int32_t Xq = 0;
@@ -360,8 +364,7 @@ int nlo_sweeps_philox(int n, const int32_t *rowptr, const int32_t *col, const do
                 }
                 xd = (x - xdg) + h[k];
                 x = x + h[k];
-                const int w0 = 2 * (k & 1);
-                const double u = ((double)(r[w0] >> 5) * 67108864.0 + (double)(r[w0 + 1] >> 6)) / 9007199254740992.0;
+                const double u = ((double)(r[k & 3] >> 5) * 67108864.0 + (double)(r2[k & 3] >> 6)) / 9007199254740992.0;
                 const double z = cb_run[2 * t + (fl == 1u)] * x;
                 const double ee = exp2_spec_f64(z);
                 accept = fma(u, ee, u) < 1.0;

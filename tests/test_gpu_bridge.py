@@ -30,12 +30,13 @@ def philox_stream(n, R, S, seed, f64, sweep0=0):
         perm[t] = np.lexsort((np.arange(n), keys))
         for c in range(R):
             if f64:
-                for b in range((n + 1) // 2):
+                for b in range((n + 3) // 4):          # high 27 bits: the UNIFORM call; low 26 bits: the same word of the UNIFORM_LO call (tag 7)
                     r = oracle.philox(b, sweep0 + t, c, TAG_UNIFORM, lo, hi).astype(np.uint64)
-                    for j in range(2):
-                        k = 2 * b + j
+                    q = oracle.philox(b, sweep0 + t, c, 7, lo, hi).astype(np.uint64)
+                    for j in range(4):
+                        k = 4 * b + j
                         if k < n:
-                            u_spin[c, t, k] = (float(r[2 * j] >> np.uint64(5)) * 67108864.0 + float(r[2 * j + 1] >> np.uint64(6))) / 9007199254740992.0
+                            u_spin[c, t, k] = (float(r[j] >> np.uint64(5)) * 67108864.0 + float(q[j] >> np.uint64(6))) / 9007199254740992.0
             else:
                 for b in range((n + 3) // 4):
                     r = oracle.philox(b, sweep0 + t, c, TAG_UNIFORM, lo, hi)

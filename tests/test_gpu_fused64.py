@@ -81,9 +81,11 @@ def test_fused_f64_equals_plain_f64_and_the_oracle_pmj(product):
     assert max(f["lv"]) < min(p["lv"])                              # the fused kernel really ran (fewer levels per sweep)
     assert np.array_equal(f["spins"], p["spins"]) and np.array_equal(f["E"], p["E"])
     check_oracle(J, h, m0, betas, (0, 3, R - 1), f, T * W)
-    # the two arithmetic modes are different chains (32-bit logistic thresholds vs 53-bit uniforms)
+    # (since round 4 the two arithmetic modes draw an update's decision from the SAME Philox word -- the "f32" mode all 32 bits through
+    # its logistic threshold, the fp64 mode its 27 high bits, and 26 more from a second call when they do not decide: the two chains
+    # differ only where a uniform falls within ~2^-24 of the acceptance probability, which 7 x 10^5 updates need not contain)
     q = run(product, inst, R, T, W, betas, True, precision="f32", m0=m0)
-    assert not np.array_equal(q["spins"], f["spins"])
+    assert np.mean(q["spins"] != f["spins"]) < 0.01
 
 
 @pytest.mark.parametrize("case", ["integer_hubs", "diag_fields", "pmj_hubs_swaps"])
