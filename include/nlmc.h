@@ -298,7 +298,13 @@ int nlmc_overlap_subsets(nlmc_ctx *ctx, int on);
 int nlmc_own_stream(nlmc_ctx *ctx);
 int nlmc_subset_count(const nlmc_ctx *ctx);
 int nlmc_get_subset(nlmc_ctx *ctx, int32_t *out_chains /*[nlmc_subset_count] local chain ids*/);
+/* on = 0: off; 1: the running minimum looks at every sweep of a call; k > 1: at sweeps 0, k, 2k, ... only -- the reference takes its
+ * argmin over the recorded columns M[:, ::M_skip] (NMC/nmc.py:390-395 == NPT/npt.py:434-437). */
 int nlmc_track_minimum(nlmc_ctx *ctx, int on);
+/* mode 1: copy the chains' CURRENT configurations aside; later nlmc_backbone_clusters calls are seeded with that copy instead of the
+ * states they find (the m_star of a cycle without a plain phase is the state after the last plain phase, NMC/nmc.py:368-373,433:
+ * full_update_frequency != 1).  mode 0: seed with the current states again. */
+int nlmc_backbone_seed(nlmc_ctx *ctx, int mode);
 int nlmc_adopt_best(nlmc_ctx *ctx);
 int nlmc_backbone_clusters(nlmc_ctx *ctx, const double *epsilon /*[n]*/, const double *lambdas, int n_lambdas, double beta,
                            double tolerance, int max_iterations, double sat, const double *thresholds, int n_thresholds);

@@ -29,7 +29,7 @@ EXPORTS = [
     "nlmc_pt_apply_swap", "nlmc_pt_swap_philox", "nlmc_pt_plan", "nlmc_pt_rounds_fused", "nlmc_pt_check", "nlmc_pt_swap_philox_host", "nlmc_pt_log_begin", "nlmc_pt_log_read", "nlmc_icm_components", "nlmc_icm_move", "nlmc_icm_get_labels", "nlmc_icm_round_philox", "nlmc_icm_round_ladders",
     "nlmc_lbp_convexified", "nlmc_find_clusters", "nlmc_trace_layout", "nlmc_energy_of_recorded",
     "nlmc_last_timing", "nlmc_timing_reset", "nlmc_timing_total", "nlmc_last_schedule_stats",
-    "nlmc_pt_mark_slots", "nlmc_select_chains", "nlmc_subset_count", "nlmc_get_subset", "nlmc_track_minimum", "nlmc_adopt_best",
+    "nlmc_pt_mark_slots", "nlmc_select_chains", "nlmc_subset_count", "nlmc_get_subset", "nlmc_track_minimum", "nlmc_backbone_seed", "nlmc_adopt_best",
     "nlmc_backbone_clusters", "nlmc_backbone_check", "nlmc_get_cluster_mask", "nlmc_set_phase", "nlmc_plan_slot", "nlmc_overlap_subsets", "nlmc_own_stream", "nlmc_plan_get_levels", "nlmc_probe_level_round", "nlmc_comm_unique_id", "nlmc_comm_init", "nlmc_comm_probe", "nlmc_comm_check", "nlmc_apt_shard", "nlmc_apt_pack", "nlmc_apt_swap_host", "nlmc_apt_swap_collective", "nlmc_pt_swap_philox_collective", "nlmc_set_cluster_mask", "nlmc_host_prefault",
 ]
 
@@ -150,7 +150,7 @@ def lib():
     L.nlmc_last_schedule_stats.restype = _i
     L.nlmc_last_schedule_stats.argtypes = [_vp, _vp, _vp]
     for name, args in (("nlmc_pt_mark_slots", [_vp, _vp]), ("nlmc_select_chains", [_vp, _i]), ("nlmc_subset_count", [_vp]),
-                       ("nlmc_get_subset", [_vp, _vp]), ("nlmc_track_minimum", [_vp, _i]), ("nlmc_adopt_best", [_vp]),
+                       ("nlmc_get_subset", [_vp, _vp]), ("nlmc_track_minimum", [_vp, _i]), ("nlmc_backbone_seed", [_vp, _i]), ("nlmc_adopt_best", [_vp]),
                        ("nlmc_backbone_clusters", [_vp, _vp, _vp, _i, _dbl, _dbl, _i, _dbl, _vp, _i]),
                        ("nlmc_backbone_check", [_vp]), ("nlmc_get_cluster_mask", [_vp, _vp]), ("nlmc_set_cluster_mask", [_vp, _vp]), ("nlmc_set_phase", [_vp, _i, _dbl]),
                        ("nlmc_plan_slot", [_vp, _i]), ("nlmc_overlap_subsets", [_vp, _i]), ("nlmc_own_stream", [_vp]),

@@ -115,6 +115,9 @@ struct nlmc_ctx {
     int sub_count() const { return subset == 0 ? n_chains : subset == 1 ? n_chains - n_marked_local : n_marked_local; }
     const int32_t *sub_list() const { return subset == 0 ? nullptr : subset == 1 ? sub_list_buf.p : sub_list_buf.p + (n_chains - n_marked_local); }
     bool track_min = false;       // sweep calls keep running minimum + argmin state on the device (nlmc_track_minimum)
+    int track_min_stride = 1;     // ... over the sweeps 0, stride, 2 stride, ... of a call (the reference's M[:, ::M_skip])
+    DevBuf<int8_t> seed_snap;     // nlmc_backbone_seed: the configurations later backbone inferences are seeded with
+    bool seed_snap_on = false;
     DevBuf<uint8_t> cmask;        // [n_chains][n_pad] backbone mask of the last inference per chain
     DevBuf<int32_t> nmc_status;   // sticky: a backbone inference diverged at its first lambda
     DevBuf<double> nmc_thr;       // thresholds of the cluster growth
@@ -561,6 +564,7 @@ int run_fused(nlmc_ctx *c, int slot, int w, uint32_t sweep0, uint64_t seed, cons
     a.trace_sweeps = outs ? n_total : T;
     a.t0 = t0;
     a.rec_stride = rec ? rec : 1;
+    a.min_stride = c->track_min ? c->track_min_stride : 1;
     a.argmin = c->argmin.p;
     if (outs) {
         a.etrace = want_energy ? c->etrace.p : nullptr;
@@ -846,6 +850,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         a.trace_sweeps = n_sweeps;
         a.t0 = t0;
         a.rec_stride = rec ? rec : 1;
+        a.min_stride = c->track_min ? c->track_min_stride : 1;
         a.strace = rec ? c->strace.p : nullptr;
         a.emin = want_min ? c->emin.p : nullptr;
         a.argmin = c->argmin.p;
@@ -1175,7 +1180,7 @@ void nlmc_destroy(nlmc_ctx *c)
     c->lbp_bar.release(); c->lbp_part.release();
     c->lbp_hm.release(); c->lbp_tot.release(); c->lbp_mag.release(); c->lbp_mag_all.release();
     c->pt_tab.release(); c->pt_beta.release(); c->pt_energies_all.release();
-    c->rounds_ebuf.release(); c->rounds_bar.release(); c->rounds_args.release();
+    c->rounds_ebuf.release(); c->rounds_bar.release(); c->rounds_args.release(); c->seed_snap.release();
     c->apt_beta.release(); c->apt_e_all.release(); c->apt_send.release(); c->apt_recv.release(); c->apt_bd.release();
     c->slot_of_chain.release(); c->chain_of_slot.release(); c->pt_pairs.release(); c->pt_status.release();
     c->pt_acc.release(); c->pt_log_acc.release(); c->pt_log_pairs.release(); c->pt_plan_pairs.release(); c->pt_plan_ok.release(); c->icm_label.release(); c->icm_info.release(); c->icm_pairs.release();
@@ -2165,7 +2170,7 @@ int nlmc_pt_rounds_fused(nlmc_ctx *c, int precision, int n_rounds, int sweeps_pe
     a.n_sweeps = T; a.sweep0 = sweep0; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
     a.tab = c->pt_tab.p; a.tab_cs = 2; a.tab_ss = 0; a.slot_of_chain = c->slot_of_chain.p;
     a.efix = c->efix.p; a.escale = c->escale; a.eshift = c->escale - c->qs; a.qinv = std::ldexp(1.0f, -c->qs);
-    a.trace_sweeps = T; a.rec_stride = 1; a.argmin = c->argmin.p;
+    a.trace_sweeps = T; a.rec_stride = 1; a.min_stride = 1; a.argmin = c->argmin.p;
     a.lds_neg_off = Lds.neg_off; a.lds_flags_off = Lds.flags_off; a.lds_u_off = Lds.u_off; a.lds_u_stride = Lds.u_bytes; a.lds_red_off = Lds.red_off;
     a.lds_snap_off = Lds.snap_off; a.lds_kt_off = Lds.kt_off; a.f64_xmax = c->xmax; a.f64_tie_mask = c->knob_tie_mask;
     a.qinv64 = std::ldexp(1.0, -c->qs);
@@ -2726,6 +2731,20 @@ int nlmc_track_minimum(nlmc_ctx *c, int on)
 {
     if (!c) return NLMC_ERR_ARG;
     c->track_min = on != 0;
+    c->track_min_stride = on > 1 ? on : 1;
+    return NLMC_OK;
+}
+
+int nlmc_backbone_seed(nlmc_ctx *c, int mode)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (mode < 0 || mode > 1) return fail(c, NLMC_ERR_ARG, "nlmc_backbone_seed: mode must be 0 or 1");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (mode == 0) { c->seed_snap_on = false; return NLMC_OK; }
+    const size_t bytes = (size_t)std::max(c->n_chains, 1) * c->n_pad;
+    HIP_TRY(c, c->seed_snap.reserve(bytes));
+    HIP_TRY(c, hipMemcpyAsync(c->seed_snap.p, c->spins.p, bytes, hipMemcpyDeviceToDevice, c->cur));
+    c->seed_snap_on = true;
     return NLMC_OK;
 }
 
@@ -2765,7 +2784,7 @@ int nlmc_backbone_clusters(nlmc_ctx *c, const double *epsilon, const double *lam
         HIP_TRY(c, hipStreamSynchronize(c->cur));
         c->nmc_thr_host = thr;
     }
-    hipLaunchKernelGGL(k_lbp_seeds, dim3(P), dim3(256), 0, c->cur, c->n, c->n_pad, c->sub_list(), c->spins.p, c->lbp_ms.p);
+    hipLaunchKernelGGL(k_lbp_seeds, dim3(P), dim3(256), 0, c->cur, c->n, c->n_pad, c->sub_list(), c->seed_snap_on ? c->seed_snap.p : c->spins.p, c->lbp_ms.p);
     HIP_TRY(c, hipGetLastError());
     { int rc = lbp_launch(c, P, n_lambdas, beta, tolerance, max_iterations, sat, false); if (rc) return rc; }
     hipLaunchKernelGGL(k_cluster_mask, dim3(P), dim3(256), (size_t)2 * c->n_pad, c->cur, c->g, c->sub_list(), c->lbp_mag.p,

@@ -600,6 +600,8 @@ struct SweepArgs {
     long long *etrace;        // [n_chains][trace_sweeps] or nullptr
     int trace_sweeps, t0;     // sweeps of the whole call / index of this launch's first sweep inside the call
     int rec_stride;
+    int min_stride;           // the running minimum looks at sweeps tg = 0, min_stride, 2 min_stride, ... of the call only (>= 1): the
+                              // reference takes its argmin over the RECORDED columns M[:, ::M_skip] (NMC/nmc.py:390-395)
     int8_t *strace;           // [n_chains][ceil(trace_sweeps/rec_stride)][n] or nullptr
     long long *emin;          // [n_chains] (in/out) or nullptr
     int32_t *argmin;          // [n_chains]
@@ -697,7 +699,7 @@ __device__ __forceinline__ void sweep_epilogue(const SweepArgs &a, ChainCtx &x, 
         if ((x.tid & 63) == 0 && w != 0) atomicAdd(reinterpret_cast<unsigned long long *>(&x.red[0]), (unsigned long long)w);
         __syncthreads();
         x.E += uniform64(x.red[0]);              // every thread: the sum stays wave-uniform (no broadcast of the decision)
-        const bool better = a.emin && x.E < x.Emin;                                  // strict <: first argmin (np.argmin)
+        const bool better = a.emin && x.E < x.Emin && (tg % a.min_stride == 0);      // strict <: first argmin (np.argmin)
         if (better) { x.Emin = x.E; x.amin = tg; }
         if (x.tid == 0 && a.etrace) a.etrace[(size_t)x.ob * a.trace_sweeps + tg] = x.E;
         __syncthreads();                         // everybody has read the sum
@@ -1798,7 +1800,7 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, const FusedWin 
         long long *red_ = reinterpret_cast<long long *>(lds_raw + a.lds_red_off);                                       \
         const int slot_ = o_t % 3, tg_ = a.t0 + o_t;                                                                    \
         E_run += uniform64(red_[slot_]);                                                                                \
-        const bool better_ = a.emin && E_run < E_min;        /* strict <: first argmin (np.argmin, NMC/nmc.py:394) */    \
+        const bool better_ = a.emin && E_run < E_min && (tg_ % a.min_stride == 0);   /* strict <: first argmin (np.argmin, NMC/nmc.py:394) */ \
         if (better_) { E_min = E_run; a_min = tg_; }                                                                    \
         if (o_tid == 0) {                                                                                               \
             red_[(o_t + 2) % 3] = 0;                          /* read a sweep ago, next used two sweeps from now */      \

@@ -243,7 +243,7 @@ class LocalTempering:
             e.set_spins(np.asarray(spins_global)[base:base + count])
 
     def configure_nmc(self, doNMC, phases, sweeps_per_phase, global_beta, temp_x, epsilon, lambdas, tolerance, max_iterations,
-                      sat, thresholds):
+                      sat, thresholds, M_skip=1):
         """Temperature slots with doNMC run NMC_task instead of MCMC_task every round (NPT/npt.py:622-647): backbone inference
         seeded with the chain's state, then `phases` ("C" / "NC" / "ALL") of `sweeps_per_phase` sweeps at `global_beta`,
         each starting from the argmin-energy configuration of the one before (NPT/npt.py:357-477).  Everything stays on the
@@ -258,7 +258,9 @@ class LocalTempering:
         self.nmc = dict(phases=list(phases), S=int(sweeps_per_phase), beta=float(global_beta), temp_x=float(temp_x),
                         epsilon=np.asarray(epsilon, dtype=np.float64), lambdas=np.asarray(lambdas, dtype=np.float64),
                         tol=float(tolerance), max_it=int(max_iterations), sat=float(sat),
-                        thresholds=np.asarray(thresholds, dtype=np.float64))
+                        thresholds=np.asarray(thresholds, dtype=np.float64), M_skip=max(1, int(M_skip)))
+        # M_skip > 1 (NPT/npt.py:434-437: M = M[:, ::M_skip] before the energies and the argmin): the phases' running minimum looks at
+        # every M_skip-th sweep only (nlmc_track_minimum(M_skip)), their recorded traces are strided the same way
 
     def sweeps_per_round(self, n_sweeps):
         """Plain sweep indices (RNG counters) one round of `n_sweeps` sweeps consumes.  The NMC phases of the marked slots draw from
@@ -316,18 +318,19 @@ class LocalTempering:
             if wants:
                 rec["nmc_chains"] = e.subset()
             e.backbone_clusters(q["epsilon"], q["lambdas"], q["beta"], q["tol"], q["max_it"], q["sat"], q["thresholds"])
-            e.track_minimum(True)
+            e.track_minimum(True, stride=q["M_skip"])
             n_ph = len(q["phases"])
+            out_nmc = dict(outputs, record_stride=q["M_skip"]) if outputs.get("record_stride") else outputs
             planned = self._nmc_planners is not None and 0 <= ii < self._planned_rounds
             for p, kind in enumerate(q["phases"]):
                 if p > 0:
                     e.adopt_best()                   # NPT/npt.py:436-437,454-455: the next phase starts from the argmin column
                 e.set_phase(kind, q["temp_x"])
                 if planned:
-                    rec["nmc"].append(self._nmc_planners[k].sweep(ii * n_ph + p, **outputs))
+                    rec["nmc"].append(self._nmc_planners[k].sweep(ii * n_ph + p, **out_nmc))
                 else:
                     rec["nmc"].append(e.sweep_philox(q["S"], self.seed, sweep0=NMC_SWEEP_SPACE + self.nmc_sweeps_done + p * q["S"],
-                                                     beta=q["beta"], precision=self.precision, **outputs))
+                                                     beta=q["beta"], precision=self.precision, **out_nmc))
             e.track_minimum(False)
             e.set_phase("ALL")
             e.select("all")

@@ -465,8 +465,13 @@ class Engine:
         self._ck(self._L.nlmc_get_subset(self._ctx, _abi.ptr(out)))
         return out
 
-    def track_minimum(self, on=True):
-        self._ck(self._L.nlmc_track_minimum(self._ctx, int(bool(on))))
+    def track_minimum(self, on=True, stride=1):
+        """Sweep calls keep the running minimum + argmin state on the device; `stride` > 1: over sweeps 0, stride, 2 stride, ... only."""
+        self._ck(self._L.nlmc_track_minimum(self._ctx, (max(1, int(stride)) if on else 0)))
+
+    def backbone_seed(self, snapshot=True):
+        """snapshot=True: later backbone_clusters calls are seeded with the configurations as they are NOW; False: with the current ones."""
+        self._ck(self._L.nlmc_backbone_seed(self._ctx, 1 if snapshot else 0))
 
     def adopt_best(self):
         self._ck(self._L.nlmc_adopt_best(self._ctx))

@@ -48,7 +48,7 @@ class NMC(Common):
     def run_restarts(self, num_restarts, num_sweeps_initial=int(1e4), num_sweeps_per_NMC_phase=int(1e4), num_NMC_cycles=10,
                      full_update_frequency=1, temp_x=20, global_beta=2.5, lambda_start=0.5, lambda_end=0.01,
                      lambda_reduction_factor=0.9, threshold_initial=0.999999, threshold_cutoff=0.99999,
-                     max_iterations=100, tolerance=np.finfo(float).eps, all_clusters=None):
+                     max_iterations=100, tolerance=np.finfo(float).eps, all_clusters=None, _force_host=False):
         """Throughput extension (not in the reference): `num_restarts` independent NMC runs of run()'s algorithm batched
         in ONE context -- anneal, then per cycle the three phases (NMC/nmc.py:365-433), every phase one launch over all
         restarts with per-restart cluster flags, the argmin-energy state of each phase handed to the next.  Device RNG
@@ -64,17 +64,18 @@ class NMC(Common):
         eng = self._cache.engine(self.J, self.h, R)
         m = np.sign(2 * np.random.default_rng(self.seed).random((R, N)) - 1).astype(np.int8)
         args = (lambda_start, lambda_end, lambda_reduction_factor, threshold_initial, threshold_cutoff, max_iterations, tolerance)
-        if full_update_frequency == 1 and (all_clusters is not None or self.lbp == "device"):     # (lbp="host": the bit-exact host inference)
-            return self._run_restarts_device(eng, inst, m, S0, S, num_NMC_cycles, temp_x, global_beta, all_clusters, *args)
+        if not _force_host and full_update_frequency >= 1 and (all_clusters is not None or self.lbp == "device"):     # (lbp="host": the bit-exact host inference)
+            return self._run_restarts_device(eng, inst, m, S0, S, num_NMC_cycles, int(full_update_frequency), temp_x, global_beta, all_clusters, *args)
         return self._run_restarts_host(eng, inst, m, S0, S, num_NMC_cycles, full_update_frequency, temp_x, global_beta,
                                        all_clusters, *args)
 
-    def _run_restarts_device(self, eng, inst, m, S0, S, num_NMC_cycles, temp_x, global_beta, all_clusters, lambda_start,
+    def _run_restarts_device(self, eng, inst, m, S0, S, num_NMC_cycles, full_update_frequency, temp_x, global_beta, all_clusters, lambda_start,
                              lambda_end, lambda_reduction_factor, threshold_initial, threshold_cutoff, max_iterations, tolerance):
-        """Every cycle ends with a plain phase (full_update_frequency == 1), so the state a cycle's backbone inference is seeded
-        with (m_star, NMC/nmc.py:368-373,433) is the state its first phase starts from: the hand-offs, the inference seeds, the
-        cluster masks and the phase flags all stay on the device (include/nlmc.h: nlmc_adopt_best, nlmc_backbone_clusters,
-        nlmc_set_phase); per launch only the minima and argmin states come back for the run's own best-of bookkeeping."""
+        """The hand-offs, the inference seeds, the cluster masks and the phase flags all stay on the device (include/nlmc.h:
+        nlmc_adopt_best, nlmc_backbone_clusters, nlmc_set_phase); per launch only the minima and argmin states come back for the
+        run's own best-of bookkeeping.  The state a cycle's backbone inference is seeded with (m_star, NMC/nmc.py:368-373,433) is the
+        state after the last PLAIN phase: with full_update_frequency == 1 the state the cycle starts from, otherwise an older one --
+        kept aside on the device (nlmc_backbone_seed) whenever a plain phase (or the anneal) ends."""
         from .lbp import lambda_list, _SAT, EPS as _EPS
         R, N = m.shape
         sweep0 = self._sweep_counter
@@ -98,6 +99,7 @@ class NMC(Common):
             sched = hostlogic.beta_schedule(S0, global_beta, True, 1, 0)
             launch(S0, np.repeat(sched[None, :], R, axis=0))
         if S > 0 and num_NMC_cycles > 0:
+            eng.backbone_seed(True)                  # m_star = the state after the anneal (NMC/nmc.py:364-365)
             if all_clusters is None:
                 lams = lambda_list(lambda_start, lambda_end, lambda_reduction_factor)
                 if not lams:
@@ -111,18 +113,23 @@ class NMC(Common):
                 mask = np.zeros((R, N), dtype=np.uint8)
                 mask[:, np.asarray(all_clusters, dtype=int)] = 1
                 eng.set_cluster_mask(mask)
-            eng.plan_ahead(sweep0, 3 * num_NMC_cycles, S, self.seed)      # the phase launches' windows, planned together
+            n_launches = sum(2 + (1 if cycle % full_update_frequency == 0 else 0) for cycle in range(num_NMC_cycles))
+            eng.plan_ahead(sweep0, n_launches, S, self.seed)              # the phase launches' windows, planned together
             try:
                 for cycle in range(num_NMC_cycles):
                     if all_clusters is None:
                         eng.backbone_clusters(epsilon, lams, global_beta, tolerance, max_iterations, _SAT - _EPS, thr)
-                    for kind in ("C", "NC", "ALL"):
+                    plain = cycle % full_update_frequency == 0            # NMC/nmc.py:419: the third phase of this cycle
+                    for kind in ("C", "NC") + (("ALL",) if plain else ()):
                         eng.set_phase(kind, temp_x)
                         launch(S, float(global_beta))
+                    if plain:
+                        eng.backbone_seed(True)                           # m_star = m_init after the plain phase (NMC/nmc.py:433)
                 eng.backbone_check()
             finally:
                 eng.plan_ahead(None, 0, 0, 0)
                 eng.set_flags(None)
+                eng.backbone_seed(False)
         self._sweep_counter = sweep0
         # the running minima were tracked in the fixed-point model; report the fp64 energies of the kept states
         return eng.energy_of(best_s), best_s, np.stack(trail, axis=1) if trail else np.zeros((R, 0))

@@ -101,7 +101,9 @@ class NPT(Common):
         if return_trace not in ("float64", "int8", None):
             raise ValueError("return_trace must be 'float64', 'int8' or None")
         any_nmc = any(bool(v) for v in doNMC)
-        device_resident = self.rng == "philox" and (not any_nmc or M_skip == 1)
+        # (with NMC replicas and M_skip > 1 the phases' traces and argmin hand-offs are strided on the device; a phase length that M_skip
+        # does not divide raises the reference's own shape error on the host-managed path)
+        device_resident = self.rng == "philox" and (not any_nmc or (int(M_skip) >= 1 and self.num_sweeps_per_NMC_phase_per_swap % int(M_skip) == 0))
         if (int(num_restarts) != 1 or (device_ids is not None and len(list(device_ids)) > 1)) and not device_resident:
             raise ValueError("num_restarts / device_ids need rng='philox' (and M_skip == 1 with NMC replicas): the "
                              "reference's own stream order has one ladder in one process")
@@ -113,7 +115,7 @@ class NPT(Common):
                 nmc = dict(num_cycles=num_cycles, full_update_frequency=full_update_frequency, temp_x=temp_x,
                            global_beta=global_beta, lambda_start=lambda_start, lambda_end=lambda_end,
                            lambda_reduction_factor=lambda_reduction_factor, threshold_initial=threshold_initial,
-                           threshold_cutoff=threshold_cutoff, max_iterations=max_iterations, tolerance=tolerance)
+                           threshold_cutoff=threshold_cutoff, max_iterations=max_iterations, tolerance=tolerance, M_skip=int(M_skip))
             M, Energy = self._run_device_resident(beta_list, int(num_restarts), device_ids, return_trace, nmc)
         else:
             M, Energy = self._run_host_managed(beta_list, num_cycles, full_update_frequency, M_skip, temp_x, global_beta,
@@ -326,8 +328,9 @@ class NPT(Common):
         if nmc:
             for cycle in range(nmc["num_cycles"]):
                 phases += ["C", "NC"] + (["ALL"] if cycle % nmc["full_update_frequency"] == 0 else [])
-            if S > 0 and len(phases) * S_nmc < S:          # NPT/npt.py:643-644: M[block] = M_nmc[:, -S:] cannot be filled
-                raise ValueError(f"could not broadcast input array from shape ({N},{len(phases) * S_nmc}) into shape ({N},{S})")
+            w_nmc = S_nmc // nmc["M_skip"]                 # recorded columns per phase (NPT/npt.py:434-435)
+            if S > 0 and len(phases) * w_nmc < S:          # NPT/npt.py:643-644: M[block] = M_nmc[:, -S:] cannot be filled
+                raise ValueError(f"could not broadcast input array from shape ({N},{len(phases) * w_nmc}) into shape ({N},{S})")
             lams = lambda_list(nmc["lambda_start"], nmc["lambda_end"], nmc["lambda_reduction_factor"])
             if not lams:                # the reference's lambda loop never runs: find_clusters(None) raises TypeError there
                 raise TypeError("bad operand type for abs(): 'NoneType'")
@@ -353,7 +356,7 @@ class NPT(Common):
         try:
             if nmc:
                 lt.configure_nmc(self.doNMC, phases, S_nmc, nmc["global_beta"], nmc["temp_x"], self._graph(inst).epsilon(inst.h),
-                                 lams, nmc["tolerance"], nmc["max_iterations"], _SAT - _EPS, thr)
+                                 lams, nmc["tolerance"], nmc["max_iterations"], _SAT - _EPS, thr, M_skip=nmc["M_skip"])
             m0 = (2 * np.random.default_rng(self.seed).integers(0, 2, size=(G, N), dtype=np.int8) - 1).astype(np.int8)
             lt.set_spins(m0)
             lt.sweeps_done = self._sweep_counter
@@ -452,7 +455,9 @@ class NPT(Common):
         for e, (base, _), rec in zip(lt.engs, lt.parts, outs):
             pc, nc = rec["plain_chains"], rec["nmc_chains"]
             full[base + pc] = rec["plain"][key]
-            tail = np.concatenate([o[key] for o in rec["nmc"]], axis=1)[:, -S:] if S > 0 else np.zeros_like(full[base + nc])
+            # (recorded traces come back strided already; per-sweep energies are strided here: NPT/npt.py:434-435)
+            ms = lt.nmc["M_skip"] if (key == "energy" and lt.nmc) else 1
+            tail = np.concatenate([o[key][:, ::ms] for o in rec["nmc"]], axis=1)[:, -S:] if S > 0 else np.zeros_like(full[base + nc])
             full[base + nc] = tail
             if E_cols is not None:
                 E_cols[base + pc] = rec["plain_energy_columns"]
