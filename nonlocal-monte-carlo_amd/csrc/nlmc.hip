@@ -1508,6 +1508,7 @@ int nlmc_plan_philox_fused(nlmc_ctx *c, uint32_t sweep0, int n_windows, int wind
     a.fmt = fused_addr_format(c) ? NLMC_FMT_ADDR : c->compact16 ? NLMC_FMT_COMPACT : NLMC_FMT_WIDE;
     a.k_zero = c->n_pad + 8;
     a.neg_off = c->n_pad + 16;
+    a.bank_aware = getenv("NLMC_NO_BANK_AWARE") ? 0 : 1;
     P.fmt = a.fmt;
     a.adj = reinterpret_cast<const uint4 *>(c->fz_adj.p); a.glv = c->fz_glv.p; a.perm = c->fz_perm.p; a.head = P.head.p; a.ell = P.ell.p; a.loff = P.loff.p; a.nlev = P.nlev.p;
     a.hi_max = P.himax.p; a.send = P.send.p; a.npos = P.npos.p;

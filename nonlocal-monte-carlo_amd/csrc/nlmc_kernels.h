@@ -250,6 +250,7 @@ struct FusedLevelizeArgs {
     int fmt;                  // entry format of the planes: NLMC_FMT_WIDE / _COMPACT / _SIGN (see FusedItem)
     int k_zero;               // address format: LDS address of a byte that is always 0 (padding entries point at it)
     int neg_off;              // address format: LDS offset of the negated copy of the spins
+    int bank_aware;           // order every item's row entries so that the 32 lanes of a half-wave gather from different LDS banks
     const uint4 *adj;         // [n][2]: the first 16 neighbours of every spin as 16-bit indices (k_fused_adjacency)
     uint16_t *glv;            // scratch [n_windows][T][n]: level of update (t, k), 1-based
     uint32_t *perm;           // scratch [n_windows][pstride]: item id k | t << 16 at its position, ~0 = padding
@@ -470,9 +471,17 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
     // A dummy item updates the scratch spin behind the real ones from an all-zero row: harmless by construction.
     int2 *head = a.head + (size_t)w * PS;
     int4 *ell = reinterpret_cast<int4 *>(a.ell) + (size_t)w * (NLMC_FZ_W / 2) * PS;
+    // Bank-aware entry order (round 4).  The sweep kernel gathers entry q of all 64 items of a chunk with ONE ds_read_u8; the LDS
+    // serves it per half-wave of 32 lanes over 32 banks of 4 bytes (scripts/probes/lds_conflict_probe.hip: same bank + different dword
+    // inside a half = one more pass: 205 / 280 / 486 ns per round of 8 gathers at 1 / 2 / 4 lanes per bank; random addresses 303).  The
+    // field is a sum, so a row's entries may stand in ANY order: slot by slot, the lanes of a half-wave claim banks (atomicOr on a
+    // 32-bit mask per half and slot; up to three candidates per lane and slot, then whatever is left).  Early slots -- many
+    // candidates per lane -- come out conflict-free, the last real entries of a row take what remains.
+    __shared__ unsigned sh_bank[16][16];             // [wave][half * 8 + slot]
     for (int pos = tid; pos < npos; pos += nt) {
         const uint32_t it = perm[pos];
         const uint32_t dpack = (uint32_t)a.k_dummy << 16;
+        if (a.bank_aware && (tid & 63) < 16) sh_bank[tid >> 6][tid & 15] = 0u;       // (npos is a multiple of 64: whole waves iterate)
         if (it == 0xFFFFFFFFu) {
             // (threshold word 3 tab_words: behind the three tables / snapshot slots, so that a dummy's threshold read and
             // snapshot write touch nothing that belongs to a spin)
@@ -499,13 +508,72 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
         for (int q = 0; q < NLMC_FZ_W; ++q) ed[q] = a.g.edge32[rs + e0 + q];    // unconditional (the array is padded by a
                                                                                 // full window): independent loads
         const int hy = second ? 0 : a.g.hq[k];
+        if (a.bank_aware) {
+            const int nreal = min(max(left, 0), NLMC_FZ_W);
+            unsigned long long banks = 0ull;                   // 5 bits per entry
+#pragma unroll
+            for (int q = 0; q < NLMC_FZ_W; ++q) {
+                const unsigned ad = (unsigned)ed[q].col + ((a.fmt == NLMC_FMT_ADDR && ed[q].q < 0) ? (unsigned)a.neg_off : 0u);
+                banks |= (unsigned long long)((ad >> 2) & 31u) << (5 * q);
+            }
+            unsigned *mask = &sh_bank[tid >> 6][((tid >> 5) & 1) * 8];
+            unsigned rem = (1u << nreal) - 1u, ordpk = 0u;     // entries not placed yet; 4 bits per slot: entry index, 8 = padding
+            int spare = NLMC_FZ_W - nreal;                     // padding entries (they gather a byte that is always 0: one address for
+                                                               // every lane, no conflict) -- a lane may spend one on a contested slot
+            const unsigned rot = (unsigned)tid * 3u;
+#pragma unroll
+            for (int q = 0; q < NLMC_FZ_W; ++q) {
+                unsigned chosen = 8u;
+                if (rem) {
+                    unsigned cand = rem;
+                    bool got = false;
+#pragma unroll
+                    for (int at = 0; at < 4; ++at) {
+                        if (!got && cand) {
+                            // a candidate among the remaining ones, starting at a lane-dependent position
+                            const unsigned r8 = ((cand | (cand << 8)) >> ((rot + (unsigned)q) & 7u)) & 0xFFu;
+                            const unsigned e = ((unsigned)__builtin_ctz(r8) + ((rot + (unsigned)q) & 7u)) & 7u;
+                            const unsigned bit = 1u << (unsigned)((banks >> (5 * e)) & 31ull);
+                            const unsigned old = atomicOr(&mask[q], bit);
+                            if (!(old & bit)) { got = true; chosen = e; }
+                            cand &= ~(1u << e);
+                        }
+                    }
+                    if (!got && spare > 0) { --spare; }               // every candidate's bank is taken: padding here, the entries later
+                    else {
+                        if (!got) chosen = (unsigned)__builtin_ctz(rem);
+                        rem &= ~(1u << chosen);
+                    }
+                }
+                ordpk |= chosen << (4 * q);
+            }
+            EdgeQ od[NLMC_FZ_W];
+#pragma unroll
+            for (int q = 0; q < NLMC_FZ_W; ++q) {
+                const unsigned e = (ordpk >> (4 * q)) & 15u;
+                EdgeQ sel = ed[0];
+#pragma unroll
+                for (int j = 1; j < NLMC_FZ_W; ++j) { sel.col = e == (unsigned)j ? ed[j].col : sel.col; sel.q = e == (unsigned)j ? ed[j].q : sel.q; }
+                od[q] = sel;
+            }
+            // real entries first in `od` is no longer true: mark padding by a zero coupling and the dummy column
+            int nr = 0;
+#pragma unroll
+            for (int q = 0; q < NLMC_FZ_W; ++q) {
+                const bool pad = ((ordpk >> (4 * q)) & 15u) == 8u;
+                ed[q] = pad ? EdgeQ{-1, 0} : od[q];
+                nr += pad ? 0 : 1;
+            }
+            (void)nr;
+        }
+        auto is_real = [&](int q) { return a.bank_aware ? ed[q].col >= 0 : q < left; };
         if (a.fmt == NLMC_FMT_ADDR) {
             // 16-bit LDS addresses: s_j for Jq = +1, the negated copy for Jq = -1, the zero byte for padding
             uint32_t pk[NLMC_FZ_W / 2];
 #pragma unroll
             for (int q = 0; q < NLMC_FZ_W; q += 2) {
-                const uint32_t lo = q < left ? (uint32_t)(ed[q].col + (ed[q].q < 0 ? a.neg_off : 0)) : (uint32_t)a.k_zero;
-                const uint32_t hi = q + 1 < left ? (uint32_t)(ed[q + 1].col + (ed[q + 1].q < 0 ? a.neg_off : 0)) : (uint32_t)a.k_zero;
+                const uint32_t lo = is_real(q) ? (uint32_t)(ed[q].col + (ed[q].q < 0 ? a.neg_off : 0)) : (uint32_t)a.k_zero;
+                const uint32_t hi = is_real(q + 1) ? (uint32_t)(ed[q + 1].col + (ed[q + 1].q < 0 ? a.neg_off : 0)) : (uint32_t)a.k_zero;
                 pk[q / 2] = lo | (hi << 16);
             }
             ell[pos] = make_int4((int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]);
@@ -516,7 +584,7 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
         if (a.fmt == NLMC_FMT_COMPACT) {
             uint32_t pk[NLMC_FZ_W];
 #pragma unroll
-            for (int q = 0; q < NLMC_FZ_W; ++q) pk[q] = q < left ? ((uint32_t)ed[q].col << 16) | ((uint32_t)ed[q].q & 0xFFFFu) : dpack;
+            for (int q = 0; q < NLMC_FZ_W; ++q) pk[q] = is_real(q) ? ((uint32_t)ed[q].col << 16) | ((uint32_t)ed[q].q & 0xFFFFu) : dpack;
 #pragma unroll
             for (int q = 0; q < NLMC_FZ_W; q += 4)
                 ell[(size_t)(q / 4) * PS + pos] = make_int4((int)pk[q], (int)pk[q + 1], (int)pk[q + 2], (int)pk[q + 3]);
@@ -524,7 +592,7 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
 #pragma unroll
             for (int q = 0; q < NLMC_FZ_W; q += 2) {
                 const EdgeQ z{a.k_dummy, 0};
-                const EdgeQ f0 = q < left ? ed[q] : z, f1 = q + 1 < left ? ed[q + 1] : z;
+                const EdgeQ f0 = is_real(q) ? ed[q] : z, f1 = is_real(q + 1) ? ed[q + 1] : z;
                 ell[(size_t)(q / 2) * PS + pos] = make_int4(f0.col, f0.q, f1.col, f1.q);
             }
         }
