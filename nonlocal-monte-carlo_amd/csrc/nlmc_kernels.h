@@ -1809,7 +1809,12 @@ __device__ __forceinline__ void fused_levels(const SweepArgs &a, const FusedWin 
         if (F64) {
             const unsigned hk = __float_as_uint(wk);
             const unsigned kaddr = ((unsigned)X << 2) + v_kt0;
+#ifdef NLMC_DEBUG_KNOBS
+            // 16384: timing experiment -- no dependent table read behind the field sum (wrong results)
+            const unsigned kh = (a.dbg_flags & 16384) ? (unsigned)(X * 3000000 + 0x4000000) : *(lds_u32)(uintptr_t)kaddr;
+#else
             const unsigned kh = *(lds_u32)(uintptr_t)kaddr;
+#endif
             up64 = hk < kh;
             const bool tie = ((hk ^ kh) & v_tie) == 0u;
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(tie) != 0ull, 0)) {

@@ -357,7 +357,9 @@ class NPT(Common):
             if nmc:
                 lt.configure_nmc(self.doNMC, phases, S_nmc, nmc["global_beta"], nmc["temp_x"], self._graph(inst).epsilon(inst.h),
                                  lams, nmc["tolerance"], nmc["max_iterations"], _SAT - _EPS, thr, M_skip=nmc["M_skip"])
-            m0 = (2 * np.random.default_rng(self.seed).integers(0, 2, size=(G, N), dtype=np.int8) - 1).astype(np.int8)
+            m0 = np.random.default_rng(self.seed).integers(0, 2, size=(G, N), dtype=np.int8)
+            m0 <<= 1                                     # 2 b - 1 in place (the same states as `2 * b - 1`, two passes over G x N bytes less)
+            m0 -= 1
             lt.set_spins(m0)
             lt.sweeps_done = self._sweep_counter
             lt.nmc_sweeps_done = getattr(self, "_nmc_sweep_counter", 0)
