@@ -191,6 +191,10 @@ int nlmc_apt_pack(nlmc_ctx *ctx, int64_t *out_slot_efix, int8_t *out_lo, int8_t 
 int nlmc_apt_swap_host(nlmc_ctx *ctx, uint32_t round, uint64_t seed, int n_pairs, const int64_t *efix_all, const int8_t *recv_lo,
                        const int8_t *recv_hi, int32_t *out_pairs, uint8_t *out_accepted);
 int nlmc_apt_swap_collective(nlmc_ctx *ctx, uint32_t round, uint64_t seed, int n_pairs, int32_t *out_pairs, uint8_t *out_accepted);
+/* Rehearsal of the collective path's neighbour exchange with ONE rank: the same grouped ncclSend / ncclRecv pair with this rank as its
+ * own lower and upper neighbour; out_recv_lo [K][n] must then equal the packed top-slot configurations (nlmc_apt_pack: out_hi),
+ * out_recv_hi the bottom-slot ones.  (N > 1 ranks on one GPU are refused by RCCL: this is what a one-GPU box can execute of it.) */
+int nlmc_apt_selftest_exchange(nlmc_ctx *ctx, int8_t *out_recv_lo, int8_t *out_recv_hi);
 
 /* Replica exchange (NPT/npt.py:602-683).  Chains are grouped into ladders of ladder_len consecutive global
  * chain ids; slot r of a ladder runs at beta_list[r].  Accepted swaps exchange the beta slots of two chains

@@ -30,7 +30,7 @@ EXPORTS = [
     "nlmc_lbp_convexified", "nlmc_find_clusters", "nlmc_trace_layout", "nlmc_energy_of_recorded",
     "nlmc_last_timing", "nlmc_timing_reset", "nlmc_timing_total", "nlmc_last_schedule_stats",
     "nlmc_pt_mark_slots", "nlmc_select_chains", "nlmc_subset_count", "nlmc_get_subset", "nlmc_track_minimum", "nlmc_backbone_seed", "nlmc_adopt_best",
-    "nlmc_backbone_clusters", "nlmc_backbone_check", "nlmc_get_cluster_mask", "nlmc_set_phase", "nlmc_plan_slot", "nlmc_overlap_subsets", "nlmc_own_stream", "nlmc_plan_get_levels", "nlmc_probe_level_round", "nlmc_comm_unique_id", "nlmc_comm_init", "nlmc_comm_probe", "nlmc_comm_check", "nlmc_apt_shard", "nlmc_apt_pack", "nlmc_apt_swap_host", "nlmc_apt_swap_collective", "nlmc_pt_swap_philox_collective", "nlmc_set_cluster_mask", "nlmc_host_prefault",
+    "nlmc_backbone_clusters", "nlmc_backbone_check", "nlmc_get_cluster_mask", "nlmc_set_phase", "nlmc_plan_slot", "nlmc_overlap_subsets", "nlmc_own_stream", "nlmc_plan_get_levels", "nlmc_probe_level_round", "nlmc_comm_unique_id", "nlmc_comm_init", "nlmc_comm_probe", "nlmc_comm_check", "nlmc_apt_shard", "nlmc_apt_pack", "nlmc_apt_swap_host", "nlmc_apt_swap_collective", "nlmc_apt_selftest_exchange", "nlmc_pt_swap_philox_collective", "nlmc_set_cluster_mask", "nlmc_host_prefault",
 ]
 
 
@@ -159,7 +159,7 @@ def lib():
                        ("nlmc_pt_rounds_fused", [_vp, _i, _i, _i, _u32, _u32, _u64, _i]),
                        ("nlmc_apt_shard", [_vp, _i, _i, _i, _vp]), ("nlmc_apt_pack", [_vp, _vp, _vp, _vp]),
                        ("nlmc_apt_swap_host", [_vp, _u32, _u64, _i, _vp, _vp, _vp, _vp, _vp]),
-                       ("nlmc_apt_swap_collective", [_vp, _u32, _u64, _i, _vp, _vp])):
+                       ("nlmc_apt_swap_collective", [_vp, _u32, _u64, _i, _vp, _vp]), ("nlmc_apt_selftest_exchange", [_vp, _vp, _vp])):
         f = getattr(L, name)
         f.restype = _i
         f.argtypes = args

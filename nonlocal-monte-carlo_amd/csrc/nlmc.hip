@@ -2099,6 +2099,34 @@ int nlmc_apt_swap_host(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs, 
     return apt_launch_swap(c, round, seed, n_pairs, out_pairs, out_accepted);
 }
 
+// Rehearsal of the neighbour exchange on ONE rank: the grouped ncclSend / ncclRecv pair of nlmc_apt_swap_collective with this rank
+// as its own neighbour on both sides (a send to oneself inside a group is legal): what rank - 1 would receive from this rank's
+// bottom-slot chains comes back as `from the upper neighbour`, and the other way round.
+int nlmc_apt_selftest_exchange(nlmc_ctx *c, int8_t *out_recv_lo, int8_t *out_recv_hi)
+{
+    { int rc = apt_require(c, "nlmc_apt_selftest_exchange"); if (rc) return rc; }
+    if (!c->comm) return fail(c, NLMC_ERR_STATE, "nlmc_apt_selftest_exchange: call nlmc_comm_init first");
+    if (!out_recv_lo || !out_recv_hi) return fail(c, NLMC_ERR_ARG, "nlmc_apt_selftest_exchange: NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rc = apt_launch_pack(c); if (rc) return rc; }
+    const int L = c->ladder_len, K = c->n_chains / L, me = c->comm_rank;
+    const size_t rowbytes = (size_t)K * c->n_pad;
+    int rc = g_rccl.GroupStart();
+    if (rc == 0) rc = g_rccl.Send(c->apt_send.p, rowbytes, /*ncclInt8*/ 0, me, c->comm, c->stream);                 // my bottom-slot chains ...
+    if (rc == 0) rc = g_rccl.Recv(c->apt_recv.p + rowbytes, rowbytes, 0, me, c->comm, c->stream);                   // ... arrive as the upper neighbour's
+    if (rc == 0) rc = g_rccl.Send(c->apt_send.p + rowbytes, rowbytes, 0, me, c->comm, c->stream);                   // my top-slot chains ...
+    if (rc == 0) rc = g_rccl.Recv(c->apt_recv.p, rowbytes, 0, me, c->comm, c->stream);                              // ... as the lower neighbour's
+    const int rc2 = g_rccl.GroupEnd();
+    if (rc != 0 || rc2 != 0) return fail(c, NLMC_ERR_HIP, "ncclSend / ncclRecv: " + rccl_err(rc != 0 ? rc : rc2));
+    for (int side = 0; side < 2; ++side) {
+        c->stage_out.resize(rowbytes);
+        HIP_TRY(c, hipMemcpyAsync(c->stage_out.data(), c->apt_recv.p + (size_t)side * rowbytes, rowbytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        rows_to_host_finish(c, side ? out_recv_hi : out_recv_lo, K);
+    }
+    return nlmc_comm_check(c, 10000);
+}
+
 int nlmc_apt_swap_collective(nlmc_ctx *c, uint32_t round, uint64_t seed, int n_pairs, int32_t *out_pairs, uint8_t *out_accepted)
 {
     { int rc = apt_require(c, "nlmc_apt_swap_collective"); if (rc) return rc; }

@@ -409,6 +409,13 @@ class Engine:
                                             _abi.ptr(pairs), _abi.ptr(acc)))
         return pairs, acc
 
+    def apt_selftest_exchange(self):
+        """(recv_lo, recv_hi) [K, n] of the collective path's neighbour exchange run with this rank as its own neighbour."""
+        K = self.n_chains // self.ladder_len
+        lo, hi = np.empty((K, self.n), np.int8), np.empty((K, self.n), np.int8)
+        self._ck(self._L.nlmc_apt_selftest_exchange(self._ctx, _abi.ptr(lo), _abi.ptr(hi)))
+        return lo, hi
+
     def apt_swap_collective(self, round_idx, seed, n_pairs, want_log=False):
         pairs, acc = self._apt_log(n_pairs, want_log)
         self._ck(self._L.nlmc_apt_swap_collective(self._ctx, int(round_idx), int(seed), int(n_pairs), _abi.ptr(pairs), _abi.ptr(acc)))

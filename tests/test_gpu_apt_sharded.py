@@ -116,6 +116,11 @@ def test_library_issued_collective_on_a_one_rank_communicator(product):
         e.comm_init(product.Engine.comm_unique_id(), 1, 0)
         e.apt_swap_collective(0, SEED, pairs)
         e.comm_check(5000)
+        # the grouped ncclSend / ncclRecv pair of the N > 1 path, with this rank as its own neighbour on both sides
+        e.set_spins(spins.reshape(K * R, N))
+        _, lo, hi = e.apt_pack()
+        rlo, rhi = e.apt_selftest_exchange()
+        assert np.array_equal(rlo, hi) and np.array_equal(rhi, lo) and not np.array_equal(lo, hi)
         with pytest.raises(RuntimeError):
             e.pt_swap_philox_collective(0, SEED, pairs)             # the chain-block collective is not this mode's
 
