@@ -249,6 +249,13 @@ int nlmc_pt_plan(nlmc_ctx *ctx, uint32_t round0, int n_rounds, uint64_t seed, in
  * wait that times out is reported by nlmc_pt_check / nlmc_pt_log_read (NLMC_ERR_HIP). */
 int nlmc_pt_rounds_fused(nlmc_ctx *ctx, int precision, int n_rounds, int sweeps_per_round, uint32_t sweep0, uint32_t round0,
                          uint64_t seed, int n_pairs);
+/* The same n_rounds rounds as n_rounds sweep launches + ONE swap launch: the sweep launch of round i decides the swap of round i - 1
+ * in its prologue (every chain looks up its pair, reads its partner's energy as the previous launch published it, takes k_pt_swap's
+ * decision and updates its own entries of the slot maps; wave 0 does it while the other waves load the spins), the last round's
+ * swap is the ordinary kernel.  Same conditions and the same NLMC_ERR_UNSUPPORTED convention as nlmc_pt_rounds_fused (n_pairs >= 1);
+ * bit-identical to nlmc_sweep_philox + nlmc_pt_swap_philox round by round, one kernel launch per round less. */
+int nlmc_pt_rounds_deferred(nlmc_ctx *ctx, int precision, int n_rounds, int sweeps_per_round, uint32_t sweep0, uint32_t round0,
+                            uint64_t seed, int n_pairs);
 /* Device-side swap log of rounds [round0, round0 + n_rounds): rounds of nlmc_pt_swap_philox(_host) called WITHOUT host
  * output pointers keep their pairs and decisions on the device; nlmc_pt_log_read copies the whole log in one go
  * (out_pairs [n_rounds][n_ladders][n_pairs][2], -1 where a round did not run; out_accepted [n_rounds][n_ladders][n_pairs])

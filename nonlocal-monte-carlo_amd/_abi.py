@@ -26,7 +26,7 @@ EXPORTS = [
     "nlmc_abi_version", "nlmc_device_count", "nlmc_create", "nlmc_destroy", "nlmc_last_error", "nlmc_set_spins",
     "nlmc_get_spins", "nlmc_set_flags", "nlmc_energy", "nlmc_energy_tracked", "nlmc_energy_dev", "nlmc_set_energy_sink", "nlmc_energy_scale", "nlmc_field_scale", "nlmc_energy_of", "nlmc_sweep_stream",
     "nlmc_sweep_philox", "nlmc_plan_philox", "nlmc_plan_philox_fused", "nlmc_fused_modes", "nlmc_plan_reserve_fused", "nlmc_pt_init", "nlmc_pt_get_slots", "nlmc_pt_set_slots",
-    "nlmc_pt_apply_swap", "nlmc_pt_swap_philox", "nlmc_pt_plan", "nlmc_pt_rounds_fused", "nlmc_pt_check", "nlmc_pt_swap_philox_host", "nlmc_pt_log_begin", "nlmc_pt_log_read", "nlmc_icm_components", "nlmc_icm_move", "nlmc_icm_get_labels", "nlmc_icm_round_philox", "nlmc_icm_round_ladders",
+    "nlmc_pt_apply_swap", "nlmc_pt_swap_philox", "nlmc_pt_plan", "nlmc_pt_rounds_fused", "nlmc_pt_rounds_deferred", "nlmc_pt_check", "nlmc_pt_swap_philox_host", "nlmc_pt_log_begin", "nlmc_pt_log_read", "nlmc_icm_components", "nlmc_icm_move", "nlmc_icm_get_labels", "nlmc_icm_round_philox", "nlmc_icm_round_ladders",
     "nlmc_lbp_convexified", "nlmc_find_clusters", "nlmc_trace_layout", "nlmc_energy_of_recorded",
     "nlmc_last_timing", "nlmc_timing_reset", "nlmc_timing_total", "nlmc_last_schedule_stats",
     "nlmc_pt_mark_slots", "nlmc_select_chains", "nlmc_subset_count", "nlmc_get_subset", "nlmc_track_minimum", "nlmc_backbone_seed", "nlmc_adopt_best",
@@ -157,6 +157,7 @@ def lib():
                        ("nlmc_plan_get_levels", [_vp, _i, _vp, _i, _vp]), ("nlmc_comm_unique_id", [_vp]), ("nlmc_comm_init", [_vp, _vp, _i, _i]),
                        ("nlmc_pt_swap_philox_collective", [_vp, _u32, _u64, _i, _i, _vp, _vp]), ("nlmc_comm_probe", []), ("nlmc_comm_check", [_vp, _i]),
                        ("nlmc_pt_rounds_fused", [_vp, _i, _i, _i, _u32, _u32, _u64, _i]),
+                       ("nlmc_pt_rounds_deferred", [_vp, _i, _i, _i, _u32, _u32, _u64, _i]),
                        ("nlmc_apt_shard", [_vp, _i, _i, _i, _vp]), ("nlmc_apt_pack", [_vp, _vp, _vp, _vp]),
                        ("nlmc_apt_swap_host", [_vp, _u32, _u64, _i, _vp, _vp, _vp, _vp, _vp]),
                        ("nlmc_apt_swap_collective", [_vp, _u32, _u64, _i, _vp, _vp]), ("nlmc_apt_selftest_exchange", [_vp, _vp, _vp])):

@@ -86,8 +86,8 @@ struct nlmc_ctx {
     bool has_flags = false;
     bool has_diag = false;
     bool has_zero_vals = false;   // a stored entry is 0.0 (or underflows to 0 in fp32)
-    size_t lds_opt[80] = {};      // dynamic-LDS opt-in already granted, one slot per kernel: 0 k_levelize, 1 k_icm_components,
-                                  // 2..7 sweep-by-sweep kernels, 8 k_stream_scatter, 16 k_levelize_fused, 17..20 k_lbp_lds, 21 k_icm_round, 22..23 packed fp64 sweep kernels, 24..47 k_sweep_fused variants, 48..59 its fp64 variants, 60..71 k_rounds_fused
+    size_t lds_opt[96] = {};      // dynamic-LDS opt-in already granted, one slot per kernel: 0 k_levelize, 1 k_icm_components,
+                                  // 2..7 sweep-by-sweep kernels, 8 k_stream_scatter, 16 k_levelize_fused, 17..20 k_lbp_lds, 21 k_icm_round, 22..23 packed fp64 sweep kernels, 24..47 k_sweep_fused variants, 48..59 its fp64 variants, 60..71 k_rounds_fused, 72..83 k_sweep_fused with the deferred swap
 
     DevBuf<int32_t> rowptr, col;
     DevBuf<double> val64, h64;
@@ -499,7 +499,8 @@ struct SweepOut {
 // One fused window.  `outs` (nullable): the launch also produces per-sweep outputs into the context's device buffers
 // (etrace / emin / argmin / best / strace, sized by the caller) as sweeps [t0, t0 + T) of a call of n_total sweeps.
 int run_fused(nlmc_ctx *c, int slot, int w, uint32_t sweep0, uint64_t seed, const double *tab_dev, int tab_cs, int tab_ss, bool use_slots,
-              bool outs, bool want_energy, bool want_min, bool want_state, int rec, int t0, int n_total, bool f64 = false)
+              bool outs, bool want_energy, bool want_min, bool want_state, int rec, int t0, int n_total, bool f64 = false,
+              const DeferSwap *defer = nullptr, double *sink_override = nullptr)
 {
     const nlmc_ctx::FusedPlan &P = c->fz[slot];
     const int R = c->sub_count(), n = c->n, T = P.T;
@@ -511,8 +512,17 @@ int run_fused(nlmc_ctx *c, int slot, int w, uint32_t sweep0, uint64_t seed, cons
     if (outs && !snap_lds) HIP_TRY(c, c->snap_g.reserve((size_t)R * (3 * (size_t)c->n_pad + 16)));
     const int variant = (outs ? 4 : 0) + (c->has_diag ? 2 : 0) + (c->has_flags ? 1 : 0);
     const void *kfun = fused_kernel(c->has_diag, c->has_flags, outs, P.fmt, f64);
-    if (!kfun) return fail(c, NLMC_ERR_STATE, "run_fused: no fp64 fused kernel with phase flags");
-    { int rc = ensure_lds(c, f64 ? 48 + ((c->has_diag ? 2 : 0) + (outs ? 1 : 0)) * 3 + P.fmt : 24 + variant * 3 + P.fmt, kfun, L.total); if (rc) return rc; }
+    int lds_slot = f64 ? 48 + ((c->has_diag ? 2 : 0) + (outs ? 1 : 0)) * 3 + P.fmt : 24 + variant * 3 + P.fmt;
+    if (defer) {             // the previous round's swap decided in this launch's prologue (plain chains, no outputs: checked by the caller)
+#define NLMC_KD(D, F64_) {reinterpret_cast<const void *>(k_sweep_fused<D, false, false, NLMC_FMT_WIDE, F64_, true>), reinterpret_cast<const void *>(k_sweep_fused<D, false, false, NLMC_FMT_COMPACT, F64_, true>), \
+                          reinterpret_cast<const void *>(k_sweep_fused<D, false, false, NLMC_FMT_ADDR, F64_, true>)}
+        static const void *const dtable[2][2][3] = {{NLMC_KD(false, false), NLMC_KD(false, true)}, {NLMC_KD(true, false), NLMC_KD(true, true)}};
+#undef NLMC_KD
+        kfun = (c->has_flags || outs) ? nullptr : dtable[c->has_diag][f64][P.fmt];
+        lds_slot = 72 + ((c->has_diag ? 2 : 0) + (f64 ? 1 : 0)) * 3 + P.fmt;
+    }
+    if (!kfun) return fail(c, NLMC_ERR_STATE, "run_fused: no kernel for this combination (fp64 mode or deferred swap with phase flags / outputs)");
+    { int rc = ensure_lds(c, lds_slot, kfun, L.total); if (rc) return rc; }
     // events around the launch (two stream commands) only while timings accumulate (nlmc_timing_reset): every launch or
     // every ev_every-th one.  An event record costs ~2.5 us of stream time: none on the plain product path.
     const bool timed = c->ev_accumulate && (c->ev_every <= 1 || c->launches_total % c->ev_every == 0);
@@ -557,7 +567,8 @@ int run_fused(nlmc_ctx *c, int slot, int w, uint32_t sweep0, uint64_t seed, cons
     a.tab = tab_dev; a.tab_cs = tab_cs; a.tab_ss = tab_ss;
     a.slot_of_chain = use_slots ? c->slot_of_chain.p : nullptr;
     a.efix = c->efix.p;
-    a.energy_sink = c->energy_sink;
+    a.energy_sink = sink_override ? sink_override : c->energy_sink;
+    if (defer) a.defer = *defer;
     a.escale = c->escale;
     a.eshift = c->escale - c->qs;
     a.qinv = std::ldexp(1.0f, -c->qs);
@@ -2267,6 +2278,72 @@ int nlmc_pt_rounds_fused(nlmc_ctx *c, int precision, int n_rounds, int sweeps_pe
     c->stat_fused_slot = fslot;
     c->sub_dirty = true;
     return NLMC_OK;
+}
+
+// n_rounds rounds as n_rounds sweep launches + ONE swap launch: launch i decides the swap of round i - 1 in its prologue
+// (k_sweep_fused<.., DEFER>), the last round's swap is the ordinary k_pt_swap.
+int nlmc_pt_rounds_deferred(nlmc_ctx *c, int precision, int n_rounds, int sweeps_per_round, uint32_t sweep0, uint32_t round0, uint64_t seed,
+                            int n_pairs)
+{
+    if (!c) return NLMC_ERR_ARG;
+    if (n_rounds < 0 || sweeps_per_round < 1 || (precision != NLMC_F32 && precision != NLMC_F64) || n_pairs < 0)
+        return fail(c, NLMC_ERR_ARG, "nlmc_pt_rounds_deferred: bad argument");
+    if (c->ladder_len == 0) return fail(c, NLMC_ERR_STATE, "nlmc_pt_rounds_deferred: call nlmc_pt_init first");
+    if (n_rounds == 0 || c->n_chains == 0) return NLMC_OK;
+    const int L = c->ladder_len, T = sweeps_per_round;
+    auto no = [&](const char *why) { return fail(c, NLMC_ERR_UNSUPPORTED, std::string("nlmc_pt_rounds_deferred: ") + why); };
+    if (getenv("NLMC_NO_DEFERRED")) return no("switched off (NLMC_NO_DEFERRED)");
+    if (c->chain_base % L != 0 || c->n_chains % L != 0) return no("the context's block cuts a ladder (the swap needs other contexts' energies)");
+    if (c->comm || (c->apt_R > 0 && c->apt_world > 1)) return no("the context takes part in a collective swap round");
+    if (c->has_flags || c->subset != 0 || c->cur != c->stream || c->track_min) return no("phase flags, a chain subset or a tracked minimum are in force");
+    if (n_pairs < 1 || n_pairs > std::max(0, L - 1)) return n_pairs < 1 ? no("no swap pairs") : fail(c, NLMC_ERR_ARG, "Cannot find non-overlapping pairs.");
+    const int fslot = fused_plan_for(c, sweep0, n_rounds * T, seed);
+    if (fslot < 0 || c->fz[fslot].T != T) return no("no fused-window plan of one window per round covers these sweeps");
+    if (precision == NLMC_F64 && !fused_f64_supported(c, T)) return no("the fp64 mode does not run on fused windows for this instance");
+    if (!(c->pt_plan_valid && c->pt_plan_seed == seed && c->pt_plan_npairs == n_pairs && round0 >= c->pt_plan_round0 &&
+          (uint64_t)round0 + (uint64_t)n_rounds <= (uint64_t)c->pt_plan_round0 + (uint64_t)c->pt_plan_rounds))
+        return no("the pair selections of these rounds are not planned (nlmc_pt_plan)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const nlmc_ctx::FusedPlan &P = c->fz[fslot];
+    const int w0 = (int)((sweep0 - P.sweep0) / (uint32_t)T), nl = c->n_chains_global / L;
+    const size_t G = (size_t)c->n_chains_global;
+    HIP_TRY(c, c->rounds_ebuf.reserve(2 * G));
+    if (!c->pt_tab_valid || c->pt_tab_temp_x != c->temp_x) {
+        std::vector<double> tab((size_t)L * 2);
+        for (int r = 0; r < L; ++r) { tab[2 * r] = -2.0 * LOG2E * c->beta_list[r]; tab[2 * r + 1] = -2.0 * LOG2E * (c->beta_list[r] / c->temp_x); }
+        HIP_TRY(c, hipMemcpyAsync(c->pt_tab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->pt_tab_valid = true; c->pt_tab_temp_x = c->temp_x;
+    }
+    if (!c->ev_accumulate) c->ev_used = 0;
+    c->ev_call_start = c->ev_used;
+    c->launches_sweep = 0;
+    const bool log = c->pt_log_on && c->pt_log_npairs == n_pairs && round0 >= c->pt_log_round0 &&
+                     (uint64_t)round0 + (uint64_t)n_rounds <= (uint64_t)c->pt_log_round0 + (uint64_t)c->pt_log_rounds;
+    for (int r = 0; r < n_rounds; ++r) {
+        DeferSwap d{};
+        d.ladder_len = L; d.n_ladders = nl; d.beta = c->pt_beta.p;
+        d.slot_of_chain = c->slot_of_chain.p; d.chain_of_slot = c->chain_of_slot.p;
+        if (r > 0) {                          // the swap of round round0 + r - 1, on the energies the previous launch published
+            const uint32_t rr = round0 + (uint32_t)(r - 1);
+            d.n_pairs = n_pairs; d.round = rr;
+            d.plan_pairs = c->pt_plan_pairs.p + (size_t)(rr - c->pt_plan_round0) * nl * n_pairs * 2;
+            d.e_prev = c->rounds_ebuf.p + (size_t)((r - 1) & 1) * G;
+            if (log) {
+                const size_t lr = rr - c->pt_log_round0;
+                d.log_pairs = c->pt_log_pairs.p + lr * (size_t)nl * n_pairs * 2;
+                d.log_acc = c->pt_log_acc.p + lr * (size_t)nl * n_pairs;
+            }
+        }
+        // (this launch publishes its chains' final energies for the next one: rows of the local chains inside the global vector)
+        double *sink = c->rounds_ebuf.p + (size_t)(r & 1) * G + c->chain_base;
+        int rc = run_fused(c, fslot, w0 + r, sweep0 + (uint32_t)(r * T), seed, c->pt_tab.p, 2, 0, true, false, false, false, false, 0, 0, T,
+                           precision == NLMC_F64, &d, sink);
+        if (rc) return rc;
+    }
+    c->sub_dirty = true;
+    // the last round's swap: the ordinary kernel on the tracked energies
+    return nlmc_pt_swap_philox(c, round0 + (uint32_t)(n_rounds - 1), seed, n_pairs, nullptr, nullptr, nullptr);
 }
 
 int nlmc_pt_log_begin(nlmc_ctx *c, uint32_t round0, int n_rounds, int n_pairs)

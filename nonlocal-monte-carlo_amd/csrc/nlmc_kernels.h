@@ -633,8 +633,26 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
 #define NLMC_FCALL
 #endif
 
+// The swap round of the PREVIOUS replica-exchange round, decided in the prologue of this round's sweep launch (k_sweep_fused<..,
+// DEFER>, nlmc_pt_rounds_deferred): every chain looks up the selected pair its slot belongs to, reads its partner's energy as the
+// previous launch published it, takes the decision k_pt_swap would take (same keys, same arithmetic; both chains of a pair compute
+// it) and updates its OWN entries of the slot maps -- chain_of_slot[new slot] is written by the chain that moves there and read,
+// before that, by the same chain only; nothing one chain writes is read by another inside the launch, so there is no fence, no
+// atomic and no second copy of the maps.  Wave 0 does it while the other waves load the spins.
+struct DeferSwap {
+    int ladder_len, n_pairs, n_ladders;
+    uint32_t round;
+    const int32_t *plan_pairs;       // the round's planned selection [n_ladders][n_pairs][2]
+    const double *beta;              // [ladder_len]
+    int32_t *slot_of_chain, *chain_of_slot;
+    const double *e_prev;            // [n_chains_global] energies after the previous round's sweeps
+    int32_t *log_pairs;              // the round's rows of the device-side swap log, or nullptr
+    uint8_t *log_acc;
+};
+
 struct SweepArgs {
     CsrDev g;
+    DeferSwap defer;          // (k_sweep_fused<.., DEFER = true> only)
     int chain_base;
     const int32_t *chain_list; // launch over a SUBSET of the context's chains: block b runs local chain chain_list[b] (state rows
                               // and RNG use the chain id, recorded traces / energy traces are dense in b); nullptr: block b = chain b
@@ -2130,20 +2148,91 @@ __device__ __forceinline__ void fused_state_store(const SweepArgs &a, unsigned c
 // of 2^-qs.  The fp64 field of the spec is then the exact integer X times 2^-qs whatever the order of the sum, z = cb x takes
 // one value per X, and the spec's test fma(u, 2^z, u) < 1 is a threshold on the 53-bit integer of u (accept_count_spec): the
 // update is the fixed-point one with `k_u < K[X]` in place of `z < W(r)`.  Same bits as the sweep-by-sweep fp64 kernel.
-template <bool DIAG, bool FLAGS, bool OUT, int FMT, bool F64 = false>
+// The swap step of one chain (k_rounds_fused after its grid-wide meeting, k_sweep_fused<.., DEFER> in its prologue): wave 0, `slot` =
+// the chain's slot before the swap, Ed / e_all = its own / everybody's energy after the round's sweeps.  Returns the slot after it.
+template <bool ATOMIC>
+__device__ __forceinline__ int pt_swap_step_of_chain(int slot, uint32_t gc, int lane, int L, int n_pairs, int n_ladders, uint32_t round,
+                                                     const int32_t *sel_round, const double *beta, int32_t *slot_of_chain, int32_t *chain_of_slot,
+                                                     double Ed, const double *e_all, int32_t *log_pairs, uint8_t *log_acc, uint32_t seed_lo,
+                                                     uint32_t seed_hi)
+{
+    (void)n_ladders;
+    const int g = (int)gc / L;
+    const int32_t *sel = sel_round + (size_t)g * n_pairs * 2;
+    int fp = -1, fi = 0, out = slot;
+    for (int p0 = 0; p0 < n_pairs; p0 += 64) {             // the pair this chain's slot belongs to, if any: one lane per selected pair
+        const int p = p0 + lane;
+        const int i = p < n_pairs ? sel[2 * p] : -5;
+        const unsigned long long m = __ballot(i == slot || i + 1 == slot);
+        if (m) { const int src = __ffsll((long long)m) - 1; fp = p0 + src; fi = __shfl(i, src, 64); break; }
+    }
+    if (fp >= 0) {                                         // (every lane of the wave computes it: the result is wave-uniform)
+        const int i = fi, ps = slot == i ? i + 1 : i;
+        int partner;
+        double Ep;
+        if (ATOMIC) {
+            partner = __hip_atomic_load(&chain_of_slot[(size_t)g * L + ps], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            Ep = __hip_atomic_load(&e_all[partner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            partner = chain_of_slot[(size_t)g * L + ps];
+            Ep = e_all[partner];
+        }
+        const double Ea = slot == i ? Ed : Ep, Eb = slot == i ? Ep : Ed;
+        const double dE = Eb - Ea, dB = beta[i + 1] - beta[i];
+        const u32x4 rr = philox4x32_10((uint32_t)fp, round, (uint32_t)g, NLMC_TAG_SWAP, seed_lo, seed_hi);
+        const double u = uniform_from(rr, 0.0);
+        const double z = (dB * dE) * 1.4426950408889634;
+        const bool acc = u < exp2_spec(z);
+        if (lane == 0) {
+            if (slot == i && log_pairs) {                  // the chain on the lower slot keeps the round's log entry
+                const size_t at = (size_t)g * n_pairs + fp;
+                log_pairs[2 * at] = i; log_pairs[2 * at + 1] = i + 1;
+                log_acc[at] = acc ? 1 : 0;
+            }
+            if (acc) {
+                if (ATOMIC) {
+                    __hip_atomic_store(&slot_of_chain[gc], ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&chain_of_slot[(size_t)g * L + ps], (int)gc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    slot_of_chain[gc] = ps;
+                    chain_of_slot[(size_t)g * L + ps] = (int)gc;
+                }
+            }
+        }
+        if (acc) out = ps;
+    }
+    return out;
+}
+
+template <bool DIAG, bool FLAGS, bool OUT, int FMT, bool F64 = false, bool DEFER = false>
 __global__ __launch_bounds__(1024) void k_sweep_fused(SweepArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     if ((unsigned)reinterpret_cast<size_t>(lds_raw) != 0u) __builtin_trap();   // spins at LDS offset 0: column == address
+    static_assert(!(DEFER && OUT), "the deferred swap rides on the plain variant");
     const int c = a.chain_list ? a.chain_list[blockIdx.x] : (int)blockIdx.x;      // local chain id (state rows, RNG)
     const uint32_t gc_chain = (uint32_t)(a.chain_base + c);
-    const int row = a.slot_of_chain ? a.slot_of_chain[gc_chain] : c;
-    const uint32_t gc = (a.rng_stride && a.slot_of_chain) ? (uint32_t)((c / a.rng_ladder_len) * a.rng_stride + a.rng_base + row) : gc_chain;
+    int row = a.slot_of_chain ? a.slot_of_chain[gc_chain] : c;
+    int new_row = row;
+    if (DEFER && a.defer.n_pairs > 0 && threadIdx.x < 64)          // wave 0, while the other waves load the spins
+        new_row = pt_swap_step_of_chain<false>(row, gc_chain, (int)threadIdx.x, a.defer.ladder_len, a.defer.n_pairs, a.defer.n_ladders, a.defer.round,
+                                               a.defer.plan_pairs, a.defer.beta, a.defer.slot_of_chain, a.defer.chain_of_slot,
+                                               a.defer.e_prev[gc_chain], a.defer.e_prev, a.defer.log_pairs, a.defer.log_acc, a.seed_lo, a.seed_hi);
 #ifdef NLMC_STAMPS
     const long long st_begin = (long long)__builtin_readcyclecounter();
 #endif
     const FusedWin W{a.lvl_off, a.fsend, a.ell32, a.head32, a.warm_head, a.warm_ell, a.fz_npos_next, a.nlev[0], a.hi_max[0], a.sweep0};
     fused_state_load<FLAGS>(a, lds_raw, c);
+    if (DEFER) {                                                   // the chain's slot after the swap, to every wave
+        volatile int *sh = reinterpret_cast<volatile int *>(lds_raw + a.lds_red_off);
+        __syncthreads();
+        if (threadIdx.x == 0) sh[0] = new_row;
+        __syncthreads();
+        row = sh[0];
+        __syncthreads();
+        if (threadIdx.x == 0) sh[0] = 0;
+    }
+    const uint32_t gc = (a.rng_stride && a.slot_of_chain) ? (uint32_t)((c / a.rng_ladder_len) * a.rng_stride + a.rng_base + row) : gc_chain;
     long long e_loc = 0;
     fused_window<DIAG, FLAGS, OUT, FMT, F64>(a, W, lds_raw, row, gc, e_loc);
     fused_state_store<OUT>(a, lds_raw, c, e_loc);
@@ -2280,37 +2369,12 @@ __global__ __launch_bounds__(1024) void k_rounds_fused(const SweepArgs *ap_g, co
 #else
         if (tid < 64) {
 #endif
-            // the pair this chain's slot belongs to in this round's selection, if any: one lane per selected pair
             const int slot = sh[0];
-            const int32_t *sel = q.plan_pairs + ((size_t)r * q.n_ladders + g) * q.n_pairs * 2;
-            int fp = -1, fi = 0;
-            for (int p0 = 0; p0 < q.n_pairs; p0 += 64) {
-                const int p = p0 + lane;
-                const int i = p < q.n_pairs ? sel[2 * p] : -5;
-                const unsigned long long m = __ballot(i == slot || i + 1 == slot);
-                if (m) { const int src = __ffsll((long long)m) - 1; fp = p0 + src; fi = __shfl(i, src, 64); break; }
-            }
-            if (fp >= 0 && lane == 0) {
-                const int i = fi, ps = slot == i ? i + 1 : i;
-                const int partner = __hip_atomic_load(&q.chain_of_slot[(size_t)g * L + ps], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const double Ep = __hip_atomic_load(&eb[partner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const double Ea = slot == i ? Ed : Ep, Eb = slot == i ? Ep : Ed;
-                const double dE = Eb - Ea, dB = q.beta[i + 1] - q.beta[i];
-                const u32x4 rr = philox4x32_10((uint32_t)fp, q.round0 + (uint32_t)r, (uint32_t)g, NLMC_TAG_SWAP, a.seed_lo, a.seed_hi);
-                const double u = uniform_from(rr, 0.0);
-                const double z = (dB * dE) * 1.4426950408889634;
-                const bool acc = u < exp2_spec(z);
-                if (slot == i && q.log_pairs) {                   // the chain on the lower slot keeps the round's log entry
-                    const size_t at = ((size_t)r * q.n_ladders + g) * q.n_pairs + fp;
-                    q.log_pairs[2 * at] = i; q.log_pairs[2 * at + 1] = i + 1;
-                    q.log_acc[at] = acc ? 1 : 0;
-                }
-                if (acc) {
-                    __hip_atomic_store(&q.slot_of_chain[gc], ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&q.chain_of_slot[(size_t)g * L + ps], (int)gc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    sh[0] = ps;
-                }
-            }
+            const int ns = pt_swap_step_of_chain<true>(slot, gc, lane, L, q.n_pairs, q.n_ladders, q.round0 + (uint32_t)r,
+                                                       q.plan_pairs + (size_t)r * q.n_ladders * q.n_pairs * 2, q.beta, q.slot_of_chain, q.chain_of_slot, Ed, eb,
+                                                       q.log_pairs ? q.log_pairs + (size_t)r * q.n_ladders * q.n_pairs * 2 : nullptr,
+                                                       q.log_acc ? q.log_acc + (size_t)r * q.n_ladders * q.n_pairs : nullptr, a.seed_lo, a.seed_hi);
+            if (lane == 0 && ns != slot) sh[0] = ns;
         }
         __syncthreads();
     }

@@ -154,8 +154,14 @@ class ShardedTempering:
         pl = getattr(self, "_planner", None)
         if persistent is None:
             persistent = bool(os.environ.get("NLMC_PERSISTENT"))
-        can = (persistent and pl is not None and self._lt is None and not self.collective and self.n_pairs > 0 and pl.window == n_sweeps == pl.S
-               and hasattr(self.eng, "pt_rounds_fused") and not getattr(self, "_persistent_refused", False))
+        # default where it applies (one process, whole ladders, fused windows of one round): a sweep launch decides the PREVIOUS
+        # round's swap in its prologue (nlmc_pt_rounds_deferred: one launch per round instead of two; NLMC_NO_DEFERRED switches it off)
+        eligible = (pl is not None and self._lt is None and not self.collective and self.n_pairs > 0 and pl.window == n_sweeps == pl.S
+                    and hasattr(self.eng, "pt_rounds_fused") and not getattr(self, "_persistent_refused", False))
+        can = eligible
+        batch = self.eng.pt_rounds_fused if persistent else getattr(self.eng, "pt_rounds_deferred", None)
+        if batch is None or (not persistent and os.environ.get("NLMC_NO_DEFERRED")):
+            can = False
         while done < n_rounds:
             ii = self.rounds_done - (self._planner_round0 if pl is not None else 0)
             if can and 0 <= ii < pl.R:
@@ -163,11 +169,14 @@ class ShardedTempering:
                     pl._plan(ii, True)                      # this chunk's schedules and pair selections (inside whatever is timed)
                 if pl._fused_from <= ii < pl._fused_to:
                     k = min(pl._fused_to - ii, n_rounds - done)
-                    if self.eng.pt_rounds_fused(k, n_sweeps, self.seed, self.sweeps_done, self.rounds_done, self.n_pairs, precision=self.precision):
+                    if batch(k, n_sweeps, self.seed, self.sweeps_done, self.rounds_done, self.n_pairs, precision=self.precision):
                         self.sweeps_done += k * n_sweeps
                         self.rounds_done += k
                         done += k
-                        self.persistent_rounds = getattr(self, "persistent_rounds", 0) + k
+                        if persistent:
+                            self.persistent_rounds = getattr(self, "persistent_rounds", 0) + k
+                        else:
+                            self.deferred_rounds = getattr(self, "deferred_rounds", 0) + k
                         continue
                     self._persistent_refused = True          # stop asking; the reason is in eng.rounds_fused_refusal
                 can = False

@@ -436,6 +436,18 @@ class Engine:
         self._ck(rc)
         return True
 
+    def pt_rounds_deferred(self, n_rounds, sweeps_per_round, seed, sweep0, round0, n_pairs, precision="f32"):
+        """n_rounds rounds as n_rounds sweep launches (each decides the previous round's swap in its prologue) + one swap launch
+        (include/nlmc.h: nlmc_pt_rounds_deferred).  True when queued, False when the context / plans do not qualify."""
+        prec = {"f32": _abi.F32, "f64": _abi.F64}[precision]
+        rc = self._L.nlmc_pt_rounds_deferred(self._ctx, prec, int(n_rounds), int(sweeps_per_round), int(sweep0) & 0xFFFFFFFF,
+                                             int(round0) & 0xFFFFFFFF, int(seed), int(n_pairs))
+        if rc == _abi.ERR_UNSUPPORTED:
+            self.rounds_fused_refusal = _abi.lib().nlmc_last_error(self._ctx).decode()
+            return False
+        self._ck(rc)
+        return True
+
     def pt_log_begin(self, round0, n_rounds, n_pairs):
         """Keep the swap log of the next rounds on the device (rounds called with want_log=False)."""
         self._ck(self._L.nlmc_pt_log_begin(self._ctx, int(round0), int(n_rounds), int(n_pairs)))

@@ -10,7 +10,7 @@ P = load_product()
 N, R, T, ROUNDS = (int(os.environ.get(k, d)) for k, d in (("N", 10000), ("R", 256), ("T", 10), ("ROUNDS", 256)))
 PREC, PAIRS = os.environ.get("PRECISION", "f64"), 77
 J, h = make_instance(N)
-for mode in ("persistent", "per-round"):
+for mode in ("persistent", "deferred", "per-round"):
     with P.Engine(J, h, R) as eng:
         eng.set_spins(init_spins(R, N)); eng.pt_init(np.geomspace(0.05, 4.0, R))
         assert eng.plan_philox_fused(0, 2 * ROUNDS, T, 7) == 2 * ROUNDS
@@ -20,6 +20,8 @@ for mode in ("persistent", "per-round"):
             eng.energy(); t0 = time.perf_counter()
             if mode == "persistent":
                 assert eng.pt_rounds_fused(ROUNDS, T, 7, rep * ROUNDS * T, rep * ROUNDS, PAIRS, precision=PREC), eng.rounds_fused_refusal
+            elif mode == "deferred":
+                assert eng.pt_rounds_deferred(ROUNDS, T, 7, rep * ROUNDS * T, rep * ROUNDS, PAIRS, precision=PREC), eng.rounds_fused_refusal
             else:
                 for r in range(rep * ROUNDS, (rep + 1) * ROUNDS):
                     eng.sweep_philox(T, 7, sweep0=r * T, beta=None, precision=PREC)

@@ -1,5 +1,6 @@
-"""k_rounds_fused (include/nlmc.h: nlmc_pt_rounds_fused): many rounds -- sweeps + replica exchange -- in one cooperative launch,
-against the same rounds driven one launch at a time: spins, tracked energies, slot maps and the swap log must be the same bits."""
+"""k_rounds_fused (include/nlmc.h: nlmc_pt_rounds_fused): many rounds -- sweeps + replica exchange -- in one cooperative launch, and
+nlmc_pt_rounds_deferred: one sweep launch per round that decides the PREVIOUS round's swap in its prologue -- against the same rounds
+driven with a sweep launch and a swap launch each: spins, tracked energies, slot maps and the swap log must be the same bits."""
 import numpy as np
 import pytest
 
@@ -20,8 +21,9 @@ def drive(product, inst, G, L, T, rounds, pairs, precision, persistent, m0, chun
         eng.pt_log_begin(0, rounds, pairs)
         if persistent:
             at = 0
+            batch = eng.pt_rounds_deferred if persistent == "deferred" else eng.pt_rounds_fused
             for k in (split or [rounds]):
-                assert eng.pt_rounds_fused(k, T, SEED, at * T, at, pairs, precision=precision), getattr(eng, "rounds_fused_refusal", "")
+                assert batch(k, T, SEED, at * T, at, pairs, precision=precision), getattr(eng, "rounds_fused_refusal", "")
                 at += k
         else:
             for r in range(rounds):
@@ -42,10 +44,11 @@ def test_persistent_rounds_equal_rounds_launched_one_by_one(product, precision):
     m0 = init_spins(G, N)
     ref = drive(product, inst, G, L, T, rounds, pairs, precision, False, m0)
     assert ref[4].sum() > 0 and not np.array_equal(ref[2], np.arange(G) % L)
-    for split in (None, [3, 4], [1, 1, 5]):
-        got = drive(product, inst, G, L, T, rounds, pairs, precision, True, m0, split=split)
-        for x, y in zip(got, ref):
-            assert np.array_equal(x, y), split
+    for mode in (True, "deferred"):
+        for split in (None, [3, 4], [1, 1, 5]):
+            got = drive(product, inst, G, L, T, rounds, pairs, precision, mode, m0, split=split)
+            for x, y in zip(got, ref):
+                assert np.array_equal(x, y), (mode, split)
     assert np.array_equal(ref[1], ref[5])                          # tracked == recomputed (+-J)
 
 
@@ -63,9 +66,10 @@ def test_persistent_rounds_other_formats(product, case):
     G = L * nl
     m0 = init_spins(G, N)
     ref = drive(product, inst, G, L, T, rounds, pairs, precision, False, m0)
-    got = drive(product, inst, G, L, T, rounds, pairs, precision, True, m0)
-    for x, y in zip(got[:5], ref[:5]):
-        assert np.array_equal(x, y)
+    for mode in (True, "deferred"):
+        got = drive(product, inst, G, L, T, rounds, pairs, precision, mode, m0)
+        for x, y in zip(got[:5], ref[:5]):
+            assert np.array_equal(x, y), mode
 
 
 def test_persistent_rounds_refusals_and_the_driver(product):
@@ -98,22 +102,25 @@ def test_persistent_rounds_refusals_and_the_driver(product):
         eng.pt_plan(0, 2, SEED, 2)
         assert not eng.pt_rounds_fused(2, T, SEED, 0, 0, 2, precision="f64") and "fp64" in eng.rounds_fused_refusal
 
-    def run(persistent):
+    def run(mode):
         st = product.distributed.ShardedTempering(lambda i, n, b, g: product.Engine(i, None, n, chain_base=b, n_chains_global=g), inst, betas,
                                                   L, SEED, 2, precision="f64")
         st.set_spins(m0)
         st.plan(11 * T, 11, chunk_rounds=4, lazy=True)
-        if persistent:
+        if mode == "persistent":
             st.run_rounds(11, T, persistent=True)
             assert st.persistent_rounds == 11
+        elif mode == "deferred":
+            st.run_rounds(11, T)                                   # the default of run_rounds where it applies
+            assert st.deferred_rounds == 11
         else:
             for _ in range(11):
                 st.round(T)
         out = st.eng.get_spins(), st.eng.energy(), st.eng.pt_slots()
         st.close()
         return out
-    a, b = run(True), run(False)
-    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    a, b, c = run("persistent"), run("per-round"), run("deferred")
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and all(np.array_equal(x, y) for x, y in zip(c, b))
 
 
 def test_c4_size_persistent_rounds(product):
@@ -126,6 +133,7 @@ def test_c4_size_persistent_rounds(product):
     ref = drive(product, inst, G, G, T, rounds, pairs, "f64", False, m0)
     a = drive(product, inst, G, G, T, rounds, pairs, "f64", True, m0)
     b = drive(product, inst, G, G, T, rounds, pairs, "f64", True, m0, split=[2, 4])
-    for x, y, z in zip(a, ref, b):
-        assert np.array_equal(x, y) and np.array_equal(z, y)
+    d = drive(product, inst, G, G, T, rounds, pairs, "f64", "deferred", m0, split=[1, 5])
+    for x, y, z, v in zip(a, ref, b, d):
+        assert np.array_equal(x, y) and np.array_equal(z, y) and np.array_equal(v, y)
     assert np.array_equal(ref[1], ref[5]) and ref[4].sum() > 100
