@@ -350,8 +350,9 @@ def main():
         st.eng.timing_reset(True, every=EVENT_EVERY if fused else 1)
         sync()
         t0 = time.perf_counter()
-        # one sweep launch + one swap launch per round (--persistent: a planned chunk of rounds per launch, k_rounds_fused -- same bits,
-        # and measured the same speed)
+        # one process, whole ladders: one launch per round (the sweep launch decides the previous round's swap in its prologue); ranks
+        # that exchange energies: sweep launch + all-gather + swap launch per round (--persistent: a planned chunk of rounds per launch,
+        # k_rounds_fused -- same bits, and measured the same speed)
         st.run_rounds(tr, S_SWAP, persistent=a.persistent)
         sync()
         dt = time.perf_counter() - t0
@@ -372,7 +373,7 @@ def main():
         st.close()
         return {"dt": dt, "tm": tm, "rounds": tr, "count": count, "e_start": e_start, "e_end": e_end, "sched": sched,
                 "chunks": chunks, "collective": coll, "fused": fused, "probe": probe, "precision": precision,
-                "persistent_rounds": getattr(st, "persistent_rounds", 0),
+                "persistent_rounds": getattr(st, "persistent_rounds", 0), "deferred_rounds": getattr(st, "deferred_rounds", 0),
                 "tracked_equals_recomputed": bool(np.array_equal(e_end, e_exact))}
 
     KERNEL = {("f64", True): "k_sweep_fused<DIAG=false,FLAGS=false,OUT=false,FMT_ADDR,F64=true>", ("f64", False): "k_sweep_philox<double,false,PK=true>",
@@ -397,6 +398,9 @@ def main():
         levels_launch = r["sched"]["levels"] if r["fused"] else r["sched"]["levels"] / max(1, r["sched"]["orders"]) * S_SWAP / max(1.0, launches_per_round)
         ach_lv = levels_launch / sec_launch if ms_launch > 0 else 0.0
         kernel = KERNEL[(r["precision"], r["fused"])]
+        if r["deferred_rounds"]:
+            # one launch per round: the sweep launch decides the previous round's swap in its prologue (nlmc_pt_rounds_deferred)
+            kernel = kernel.replace(">", ",DEFER=true>")
         if r["persistent_rounds"]:
             # rounds run inside k_rounds_fused: "launch" below = one ROUND of it (10 sweeps of every chain + the in-kernel swap round;
             # events around every chunk launch, divided by its rounds)
@@ -408,6 +412,7 @@ def main():
             "seconds_timed": dt, "ms_per_round": dt / tr * 1e3,
             "value_kernel_loop": (upd_launch / sec_launch / launches_per_round) * world if ms_launch > 0 else None,
             "kernel": kernel, "us_per_launch": ms_launch * 1e3, "rounds_in_persistent_launches": r["persistent_rounds"],
+            "rounds_with_swap_in_the_sweep_launch": r["deferred_rounds"],
             "sweep_launches": tm["launches_sweep"], "sweep_launches_with_events": tm["launches_timed"],
             "ms_levelize": tm["ms_levelize"], "ms_sweep_kernels": ms_launch * tm["launches_sweep"],
             "plan_chunks_in_timed_region": r["chunks"],
