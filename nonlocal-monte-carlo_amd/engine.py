@@ -46,6 +46,8 @@ def _beta_table(beta, R, S):
     if b.ndim == 2:
         if b.shape != (R, S):
             raise ValueError("beta table must be [n_chains, n_sweeps]")
+        if S > 1 and (b == b[:, :1]).all():         # one temperature per chain: the kernels' plain variants (stride 0 over sweeps)
+            return np.ascontiguousarray(b[:, 0]), 1, 0
         return np.ascontiguousarray(b), S, 1
     raise ValueError("pass a scalar or a 2-D table; use per_chain()/per_sweep() helpers for 1-D inputs")
 

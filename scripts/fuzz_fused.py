@@ -1,6 +1,7 @@
 """Randomised differential test of the fused-window kernels against the sweep-by-sweep kernels (which the oracle tests
 pin): random graphs (degree mixes incl. hubs and isolated spins), the three schedule entry formats (+-J / small integers /
-Gaussian), integer or real fields, self-couplings, phase flags, with and without per-sweep outputs.  Same bits or it
+Gaussian), integer or real fields, self-couplings, phase flags, with and without per-sweep outputs, both arithmetic modes (the
+fp64 mode fuses on +-J / integer instances only; on some of those cases the test knob NLMC_F64_TIE_MASK widens its exact path).  Same bits or it
 prints the failing case.  CASES (default 60), SEED."""
 import os, sys
 import numpy as np
@@ -39,7 +40,15 @@ for case in range(CASES):
     use_flags, outs = rng.random() < 0.4, rng.random() < 0.5
     flags = rng.choice([0, 0, 0, 1, 2, 3], size=(R, n)).astype(np.uint8) if use_flags else None
     beta = np.repeat(np.geomspace(0.2, 2.5, R)[:, None], T * W, axis=1)
+    per_sweep = rng.random() < 0.4                             # a temperature per sweep (fp64 mode: runs sweep by sweep then)
+    if per_sweep:
+        beta = beta * np.linspace(0.5, 1.0, T * W)[None, :]
     inst = P.Instance(A, h)
+    prec = "f64" if (kind != "gauss" and rng.random() < 0.5) else "f32"
+    tie = str(rng.choice(["", "", "0xFFFF0000", "0"])) if prec == "f64" else ""
+    os.environ.pop("NLMC_F64_TIE_MASK", None)
+    if tie:
+        os.environ["NLMC_F64_TIE_MASK"] = tie                  # read at Engine creation
     res = []
     for fused in (True, False):
         with P.Engine(inst, None, R) as eng:
@@ -49,11 +58,11 @@ for case in range(CASES):
             planned = eng.plan_philox_fused(0, W, T, 99) if fused else 0
             kw = dict(record_stride=2, want_energy=True, want_min=True, want_state=True) if outs else {}
             if outs:
-                o = eng.sweep_philox(T * W, 99, sweep0=0, beta=beta, **kw)
+                o = eng.sweep_philox(T * W, 99, sweep0=0, beta=beta, precision=prec, **kw)
             else:
                 o = None
                 for w in range(W):
-                    eng.sweep_philox(T, 99, sweep0=w * T, beta=beta[:, :T])
+                    eng.sweep_philox(T, 99, sweep0=w * T, beta=beta[:, w * T:(w + 1) * T], precision=prec)
             res.append((eng.get_spins(), eng.energy_tracked(), o, planned, eng.last_schedule_stats()["orders"]))
     a, b = res
     ok = np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
@@ -61,7 +70,7 @@ for case in range(CASES):
         ok = ok and all(np.array_equal(a[2][k], b[2][k]) for k in ("spins", "energy", "min_energy", "argmin", "argmin_state"))
     used = a[3] == W and a[4] == T
     print(f"case {case}: n={n} deg~{mean_deg} {kind} diag={diag} h={'int' if h.any() and kind != 'gauss' else ('real' if h.any() else '0')} "
-          f"R={R} T={T} W={W} flags={use_flags} outs={outs} fused_used={used} -> {'ok' if ok else 'MISMATCH'}", flush=True)
+          f"{prec}{'/tie=' + tie if tie else ''} R={R} T={T} W={W} temps={'per-sweep' if per_sweep else 'per-chain'} flags={use_flags} outs={outs} fused_used={used} -> {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += not ok
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
