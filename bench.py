@@ -7,8 +7,8 @@ With N > 1 and no torch.distributed environment this script starts `python -m to
 bench.py ...` itself as a CHILD process (before anything touches the GPU) and exits with the child's code; launched by
 torch.distributed.run it is one rank per GPU over RCCL.
 
-A "step" is ROUNDS_PER_STEP = 4096 replica-exchange rounds of NPT (~0.5 s of GPU time: the driver's --steps 20 times ~10 s
-per leg, the default 4 steps 2 s); a round is S_SWAP = 10 heat-bath sweeps of every replica at its ladder temperature
+A "step" is ROUNDS_PER_STEP = 5120 replica-exchange rounds of NPT (~0.6 s of GPU time: the driver's --steps 20 times ~12 s
+per leg, the default 4 steps 2.4 s); a round is S_SWAP = 10 heat-bath sweeps of every replica at its ladder temperature
 followed by one swap-attempt round.  TWO legs of equal standing run with the same --steps / --warmup, GPU work first, CPU
 baselines last: the headline leg in the reference's arithmetic (fp64 field, 53-bit uniform: NMC/nmc.py:86-87 -- the "f64"
 mode, on fused windows because the +-J instance makes the fp64 field an exact integer, bit-identical to the sweep-by-sweep
@@ -47,8 +47,8 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 N_SPINS = 10_000
 REPLICAS_PER_GPU = 256
 S_SWAP = 10
-ROUNDS_PER_STEP = int(os.environ.get("NLMC_BENCH_ROUNDS_PER_STEP", "4096"))   # (the override is for the profiler passes of scripts/profile_round.sh)
-# 4096 rounds x ~0.125 ms: a step is ~0.5 s, the driver's --steps 20 times ~10 s per leg (VERDICT r3 #1c)
+ROUNDS_PER_STEP = int(os.environ.get("NLMC_BENCH_ROUNDS_PER_STEP", "5120"))   # (the override is for the profiler passes of scripts/profile_round.sh)
+# 5120 rounds x ~0.116 ms: a step is ~0.6 s, the driver's --steps 20 times ~12 s per leg (VERDICT r3 #1c)
 EVENT_EVERY = int(os.environ.get("NLMC_BENCH_EVENT_EVERY", "8"))   # HIP events around every 8th sweep-kernel launch of the timed region
 PLAN_CHUNK_ROUNDS = 256      # rounds whose schedules are built together (one workgroup per window: fills the chip)
 BETA_MIN, BETA_MAX = 0.05, 4.0
