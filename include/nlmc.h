@@ -42,7 +42,11 @@ enum { NLMC_ORDER_SHARED = 0, NLMC_ORDER_PER_CHAIN = 1 }; /* one permutation per
 /* phase flags, one byte per (chain, spin): caller contract of NMC/nmc.py:377-381,398-401 */
 enum { NLMC_SPIN_NORMAL = 0, NLMC_SPIN_SCALED = 1, NLMC_SPIN_FROZEN_UP = 2, NLMC_SPIN_FROZEN_DOWN = 3 };
 
-#define NLMC_MAX_N 24576 /* spins per chain this build keeps in LDS */
+#define NLMC_LDS_N 24576    /* up to here a chain's spins live in LDS (the fast kernels); longer chains keep them in global memory:
+                             * sweeps (all three modes), energies, traces and replica exchange work at any size, with the same
+                             * results spin for spin; the fused windows, the Houdayer kernels and the cluster-mask kernel do not
+                             * (NLMC_ERR_UNSUPPORTED / a failed launch reported as NLMC_ERR_HIP -- never a wrong result) */
+#define NLMC_MAX_N 16777216 /* spins per chain (32-bit positions of the schedules, counters of the level histogram) */
 
 /* Version of this interface; nlmc_abi_version() returns the value the library was built with and the binding refuses a
  * library whose value differs.  2 (round 3): nlmc_timing_total has a fifth out-pointer and nlmc_timing_reset's argument is

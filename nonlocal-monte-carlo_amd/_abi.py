@@ -17,7 +17,8 @@ OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4
 F32, F64 = 0, 1
 ORDER_SHARED, ORDER_PER_CHAIN = 0, 1
 SPIN_NORMAL, SPIN_SCALED, SPIN_FROZEN_UP, SPIN_FROZEN_DOWN = 0, 1, 2, 3
-MAX_N = 24576
+LDS_N = 24576          # chains up to this length live in LDS (include/nlmc.h: NLMC_LDS_N)
+MAX_N = 16777216
 ABI_VERSION = 3                      # include/nlmc.h: NLMC_ABI_VERSION
 CHAINS_ALL, CHAINS_UNMARKED, CHAINS_MARKED = 0, 1, 2
 PHASE_ALL, PHASE_BACKBONE_HOT, PHASE_BACKBONE_FROZEN = 0, 1, 2

@@ -6,6 +6,7 @@
 #include "nlmc_lbp.h"
 #include "nlmc_nmc.h"
 #include "nlmc_probe.h"
+#include "nlmc_big.h"
 #include "nlmc_host.h"
 
 #include <dlfcn.h>
@@ -129,6 +130,19 @@ struct nlmc_ctx {
         DevBuf<int32_t> lvl_off, nlev, hi_max, ellc64;
         DevBuf<EdgeQ> ell32;
         DevBuf<double> ellv64, headh64;
+        DevBuf<uint32_t> bkey, bcur;      // chains too long for LDS (csrc/nlmc_big.h): the levelizer's keys / cursors
+        DevBuf<int32_t> blvl;
+        hipError_t reserve_big(size_t orders, size_t n, bool philox_keys)
+        {
+            hipError_t e;
+            if ((e = order.reserve(orders * n)) != hipSuccess) return e;
+            if ((e = lvl_off.reserve(orders * (n + 1))) != hipSuccess) return e;
+            if ((e = nlev.reserve(orders)) != hipSuccess) return e;
+            if ((e = hi_max.reserve(orders)) != hipSuccess) return e;
+            if (philox_keys && (e = bkey.reserve(orders * n)) != hipSuccess) return e;
+            if ((e = blvl.reserve(orders * n)) != hipSuccess) return e;
+            return bcur.reserve(orders * (n + 2));
+        }
         hipError_t reserve(size_t orders, size_t n, int mode /*0 none, 1 f32, 2 f64*/)
         {
             hipError_t e;
@@ -146,9 +160,11 @@ struct nlmc_ctx {
             }
             return hipSuccess;
         }
-        void release() { order.release(); head32.release(); lvl_off.release(); nlev.release(); hi_max.release(); ellc64.release(); ell32.release(); ellv64.release(); headh64.release(); }
+        void release() { order.release(); head32.release(); lvl_off.release(); nlev.release(); hi_max.release(); ellc64.release(); ell32.release(); ellv64.release(); headh64.release(); bkey.release(); bcur.release(); blvl.release(); }
     };
     Sched scratch, plan;
+    bool big = false;                    // n > NLMC_LDS_N: every sweep runs the global-memory kernels of csrc/nlmc_big.h
+    bool plan_big = false;               // the cached plan was built by k_levelize_big (its items are { k, row start })
     int plan_precision = 0;
     bool plan_valid = false;
     int plan_mode = 0;
@@ -332,6 +348,14 @@ int level_block(int n)
     return std::min(1024, std::max(64, nt));
 }
 
+// (chains too long for LDS: read in place, csrc/nlmc_big.h)
+void launch_energy(nlmc_ctx *c, unsigned count, hipStream_t st, const EnergyArgs &a)
+{
+    const dim3 nt(c->n >= 4096 ? 1024 : 256);          // (the partial sums are per thread: one width for both variants)
+    if (c->big) hipLaunchKernelGGL(k_energy<true>, dim3(count), nt, 0, st, a);
+    else hipLaunchKernelGGL(k_energy<false>, dim3(count), nt, (size_t)c->n_pad, st, a);
+}
+
 // energies of the context's own chains -> efix (+ optional double output on device)
 int launch_energy_self(nlmc_ctx *c, double *dev_out)
 {
@@ -342,8 +366,7 @@ int launch_energy_self(nlmc_ctx *c, double *dev_out)
     a.out = dev_out;
     a.efix = c->efix.p;
     a.escale = c->escale;
-    if (c->n_chains > 0)
-        hipLaunchKernelGGL(k_energy, dim3(c->n_chains), dim3(c->n >= 4096 ? 1024 : 256), (size_t)c->n_pad, c->stream, a);
+    if (c->n_chains > 0) launch_energy(c, (unsigned)c->n_chains, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return NLMC_OK;
 }
@@ -352,6 +375,18 @@ int run_levelize(nlmc_ctx *c, int n_orders, const uint32_t *keys_in, int per_cha
                  uint64_t seed, nlmc_ctx::Sched &sc, int ell_mode)
 {
     if (n_orders <= 0) return NLMC_OK;
+    if (ell_mode < 0) {            // spins in global memory (csrc/nlmc_big.h); sc was reserved with reserve_big
+        BigLevelizeArgs b{};
+        b.g = c->g;
+        b.keys_in = keys_in;
+        b.seed_lo = (uint32_t)seed; b.seed_hi = (uint32_t)(seed >> 32); b.sweep0 = sweep0;
+        b.per_chain = per_chain; b.n_sweeps = n_sweeps; b.chain_base = c->chain_base;
+        b.key = sc.bkey.p; b.lvl = sc.blvl.p; b.cur = sc.bcur.p;
+        b.ord2 = sc.order.p; b.lvl_off = sc.lvl_off.p; b.nlev = sc.nlev.p; b.hi_max = sc.hi_max.p;
+        hipLaunchKernelGGL(k_levelize_big, dim3(n_orders), dim3(1024), 0, c->cur, b);
+        HIP_TRY(c, hipGetLastError());
+        return NLMC_OK;
+    }
     LevelizeArgs a{};
     a.g = c->g;
     a.n_orders = n_orders;
@@ -448,7 +483,7 @@ int fused_gen0(int nt)
 // uniform tables next to the spins in LDS (flags counted in: they may be switched on later).
 bool fused_supported(const nlmc_ctx *c, int T)
 {
-    if (getenv("NLMC_NO_FUSED")) return false;
+    if (getenv("NLMC_NO_FUSED") || c->big) return false;
     if (c->n < 256 || c->n > NLMC_FZ_SPT * 1024 || c->max_deg > 0x3FFF || T < 3 || T > NLMC_FUSED_TMAX) return false;
     if ((size_t)T * ((size_t)c->n + c->n_long) > ((size_t)1 << 22)) return false;   // 32-bit buffer offsets of the packed planes
     if (c->n_pad + 16 > 0x3FFF) return false;                          // spin address in 14 bits of the item head
@@ -686,6 +721,16 @@ int fused_plan_for(const nlmc_ctx *c, uint32_t sweep0, int n_sweeps, uint64_t se
     return -1;
 }
 
+// Chains whose state does not fit in LDS next to what the mode keeps there run the kernels of csrc/nlmc_big.h.  The LDS need is
+// taken at its worst (phase flags on, one copy of the uniforms), so that the answer does not change during a context's life: a
+// cached plan is in the format of the levelizer that goes with the answer.
+bool sweeps_big(const nlmc_ctx *c, bool stream_mode, bool f64)
+{
+    if (c->big) return true;
+    const size_t n4 = ((size_t)c->n + 3) / 4 * 4, u_bytes = stream_mode ? 0 : n4 * (f64 ? 8 : 4);
+    return 2 * (size_t)c->n_pad + 32 + u_bytes + (size_t)NLMC_LCAP * 4 + 32 > (size_t)158 * 1024;
+}
+
 // Shared driver: windows of sweeps -> (levelize) -> k_sweep.  `stream_mode` selects the kernel flavour.
 int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int n_sweeps, uint32_t sweep0,
                uint64_t seed, const double *tab_dev, int tab_cs, int tab_ss, bool use_slots, const uint32_t *keys_dev,
@@ -760,23 +805,25 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
     if (per_chain && c->subset != 0) return fail(c, NLMC_ERR_UNSUPPORTED, "chain subsets run shared-order philox sweeps only");
     // plan cache hit?
     const bool f64 = stream_mode || precision == NLMC_F64;
-    const int ell_mode = stream_mode ? 0 : (f64 ? 2 : 1);
-    const bool cached = !stream_mode && c->plan_valid && c->plan_mode == order_mode && c->plan_seed == seed &&
+    const bool big = sweeps_big(c, stream_mode, f64);      // spins stay in global memory (csrc/nlmc_big.h)
+    const int ell_mode = big ? -1 : stream_mode ? 0 : (f64 ? 2 : 1);
+    const bool cached = !stream_mode && c->plan_valid && c->plan_mode == order_mode && c->plan_seed == seed && c->plan_big == big &&
                         c->plan_precision == precision && !per_chain && sweep0 >= c->plan_sweep0 &&
                         (uint64_t)sweep0 + (uint64_t)n_sweeps <= (uint64_t)c->plan_sweep0 + (uint64_t)c->plan_count;
     // window size: keep the schedule scratch under ~256 MiB
     const size_t per_sweep_orders = per_chain ? (size_t)R : 1;
-    const size_t item_bytes = ell_mode == 1 ? 8 + 8 + 8 * NLMC_ELL_W32 : (ell_mode == 2 ? 8 + 8 + 12 * NLMC_ELL_W : 8);
+    const size_t item_bytes = big ? 8 + 12 : ell_mode == 1 ? 8 + 8 + 8 * NLMC_ELL_W32 : (ell_mode == 2 ? 8 + 8 + 12 * NLMC_ELL_W : 8);
     const size_t bytes_per_sweep = per_sweep_orders * ((size_t)n * item_bytes + (size_t)(n + 1) * 4 + 4);
     int W = n_sweeps;
     if (!cached) {
         // stream mode indexes its uniforms/keys by (chain, sweep) over the WHOLE call -> single window there
         if (!stream_mode) W = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_sweeps, ((size_t)256 << 20) / bytes_per_sweep));
         const size_t orders = per_sweep_orders * (size_t)W;
-        HIP_TRY(c, c->scratch.reserve(orders, (size_t)n, ell_mode));
+        if (big) HIP_TRY(c, c->scratch.reserve_big(orders, (size_t)n, !stream_mode));
+        else HIP_TRY(c, c->scratch.reserve(orders, (size_t)n, ell_mode));
     }
 
-    const int nt = sweep_block_for(n, !stream_mode && f64, !stream_mode && !f64 && c->has_diag);
+    const int nt = big ? 1024 : sweep_block_for(n, !stream_mode && f64, !stream_mode && !f64 && c->has_diag);
     // LDS carve-up: spins | flags | uniforms of one sweep (philox) | level offsets (philox) | reduction scratch
     const int lds_flags_off = c->n_pad;
     int cur = c->n_pad * (c->has_flags ? 2 : 1);
@@ -800,7 +847,7 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
                              : (c->has_diag ? reinterpret_cast<const void *>(k_sweep_philox<float, true>)
                                             : reinterpret_cast<const void *>(k_sweep_philox<float, false>));
     const int kslot = stream_mode ? 2 : (f64 ? (c->f64_pack16 ? 22 : 3) : 5) + (c->has_diag ? 1 : 0);
-    { int rc = ensure_lds(c, kslot, kfun, lds); if (rc) return rc; }
+    if (!big) { int rc = ensure_lds(c, kslot, kfun, lds); if (rc) return rc; }
 
     for (int t0 = 0; t0 < n_sweeps; t0 += W) {
         const int w = std::min(W, n_sweeps - t0);
@@ -874,7 +921,13 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         a.lds_u_stride = dbuf ? u_bytes : 0;
         a.lds_loff_stride = dbuf ? NLMC_LCAP * 4 : 0;
         a.lds_flags_off = lds_flags_off; a.lds_u_off = lds_u_off; a.lds_loff_off = lds_loff_off; a.lds_red_off = lds_red_off;
-        if (stream_mode)
+        if (big && stream_mode)
+            hipLaunchKernelGGL(k_sweep_big<NLMC_BIG_STREAM>, dim3(R), dim3(nt), 0, c->cur, a);
+        else if (big && f64)
+            hipLaunchKernelGGL(k_sweep_big<NLMC_BIG_F64>, dim3(R), dim3(nt), 0, c->cur, a);
+        else if (big)
+            hipLaunchKernelGGL(k_sweep_big<NLMC_BIG_F32>, dim3(R), dim3(nt), 0, c->cur, a);
+        else if (stream_mode)
             hipLaunchKernelGGL(k_sweep_stream, dim3(R), dim3(nt), lds, c->cur, a);
         else if (f64 && c->f64_pack16 && c->has_diag)
             hipLaunchKernelGGL((k_sweep_philox<double, true, true>), dim3(R), dim3(nt), lds, c->cur, a);
@@ -1004,7 +1057,7 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
     if (n < 1 || nnz < 0 || !rowptr || (nnz > 0 && (!colidx || !vals)) || !h || n_chains < 0 || chain_base < 0 ||
         n_chains_global < chain_base + n_chains)
         return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: bad sizes or NULL arrays");
-    if (n > NLMC_MAX_N) return fail(nullptr, NLMC_ERR_UNSUPPORTED, "nlmc_create: n exceeds NLMC_MAX_N (spins are LDS-resident)");
+    if (n > NLMC_MAX_N) return fail(nullptr, NLMC_ERR_UNSUPPORTED, "nlmc_create: n exceeds NLMC_MAX_N");
     if (rowptr[0] != 0 || rowptr[n] != nnz) return fail(nullptr, NLMC_ERR_ARG, "nlmc_create: rowptr[0] != 0 or rowptr[n] != nnz");
     bool diag = false, zero_vals = false;
     int max_deg = 0, n_long = 0;
@@ -1031,6 +1084,7 @@ int nlmc_create(nlmc_ctx **out, int device, void *hip_stream, int n, int64_t nnz
     c->stream = reinterpret_cast<hipStream_t>(hip_stream);
     c->cur = c->stream;
     c->n = n;
+    c->big = n > NLMC_LDS_N || getenv("NLMC_FORCE_BIG") != nullptr;      // (the knob: tests compare the two sets of kernels at one size)
     c->n_pad = (n + 15) / 16 * 16;
     c->nnz = nnz;
     c->n_chains = n_chains;
@@ -1316,7 +1370,7 @@ int nlmc_energy_of(nlmc_ctx *c, const int8_t *spins, int64_t count, double *out)
         HIP_TRY(c, hipMemcpyAsync(c->cfg.p, spins + b * c->n, (size_t)m * c->n, hipMemcpyHostToDevice, c->stream));
         EnergyArgs a{};
         a.g = c->g; a.spins = c->cfg.p; a.stride = c->n; a.out = c->etrace_d.p; a.efix = nullptr; a.escale = c->escale;
-        hipLaunchKernelGGL(k_energy, dim3((unsigned)m), dim3(c->n >= 4096 ? 1024 : 256), (size_t)c->n_pad, c->stream, a);
+        launch_energy(c, (unsigned)m, c->stream, a);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipMemcpyAsync(out + b, c->etrace_d.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1336,7 +1390,7 @@ int nlmc_energy_of_recorded(nlmc_ctx *c, int first, int count, double *out)
     EnergyArgs a{};
     a.g = c->g; a.spins = c->strace.p + (size_t)first * c->n; a.stride = c->n; a.stride_outer = (int64_t)c->strace_nrec * c->n;
     a.inner = count; a.out = c->etrace_d.p; a.efix = nullptr; a.escale = c->escale;
-    hipLaunchKernelGGL(k_energy, dim3((unsigned)m), dim3(c->n >= 4096 ? 1024 : 256), (size_t)c->n_pad, c->cur, a);
+    launch_energy(c, (unsigned)m, c->cur, a);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(out, c->etrace_d.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, c->cur));
     HIP_TRY(c, hipStreamSynchronize(c->cur));
@@ -1371,9 +1425,15 @@ int nlmc_sweep_stream(nlmc_ctx *c, int n_sweeps, const int32_t *perm, const doub
     HIP_TRY(c, hipMemcpyAsync(c->perm_raw.p, perm, sizeof(int32_t) * tot * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->u_raw.p, u, sizeof(double) * tot * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->tab.p, tab.data(), sizeof(double) * tot, hipMemcpyHostToDevice, c->stream));
-    { int rc = ensure_lds(c, 8, reinterpret_cast<const void *>(k_stream_scatter), (size_t)n * 4); if (rc) return rc; }
-    hipLaunchKernelGGL(k_stream_scatter, dim3((unsigned)tot), dim3(256), (size_t)n * 4, c->stream, n, c->perm_raw.p, c->u_raw.p, c->keys.p,
-                       c->ustream.p, c->stream_bad.p);
+    if (c->big || (size_t)n * 4 > (size_t)150 * 1024) {       // (the seen-marks of k_stream_scatter live in LDS)
+        HIP_TRY(c, hipMemsetAsync(c->keys.p, 0xFF, sizeof(uint32_t) * tot * n, c->stream));
+        hipLaunchKernelGGL(k_stream_scatter_big, dim3((unsigned)tot), dim3(1024), 0, c->stream, n, c->perm_raw.p, c->u_raw.p, c->keys.p,
+                           c->ustream.p, c->stream_bad.p);
+    } else {
+        { int rc = ensure_lds(c, 8, reinterpret_cast<const void *>(k_stream_scatter), (size_t)n * 4); if (rc) return rc; }
+        hipLaunchKernelGGL(k_stream_scatter, dim3((unsigned)tot), dim3(256), (size_t)n * 4, c->stream, n, c->perm_raw.p, c->u_raw.p, c->keys.p,
+                           c->ustream.p, c->stream_bad.p);
+    }
     HIP_TRY(c, hipGetLastError());
     int32_t bad = 0;
     HIP_TRY(c, hipMemcpyAsync(&bad, c->stream_bad.p, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
@@ -1453,8 +1513,10 @@ int nlmc_plan_philox(nlmc_ctx *c, int precision, int order_mode, uint32_t sweep0
     HIP_TRY(c, hipSetDevice(c->device));
     c->plan_valid = false;
     if (n_sweeps == 0) return NLMC_OK;
-    const int ell_mode = precision == NLMC_F64 ? 2 : 1;
-    HIP_TRY(c, c->plan.reserve((size_t)n_sweeps, (size_t)c->n, ell_mode));
+    const bool big = sweeps_big(c, false, precision == NLMC_F64);
+    const int ell_mode = big ? -1 : precision == NLMC_F64 ? 2 : 1;
+    if (big) HIP_TRY(c, c->plan.reserve_big((size_t)n_sweeps, (size_t)c->n, true));
+    else HIP_TRY(c, c->plan.reserve((size_t)n_sweeps, (size_t)c->n, ell_mode));
     hipEvent_t pe0 = nullptr, pe1 = nullptr, pe2 = nullptr;      // planning time -> levelize time of nlmc_timing_total
     if (c->ev_accumulate) {
         pe0 = next_event(c); pe1 = next_event(c); pe2 = next_event(c);
@@ -1466,6 +1528,7 @@ int nlmc_plan_philox(nlmc_ctx *c, int precision, int order_mode, uint32_t sweep0
     if (rc) return rc;
     if (pe0) HIP_TRY(c, hipEventRecord(pe2, c->stream));
     c->plan_valid = true;
+    c->plan_big = big;
     c->plan_mode = order_mode;
     c->plan_precision = precision;
     c->plan_sweep0 = sweep0;

@@ -2404,17 +2404,24 @@ struct EnergyArgs {
     int escale;
 };
 
+// IN_PLACE: the configuration is read where it lies in global memory (chains too long for LDS, csrc/nlmc_big.h) -- the same sums
+// in the same order.
+template <bool IN_PLACE = false>
 __global__ void k_energy(EnergyArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ double part[16];
     const int n = a.g.n;
-    int8_t *s = reinterpret_cast<int8_t *>(lds_raw);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int8_t *src = a.inner > 0 ? a.spins + (size_t)(blockIdx.x / a.inner) * a.stride_outer + (size_t)(blockIdx.x % a.inner) * a.stride
                                     : a.spins + (size_t)blockIdx.x * a.stride;
-    for (int i = tid; i < n; i += nt) s[i] = src[i];
-    __syncthreads();
+    const int8_t *s = src;
+    if constexpr (!IN_PLACE) {
+        int8_t *sl = reinterpret_cast<int8_t *>(lds_raw);
+        for (int i = tid; i < n; i += nt) sl[i] = src[i];
+        __syncthreads();
+        s = sl;
+    }
     // Four rows per thread at a time, the first 8 entries of each fetched unconditionally (padded arrays): 64
     // independent loads in flight instead of a rowptr -> entry -> entry chain per row.  The association of every sum
     // is the plain row-by-row, entry-by-entry one (a skipped slot leaves x untouched).

@@ -1,0 +1,174 @@
+"""Chains too long for LDS (csrc/nlmc_big.h; the reference takes any N, NMC/nmc.py:49-53): the global-memory kernels against
+the oracle at sizes only they take (N = 30 000 and 70 000: spin indices past 16 bits) and, forced on at a small size (the knob
+NLMC_FORCE_BIG, read when a context is created), against the LDS kernels on everything a sweep call can return.
+
+Bars as in test_gpu_sweep.py: spins bit-exact, philox-mode energies bit-exact, stream-mode energies within 1e-10."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+from helpers import make_instance, init_spins, draw_stream
+
+pytestmark = pytest.mark.gpu
+E_RTOL = 1e-10
+
+
+def assert_energy(a, b, rtol=E_RTOL):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    assert a.shape == b.shape
+    assert np.all(np.abs(a - b) <= rtol * np.maximum(1.0, np.abs(b))), np.max(np.abs(a - b))
+
+
+def big_instance(n, seed, gaussian=False, diag=False):
+    """ring + random chords (mean degree ~6), a few hub rows, optionally self-couplings"""
+    r = np.random.default_rng(seed)
+    i = np.concatenate([np.arange(n), r.integers(0, n, 2 * n), np.full(40, 7), np.full(25, n - 3)])
+    j = np.concatenate([(np.arange(n) + 1) % n, r.integers(0, n, 2 * n), r.integers(0, n, 40), r.integers(0, n, 25)])
+    keep = i != j
+    A = sp.coo_matrix((np.ones(keep.sum()), (i[keep], j[keep])), shape=(n, n)).tocsr()
+    A = sp.triu(((A + A.T) > 0).astype(np.float64), 1).tocsr()
+    A.data = r.normal(0, 1, A.nnz) if gaussian else r.choice([-1.0, 1.0], A.nnz)
+    A = (A + A.T).tolil()
+    if diag:
+        for k in r.choice(n, 30, replace=False):
+            A[k, k] = r.normal() if gaussian else r.choice([-1.0, 1.0])
+    A = A.tocsr()
+    A.sort_indices()
+    h = r.normal(0, 0.3, n) if gaussian else r.integers(-1, 2, n).astype(float)
+    return A, h
+
+
+@pytest.mark.parametrize("n,gaussian,diag", [(30_000, True, True), (70_000, False, False)])
+def test_stream_mode_of_long_chains_matches_the_oracle(product, n, gaussian, diag):
+    J, h = big_instance(n, 11, gaussian, diag)
+    R, S = 3, 3
+    csr = oracle.Csr(J)
+    m0 = init_spins(R, n)
+    np.random.seed(5)
+    perm, u = draw_stream(R, S, n)
+    betas = np.array([0.4, 1.1, 2.5])
+    with product.Engine(J, h, R) as eng:
+        eng.set_spins(m0)
+        assert_energy(eng.energy(), [oracle.energy(csr, h, m0[c].astype(float)) for c in range(R)])
+        o = eng.sweep_stream(perm, u, np.repeat(betas[:, None], S, axis=1), record_stride=1, want_energy=True, want_min=True,
+                             want_state=True)
+        final = eng.get_spins()
+        assert_energy(eng.energy_tracked(), eng.energy())
+        bad = perm.copy()
+        bad[1, 2, 5] = bad[1, 2, 6]
+        with pytest.raises(ValueError):
+            eng.sweep_stream(bad, u, np.repeat(betas[:, None], S, axis=1))
+    for c in range(R):
+        M, _ = oracle.sweeps_stream(csr, h, m0[c].astype(float), np.full(S, betas[c]), perm[c], u[c])
+        assert np.array_equal(o["spins"][c], M), c
+        assert np.array_equal(final[c], M[-1])
+        E = np.array([oracle.energy(csr, h, M[t]) for t in range(S)])
+        assert_energy(o["energy"][c], E)
+        assert o["argmin"][c] == int(np.argmin(o["energy"][c])) and np.array_equal(o["argmin_state"][c], M[o["argmin"][c]])
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+@pytest.mark.parametrize("order", ["shared", "per_chain"])
+def test_philox_modes_of_long_chains_match_the_oracle(product, precision, order):
+    n = 30_000 if order == "shared" else 66_000
+    J, h = big_instance(n, 3, gaussian=(precision == "f64"), diag=(order == "shared"))
+    R, S = 3, 3
+    csr = oracle.Csr(J)
+    m0 = init_spins(R, n)
+    betas = np.array([0.3, 1.0, 2.2])
+    seed, sweep0, f64 = 0x1234 + (5 << 32), 9, precision == "f64"
+    flags = np.zeros((R, n), np.uint8)
+    cl = np.random.default_rng(1).random(n) < 0.1
+    flags[1, cl] = 1
+    flags[1, ~cl] = np.where(m0[1, ~cl] > 0, 2, 3)
+    with product.Engine(J, h, R, chain_base=2, n_chains_global=R + 2) as eng:
+        eng.set_spins(m0)
+        eng.set_flags(flags, 20.0)
+        E0 = eng.energy()
+        esc = eng.energy_scale
+        o = eng.sweep_philox(S, seed, sweep0=sweep0, beta=np.repeat(betas[:, None], S, axis=1), precision=precision, order=order,
+                             record_stride=1, want_energy=True, want_min=True, want_state=True)
+        # the same sweeps from a cached plan, in two calls
+        eng.set_spins(m0)
+        if order == "shared":
+            eng.plan_philox(sweep0, S, seed, precision=precision)
+        eng.sweep_philox(1, seed, sweep0=sweep0, beta=betas[:, None], precision=precision, order=order)
+        eng.sweep_philox(S - 1, seed, sweep0=sweep0 + 1, beta=np.repeat(betas[:, None], S - 1, axis=1), precision=precision, order=order)
+        again = eng.get_spins()
+    for c in range(R):
+        gc = c + 2
+        cb = np.tile(np.array(oracle.cb_pair(betas[c], 20.0, f64)), (S, 1))
+        M, s_fin, tr = oracle.sweeps_philox(csr, h, m0[c], cb, seed, gc, order_group=(gc + 1 if order == "per_chain" else 0),
+                                            sweep0=sweep0, flags=flags[c], escale=esc, use_f64=f64, efix0=int(np.rint(E0[c] * 2.0 ** esc)))
+        assert np.array_equal(o["spins"][c], M), c
+        assert np.array_equal(again[c], s_fin)
+        assert np.array_equal(o["energy"][c], tr.astype(np.float64) * 2.0 ** -esc)
+        assert o["argmin"][c] == int(np.argmin(tr)) and np.array_equal(o["argmin_state"][c], M[int(np.argmin(tr))])
+
+
+def test_global_memory_kernels_equal_the_lds_kernels_at_a_size_both_take(product, monkeypatch):
+    """NLMC_FORCE_BIG: stream and both philox modes, per-chain temperatures, phase flags, a self-coupling, recorded
+    configurations with a stride, energy trace, running minimum with its state, a replica-exchange ladder in between."""
+    J, h = make_instance(700, seed=8, with_h=True, gaussian=True)
+    J = J.tolil(); J[5, 5] = 0.5; J[40, 40] = -1.25; J = J.tocsr(); J.sort_indices()
+    R, S, N = 6, 7, 700
+    m0 = init_spins(R, N)
+    np.random.seed(3)
+    perm, u = draw_stream(R, S, N)
+    beta = np.repeat(np.geomspace(0.2, 3.0, R)[:, None], S, axis=1) * np.linspace(0.6, 1.0, S)[None, :]
+    flags = np.random.default_rng(2).choice([0, 0, 0, 1, 2, 3], size=(R, N)).astype(np.uint8)
+
+    def run():
+        out = []
+        with product.Engine(J, h, R) as eng:
+            eng.set_spins(m0)
+            out.append(eng.energy())
+            out.append(eng.sweep_stream(perm, u, beta, record_stride=2, want_energy=True, want_min=True, want_state=True))
+            eng.set_flags(flags, 7.0)
+            out.append(eng.sweep_stream(perm, u, beta, record_stride=1, want_energy=True))
+            for prec in ("f32", "f64"):
+                for order in ("shared", "per_chain"):
+                    out.append(eng.sweep_philox(S, 17, sweep0=3, beta=beta, precision=prec, order=order, record_stride=3,
+                                                want_energy=True, want_min=True, want_state=True))
+            eng.set_flags(np.zeros((R, N), np.uint8), 1.0)
+            eng.pt_init(np.geomspace(0.2, 3.0, R))
+            for rnd in range(4):
+                out.append(eng.sweep_philox(3, 17, sweep0=100 + 3 * rnd, beta=None, precision="f64", want_energy=True))
+                out.append(eng.pt_swap_philox(rnd, 17, 2))
+            out.append(eng.pt_slots())
+            out.append(eng.get_spins())
+            out.append(eng.energy_tracked())
+            out.append(eng.energy_of(m0))
+        return out
+
+    monkeypatch.delenv("NLMC_FORCE_BIG", raising=False)
+    a = run()
+    monkeypatch.setenv("NLMC_FORCE_BIG", "1")
+    b = run()
+
+    def same(x, y):
+        if isinstance(x, dict):
+            return all(same(x[k], y[k]) for k in x)
+        if isinstance(x, (tuple, list)):
+            return len(x) == len(y) and all(same(p, q) for p, q in zip(x, y))
+        return np.array_equal(np.asarray(x), np.asarray(y))
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert same(x, y), i
+
+
+def test_drop_in_classes_on_a_long_chain(product):
+    """NMC.MCMC and NPT.run at N = 26 000 (past the LDS kernels) in the default numpy mode against the oracle's restatement of
+    the reference classes on the same random streams."""
+    from oracle import refport
+    n = 26_000
+    J, h = big_instance(n, 21)
+    Jd = J.tocsr()
+    np.random.seed(4)
+    m0 = np.sign(np.random.rand(n) - 0.5)
+    obj = product.NMC(Jd, h.copy())
+    np.random.seed(9)
+    M = obj.MCMC(3, m0.copy(), 1.3, Jd, h)
+    np.random.seed(9)
+    Mr = refport.mcmc(3, m0.copy(), 1.3, oracle.Csr(J), h)
+    assert np.array_equal(np.asarray(M), Mr)

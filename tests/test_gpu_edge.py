@@ -99,26 +99,27 @@ def test_zero_sweeps_and_record_stride(product):
 
 
 def test_size_limits(product):
-    n = product._abi.MAX_N
+    n = product._abi.LDS_N
     r = np.random.default_rng(1)
     i = np.arange(n)
     w = r.choice([-1.0, 1.0], n)
     J = sp.coo_matrix((np.concatenate([w, w]), (np.concatenate([i, (i + 1) % n]), np.concatenate([(i + 1) % n, i]))),
-                      shape=(n, n)).tocsr()          # ring of the largest supported size
+                      shape=(n, n)).tocsr()          # ring of the largest size whose spins live in LDS
     csr = oracle.Csr(J)
     m0 = init_spins(1, n)
     with product.Engine(J, np.zeros(n), 1) as eng:
         eng.set_spins(m0)
         E0 = eng.energy()
-        o = eng.sweep_philox(2, 4, beta=0.7, record_stride=1)
-        cb = np.tile(np.array(oracle.cb_pair(0.7)), (2, 1))
-        M, _, _ = oracle.sweeps_philox(csr, np.zeros(n), m0[0], cb, 4, 0, escale=eng.energy_scale,
-                                       efix0=int(np.rint(E0[0] * 2.0 ** eng.energy_scale)))
-        assert np.array_equal(o["spins"][0], M)
-        with pytest.raises(NotImplementedError):      # fp64 uniforms of that many spins do not fit in LDS
-            eng.sweep_philox(1, 4, beta=0.7, precision="f64")
+        for f64 in (False, True):      # (fp64 uniforms of that many spins do not fit in LDS: the global-memory kernels, csrc/nlmc_big.h)
+            eng.set_spins(m0)
+            o = eng.sweep_philox(2, 4, beta=0.7, record_stride=1, precision="f64" if f64 else "f32")
+            cb = np.tile(np.array(oracle.cb_pair(0.7, 1.0, f64)), (2, 1))
+            M, _, _ = oracle.sweeps_philox(csr, np.zeros(n), m0[0], cb, 4, 0, escale=eng.energy_scale, use_f64=f64,
+                                           efix0=int(np.rint(E0[0] * 2.0 ** eng.energy_scale)))
+            assert np.array_equal(o["spins"][0], M)
+    n = product._abi.MAX_N + 1
     with pytest.raises(NotImplementedError):
-        product.Engine(sp.identity(n + 1, format="csr") * 0.0 + sp.eye(n + 1, k=1) + sp.eye(n + 1, k=-1), np.zeros(n + 1), 1)
+        product.Engine(sp.csr_matrix((n, n)), np.zeros(n), 1)
 
 
 def test_new_entry_points_degenerate_inputs(product):
