@@ -43,9 +43,9 @@ enum { NLMC_ORDER_SHARED = 0, NLMC_ORDER_PER_CHAIN = 1 }; /* one permutation per
 enum { NLMC_SPIN_NORMAL = 0, NLMC_SPIN_SCALED = 1, NLMC_SPIN_FROZEN_UP = 2, NLMC_SPIN_FROZEN_DOWN = 3 };
 
 #define NLMC_LDS_N 24576    /* up to here a chain's spins live in LDS (the fast kernels); longer chains keep them in global memory:
-                             * sweeps (all three modes), energies, traces and replica exchange work at any size, with the same
-                             * results spin for spin; the fused windows, the Houdayer kernels and the cluster-mask kernel do not
-                             * (NLMC_ERR_UNSUPPORTED / a failed launch reported as NLMC_ERR_HIP -- never a wrong result) */
+                             * sweeps (all three modes), energies, traces, replica exchange, the Houdayer move and the backbone
+                             * inference work at any size with the same results spin for spin (csrc/nlmc_big.h); only the
+                             * fused windows stay with the LDS kernels (nlmc_fused_modes reports 0, sweeps run order by order) */
 #define NLMC_MAX_N 16777216 /* spins per chain (32-bit positions of the schedules, counters of the level histogram) */
 
 /* Version of this interface; nlmc_abi_version() returns the value the library was built with and the binding refuses a

@@ -120,6 +120,7 @@ struct nlmc_ctx {
     DevBuf<int8_t> seed_snap;     // nlmc_backbone_seed: the configurations later backbone inferences are seeded with
     bool seed_snap_on = false;
     DevBuf<uint8_t> cmask;        // [n_chains][n_pad] backbone mask of the last inference per chain
+    DevBuf<uint8_t> cmask_scratch; // chains too long for LDS: the two membership arrays of k_cluster_mask per problem
     DevBuf<int32_t> nmc_status;   // sticky: a backbone inference diverged at its first lambda
     DevBuf<double> nmc_thr;       // thresholds of the cluster growth
     std::vector<double> nmc_thr_host, tab_host, lbp_eps_host, lbp_lams_host;   // contents of the device copies (uploads skipped when unchanged)
@@ -1253,7 +1254,7 @@ void nlmc_destroy(nlmc_ctx *c)
     c->spins.release(); c->best.release(); c->flags.release(); c->efix.release(); c->emin.release(); c->etrace.release();
     c->argmin.release(); c->energy.release(); c->tab.release(); c->ustream.release(); c->etrace_d.release();
     c->keys.release(); c->perm_raw.release(); c->u_raw.release(); c->stream_bad.release(); c->strace.release(); c->cfg.release(); c->snap_g.release(); c->scratch.release(); c->plan.release();
-    c->slot_mark.release(); c->sub_list_buf.release(); c->cmask.release(); c->nmc_status.release(); c->nmc_thr.release();
+    c->slot_mark.release(); c->sub_list_buf.release(); c->cmask.release(); c->cmask_scratch.release(); c->nmc_status.release(); c->nmc_thr.release();
     c->fz_glv.release(); c->fz_perm.release(); c->fz_adj.release(); c->fz_stats.release(); c->fz[0].release(); c->fz[1].release();
     c->lbp_src.release(); c->lbp_rev.release(); c->lbp_flag.release(); c->lbp_out_i.release(); c->lbp_tJ.release();
     c->lbp_eps.release(); c->lbp_ms.release(); c->lbp_lams.release(); c->lbp_w0.release(); c->lbp_w1.release();
@@ -2475,6 +2476,11 @@ static int icm_launch_components(nlmc_ctx *c, const int32_t *pairs_dev, int n_pa
     HIP_TRY(c, c->icm_info.reserve((size_t)n_pairs * 2));
     IcmArgs a{};
     a.g = c->g; a.spins = c->spins.p; a.pairs = pairs_dev; a.label = c->icm_label.p; a.info = c->icm_info.p;
+    if (c->big) {                   // the forest lives in the labels themselves (csrc/nlmc_big.h)
+        hipLaunchKernelGGL(k_icm_components_big, dim3(n_pairs), dim3(1024), 0, c->stream, a);
+        HIP_TRY(c, hipGetLastError());
+        return NLMC_OK;
+    }
     if (!c->has_zero_vals && c->n <= 65535) {
         int rc = ensure_adjacency(c);
         if (rc) return rc;
@@ -2503,6 +2509,14 @@ static int icm_launch_round(nlmc_ctx *c, const int32_t *pairs_dev, int n_pairs, 
     }
     a.round = round; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.katz = katz; a.chain_base = c->chain_base;
     a.efix = c->efix.p; a.energy_sink = c->energy_sink; a.eshift = c->escale - c->qs; a.escale = c->escale;
+    if (c->big) {
+        if (!pairs_dev && pair_K > 1024) return fail(c, NLMC_ERR_UNSUPPORTED, "icm: more sub-replicas than threads of a workgroup");
+        HIP_TRY(c, c->icm_label.reserve((size_t)n_pairs * c->n));
+        a.adj = nullptr;
+        hipLaunchKernelGGL(k_icm_round_big, dim3(n_pairs), dim3(1024), 0, c->stream, a, c->icm_label.p);
+        HIP_TRY(c, hipGetLastError());
+        return NLMC_OK;
+    }
     size_t cur = (size_t)c->n * 4;
     a.lds_cand_off = (int)cur; cur += (((size_t)c->n + 7) & ~(size_t)7) * 2;
     cur = (cur + 15) & ~(size_t)15;
@@ -2971,8 +2985,13 @@ int nlmc_backbone_clusters(nlmc_ctx *c, const double *epsilon, const double *lam
     hipLaunchKernelGGL(k_lbp_seeds, dim3(P), dim3(256), 0, c->cur, c->n, c->n_pad, c->sub_list(), c->seed_snap_on ? c->seed_snap.p : c->spins.p, c->lbp_ms.p);
     HIP_TRY(c, hipGetLastError());
     { int rc = lbp_launch(c, P, n_lambdas, beta, tolerance, max_iterations, sat, false); if (rc) return rc; }
-    hipLaunchKernelGGL(k_cluster_mask, dim3(P), dim3(256), (size_t)2 * c->n_pad, c->cur, c->g, c->sub_list(), c->lbp_mag.p,
-                       c->lbp_out_i.p + P, c->nmc_thr.p, n_thresholds, c->cmask.p, c->nmc_status.p);
+    if (c->big || (size_t)2 * c->n_pad > (size_t)60 * 1024) {
+        HIP_TRY(c, c->cmask_scratch.reserve((size_t)P * 2 * c->n_pad));
+        hipLaunchKernelGGL(k_cluster_mask<true>, dim3(P), dim3(1024), 0, c->cur, c->g, c->sub_list(), c->lbp_mag.p,
+                           c->lbp_out_i.p + P, c->nmc_thr.p, n_thresholds, c->cmask.p, c->nmc_status.p, c->cmask_scratch.p);
+    } else
+        hipLaunchKernelGGL(k_cluster_mask<false>, dim3(P), dim3(256), (size_t)2 * c->n_pad, c->cur, c->g, c->sub_list(), c->lbp_mag.p,
+                           c->lbp_out_i.p + P, c->nmc_thr.p, n_thresholds, c->cmask.p, c->nmc_status.p, (uint8_t *)nullptr);
     HIP_TRY(c, hipGetLastError());
     return NLMC_OK;
 }

@@ -251,3 +251,183 @@ __global__ __launch_bounds__(1024) void k_sweep_big(SweepArgs a)
         if (a.emin) { a.emin[x.c] = x.Emin; a.argmin[x.c] = x.amin; }
     }
 }
+
+// ---- iso-cluster move (csrc/nlmc_pt_icm.h) on chains too long for LDS ------------------------------------------------------------
+#include "nlmc_pt_icm.h"
+
+// k_icm_components with the union-find forest in the output labels themselves (global memory).  Same result: the label of a
+// disagreeing spin is the smallest member of its component, INT_MAX elsewhere; info = {number of components, 0}.
+__global__ __launch_bounds__(1024) void k_icm_components_big(IcmArgs a)
+{
+    __shared__ int nroots;
+    const int n = a.g.n, tid = threadIdx.x, nt = blockDim.x, p = blockIdx.x;
+    const int8_t *sa = a.spins + (size_t)a.pairs[2 * p] * a.g.n_pad;
+    const int8_t *sb = a.spins + (size_t)a.pairs[2 * p + 1] * a.g.n_pad;
+    int32_t *lab = a.label + (size_t)p * n;
+    if (tid == 0) nroots = 0;
+    for (int k = tid; k < n; k += nt) lab[k] = ((int)sa[k] * (int)sb[k] == -1) ? k : INT_MAX;
+    __syncthreads();
+    bool converged = false;
+    for (int it = 0; it <= n; ++it) {
+        int changed = 0;
+        for (int k = tid; k < n; k += nt) {
+            if (lab[k] == INT_MAX) continue;
+            int rk = icm_find(lab, k);
+            const int rs = a.g.rowptr[k], re = a.g.rowptr[k + 1];
+            for (int e = rs; e < re; ++e) {
+                const EdgeQ t = a.g.edge32[e];
+                const int j = t.col;
+                if ((t.q == 0 && a.g.val64[e] == 0.0) || j == k || lab[j] == INT_MAX) continue;   // (`val != 0`, NPT/apt_ICM.py:129)
+                const int rj = icm_find(lab, j);
+                if (rj < rk) { atomicMin(&lab[rk], rj); rk = rj; changed = 1; }
+                else if (rk < rj) { atomicMin(&lab[rj], rk); changed = 1; }
+            }
+        }
+        if (!__syncthreads_or(changed)) { converged = true; break; }
+    }
+    int cnt = 0;
+    for (int k = tid; k < n; k += nt) {
+        int l = lab[k];
+        if (l != INT_MAX) l = icm_find(lab, k);      // (points every spin at its root: a pointer is only ever replaced by an ancestor)
+        cnt += (l == k);
+    }
+    if (cnt) atomicAdd(&nroots, cnt);
+    __syncthreads();
+    for (int k = tid; k < n; k += nt) if (lab[k] != INT_MAX) lab[k] = icm_find(lab, k);
+    if (tid == 0) { a.info[2 * p] = converged ? nroots : -1; a.info[2 * p + 1] = 0; }
+}
+
+// k_icm_round (components, pick, move, energy bookkeeping of one pair in one workgroup) with the labels in global scratch
+// `lab_g` [n_pairs][n] and both configurations read and exchanged in place.  Same pairing keys, same pick, same integers.
+__global__ __launch_bounds__(1024) void k_icm_round_big(IcmRoundArgs a, int32_t *lab_g)
+{
+    __shared__ int nroots, sh_root, sh_size;
+    __shared__ int sh_scan[17];
+    __shared__ long long sh_dE[2];
+    __shared__ int sh_pair[2], sh_lad[2];
+    const int n = a.g.n, n_pad = a.g.n_pad, tid = threadIdx.x, nt = blockDim.x, p = blockIdx.x;
+    if (!a.pairs) {
+        const int half = a.pair_K / 2, r = p / half, i = p % half;
+        const uint32_t rg = (uint32_t)(r + a.slot0);
+        if (tid < a.pair_K) {
+            const uint32_t kj = philox4x32_10((uint32_t)tid, a.round, rg, NLMC_TAG_ICM_PAIR, a.seed_lo, a.seed_hi).x;
+            int rank = 0;
+            for (int q = 0; q < a.pair_K; ++q) {
+                if (q == tid) continue;
+                const uint32_t kq = philox4x32_10((uint32_t)q, a.round, rg, NLMC_TAG_ICM_PAIR, a.seed_lo, a.seed_hi).x;
+                rank += (kq < kj) || (kq == kj && q < tid);
+            }
+            if (rank == 2 * i || rank == 2 * i + 1) { sh_pair[rank & 1] = a.chain_of_slot[(size_t)tid * a.pair_R + r]; sh_lad[rank & 1] = tid; }
+        }
+        __syncthreads();
+    }
+    const int ca = a.pairs ? a.pairs[2 * p] : sh_pair[0], cb = a.pairs ? a.pairs[2 * p + 1] : sh_pair[1];
+    int8_t *sa = a.spins + (size_t)ca * n_pad, *sb = a.spins + (size_t)cb * n_pad;
+    int32_t *lab = lab_g + (size_t)p * n;
+    if (tid == 0) { nroots = 0; sh_size = 0; sh_dE[0] = 0; sh_dE[1] = 0; sh_root = -1; }
+    for (int k = tid; k < n; k += nt) lab[k] = ((int)sa[k] * (int)sb[k] == -1) ? k : INT_MAX;
+    __syncthreads();
+    for (int k = tid; k < n; k += nt) {
+        if (lab[k] == INT_MAX) continue;
+        const int rs = a.g.rowptr[k], re = a.g.rowptr[k + 1];
+        for (int e = rs; e < re; ++e) {
+            const EdgeQ t = a.g.edge32[e];
+            const int j = t.col;
+            if ((t.q == 0 && a.g.val64[e] == 0.0) || j >= k || lab[j] == INT_MAX) continue;       // every edge from its larger end
+            int ra = icm_find_halving(lab, k), rb = icm_find_halving(lab, j);
+            while (ra != rb) {
+                if (ra < rb) { const int x = ra; ra = rb; rb = x; }
+                const int old = atomicCAS(&lab[ra], ra, rb);
+                if (old == ra) break;
+                ra = icm_find_halving(lab, old);
+                rb = icm_find_halving(lab, rb);
+            }
+        }
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int k = tid; k < n; k += nt) if (lab[k] != INT_MAX) cnt += (icm_find_halving(lab, k) == k);
+    if (cnt) atomicAdd(&nroots, cnt);
+    __syncthreads();
+    for (int k = tid; k < n; k += nt) if (lab[k] != INT_MAX) lab[k] = icm_find_halving(lab, k);
+    __syncthreads();
+    const int ncomp = nroots;
+    if (ncomp <= 0) {
+        if (tid == 0) { a.info[2 * p] = ncomp; a.info[2 * p + 1] = 0; }
+        return;
+    }
+    uint32_t ida = (uint32_t)(a.chain_base + ca), idb = (uint32_t)(a.chain_base + cb);
+    if (a.rng_stride && !a.pairs) {
+        const int rl = p / (a.pair_K / 2);
+        ida = (uint32_t)(sh_lad[0] * a.rng_stride + a.rng_base + rl);
+        idb = (uint32_t)(sh_lad[1] * a.rng_stride + a.rng_base + rl);
+    }
+    const uint32_t r = philox4x32_10(ida, a.round, idb, NLMC_TAG_ICM, a.seed_lo, a.seed_hi).x;
+    const int pick = (int)(((unsigned long long)r * (unsigned long long)ncomp) >> 32);
+    const int chunk = (n + nt - 1) / nt;
+    const int b = min(tid * chunk, n), e = min(b + chunk, n);
+    int mine = 0;
+    for (int k = b; k < e; ++k) mine += (lab[k] == k);
+    const int lane = tid & 63, wv = tid >> 6;
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+    if (lane == 63) sh_scan[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += sh_scan[w];
+    const int before = base + incl - mine;
+    if (pick >= before && pick < before + mine) {
+        int seen = before;
+        for (int k = b; k < e; ++k)
+            if (lab[k] == k) { if (seen == pick) { sh_root = k; break; } ++seen; }
+    }
+    __syncthreads();
+    const int root = sh_root;
+    int csz = 0;
+    for (int k = tid; k < n; k += nt) csz += (lab[k] == root);
+    if (csz) atomicAdd(&sh_size, csz);
+    __syncthreads();
+    const int size = sh_size;
+    long long dEa = 0, dEb = 0;
+    if (a.katz && size > n / 2) {
+        for (int k = tid; k < n; k += nt) { const int8_t v = sa[k]; dEa += 2ll * (long long)a.g.hq[k] * (long long)v; sa[k] = (int8_t)(-v); }
+    } else {
+        // (a cluster member reads its own two spins and spins OUTSIDE the cluster only; nothing outside is written)
+        for (int k = tid; k < n; k += nt) {
+            if (lab[k] != root) continue;
+            const int rs = a.g.rowptr[k], re = a.g.rowptr[k + 1];
+            long long fa = a.g.hq[k], fb = fa;
+            for (int q = rs; q < re; ++q) {
+                const EdgeQ t = a.g.edge32[q];
+                if (lab[t.col] == root) continue;
+                fa += (long long)t.q * (long long)sa[t.col];
+                fb += (long long)t.q * (long long)sb[t.col];
+            }
+            const int8_t va = sa[k], vb = sb[k];
+            dEa += 2ll * (long long)va * fa;
+            dEb += 2ll * (long long)vb * fb;
+            sa[k] = vb;
+            sb[k] = va;
+        }
+    }
+    dEa = wave_sum_i64(dEa);
+    dEb = wave_sum_i64(dEb);
+    if (lane == 0) {
+        if (dEa) atomicAdd(reinterpret_cast<unsigned long long *>(&sh_dE[0]), (unsigned long long)dEa);
+        if (dEb) atomicAdd(reinterpret_cast<unsigned long long *>(&sh_dE[1]), (unsigned long long)dEb);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const long long ea = a.efix[ca] + sh_dE[0] * (1ll << a.eshift), eb = a.efix[cb] + sh_dE[1] * (1ll << a.eshift);
+        a.efix[ca] = ea;
+        a.efix[cb] = eb;
+        if (a.energy_sink) {
+            const double inv = __longlong_as_double((long long)(1023 - a.escale) << 52);
+            a.energy_sink[ca] = (double)ea * inv;
+            a.energy_sink[cb] = (double)eb * inv;
+        }
+        a.info[2 * p] = ncomp;
+        a.info[2 * p + 1] = size;
+    }
+}

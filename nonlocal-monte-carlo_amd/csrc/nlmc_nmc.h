@@ -73,12 +73,14 @@ __global__ void k_lbp_seeds(int n, int n_pad, const int32_t *list, const int8_t 
 // the order the reference serves the clusters in: one synchronous expansion per threshold).
 // -> mask[list[p]][n_pad] (1 = backbone spin).  A diverged inference (status 1: "LBP diverged at initial lambda") sets the
 // sticky flag; its marginals are all zero, i.e. the mask is empty.
+// (BIG: chains too long for LDS keep the two membership arrays in global scratch [problems][2 n_pad], csrc/nlmc_big.h)
+template <bool BIG = false>
 __global__ void k_cluster_mask(CsrDev g, const int32_t *list, const double *mag, const int32_t *lbp_status, const double *thresholds,
-                               int n_thresholds, uint8_t *mask, int32_t *sticky)
+                               int n_thresholds, uint8_t *mask, int32_t *sticky, uint8_t *scratch_g)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int n = g.n, p = blockIdx.x, c = list ? list[p] : p, tid = threadIdx.x, nt = blockDim.x;
-    uint8_t *cur = lds_raw, *nxt = lds_raw + g.n_pad;
+    uint8_t *cur = BIG ? scratch_g + (size_t)p * 2 * g.n_pad : lds_raw, *nxt = cur + g.n_pad;
     const double *m = mag + (size_t)p * n;
     if (tid == 0 && lbp_status[p] != 0) atomicOr(sticky, lbp_status[p]);
     const double t0 = thresholds[0];

@@ -172,3 +172,96 @@ def test_drop_in_classes_on_a_long_chain(product):
     np.random.seed(9)
     Mr = refport.mcmc(3, m0.copy(), 1.3, oracle.Csr(J), h)
     assert np.array_equal(np.asarray(M), Mr)
+
+    import contextlib, io, random
+    R, betas = 4, np.geomspace(0.3, 2.0, 4)
+    args = (betas, R, [False] * R, 8, 8, 4, 1, 1, 1, 1, 20, 2.5, 3, 0.01, 0.9, 0.9999999, 0.999999, 100, np.finfo(float).eps)
+    res = []
+    for cls in (product.NPT, refport.RefNPT):
+        np.random.seed(31)
+        random.seed(31)
+        obj = cls(Jd, h.copy())
+        with contextlib.redirect_stdout(io.StringIO()):
+            Mx, Ex = obj.run(*args)
+        res.append((np.asarray(Mx), np.asarray(Ex), np.asarray(obj.swap_pairs), np.asarray(obj.swap_accepted)))
+    assert res[0][0].shape == (R * n, 2) and np.array_equal(res[0][0], res[1][0])
+    assert_energy(res[0][1], res[1][1])
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+
+
+def test_houdayer_move_and_backbone_mask_on_long_chains(product, monkeypatch):
+    """The iso-cluster kernels and the cluster-mask kernel with their work arrays in global memory: components against the
+    oracle's search at N = 30 000, the device-decided round's conservation laws there, and everything against the LDS kernels at
+    a size both take (NLMC_FORCE_BIG)."""
+    n = 30_000
+    J, h = big_instance(n, 5)
+    csr = oracle.Csr(J)
+    m0 = init_spins(4, n)
+    with product.Engine(J, h, 4) as eng:
+        eng.set_spins(m0)
+        eng.sweep_philox(3, 5, beta=0.9)                      # correlated pairs: many small clusters, one large
+        s = eng.get_spins()
+        nc = eng.icm_components(0, 1)
+        lab = eng.icm_labels()
+        cl = oracle.clusters(csr, s[0].astype(float), s[1].astype(float))
+        assert nc == len(cl)
+        want = np.full(n, -1, np.int64)
+        for members in cl:
+            want[np.asarray(members)] = int(np.min(members))
+        assert np.array_equal(lab, want)
+        pick = 7 % nc
+        ncomp, size = eng.icm_move(0, 1, pick, True)
+        roots = sorted(int(np.min(m)) for m in cl)
+        members = np.flatnonzero(want == roots[pick])
+        exp = s.copy()
+        if size > n // 2:
+            exp[0] = -exp[0]
+        else:
+            exp[0, members], exp[1, members] = s[1, members], s[0, members]
+        assert size == len(members) and np.array_equal(eng.get_spins(), exp)
+        # device-decided round on the other pair + the first: energies stay tracked exactly, spins off the clusters untouched
+        before = eng.get_spins()
+        eng.energy()
+        info = eng.icm_round_philox([[2, 3], [0, 1]], 4, 99, True, want_info=True)
+        after = eng.get_spins()
+        assert np.all(info[:, 0] > 0)
+        assert np.array_equal(eng.energy_tracked(), eng.energy())
+        for a, b in ((2, 3), (0, 1)):
+            agree = before[a] == before[b]
+            moved = after[a] != before[a]
+            if not np.array_equal(after[a], -before[a]):       # (not the global flip of the Katzgraber variant)
+                assert not np.any(moved & agree) and np.array_equal(after[a][moved], before[b][moved])
+                assert np.array_equal(after[b][moved], before[a][moved])
+
+    J2, h2 = make_instance(900, seed=12)
+    m2 = init_spins(8, 900)
+    inst2 = product.Instance(J2, h2)
+    eps2 = product.lbp.EdgeGraph(inst2).epsilon(inst2.h)
+    lams2 = product.lbp.lambda_list(3.0, 0.05, 0.8)
+    thr2 = [0.9999 - 0.01 * i for i in range(3)]
+
+    def run():
+        out = []
+        with product.Engine(J2, h2, 8) as eng:
+            eng.set_spins(m2)
+            eng.pt_init(np.geomspace(0.3, 2.0, 4))            # 2 ladders of 4 slots
+            eng.sweep_philox(4, 3, beta=None)
+            eng.energy()
+            out.append(eng.icm_round_philox([[0, 4], [1, 5], [2, 6]], 1, 77, True, want_info=True))
+            out.append(eng.icm_round_ladders(2, 77, False, want_info=True))
+            out.append(eng.get_spins()); out.append(eng.energy_tracked())
+            out.append(eng.icm_components(3, 7)); out.append(eng.icm_labels())
+            eng.track_minimum(True)
+            eng.sweep_philox(3, 3, sweep0=10, beta=None)
+            eng.backbone_clusters(eps2, lams2, 3.0, np.finfo(float).eps, 100, float(np.tanh(19.06)) - np.finfo(float).eps, thr2)
+            eng.backbone_check()
+            out.append(eng.cluster_mask())
+            assert 0 < out[-1].sum() < out[-1].size
+        return out
+
+    monkeypatch.delenv("NLMC_FORCE_BIG", raising=False)
+    a = run()
+    monkeypatch.setenv("NLMC_FORCE_BIG", "1")
+    b = run()
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(np.asarray(x), np.asarray(y)), i
