@@ -188,6 +188,26 @@ def test_drop_in_classes_on_a_long_chain(product):
     assert_energy(res[0][1], res[1][1])
     assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
 
+    # APT_ICM.run (Houdayer moves between two sub-replicas per temperature): default numpy mode against the oracle's restatement,
+    # then the device-resident mode (rng="philox", icm_feedback=True) for its invariants
+    res = []
+    for cls in (product.APT_ICM, refport.RefAPT_ICM):
+        np.random.seed(32)
+        random.seed(32)
+        obj = cls(Jd, h.copy())
+        with contextlib.redirect_stdout(io.StringIO()):
+            Mx, Ex = obj.run(betas, R, 8, 8, 4, 1)
+        res.append((np.asarray(Mx), np.asarray(Ex), np.asarray(obj.swap_pairs), np.asarray(obj.swap_accepted)))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert_energy(res[0][1], res[1][1])
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+    obj = product.APT_ICM(Jd, h.copy(), rng="philox", seed=5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        Mx, Ex = obj.run(betas, R, 8, 8, 4, 1, icm_feedback=True, return_trace="int8")
+    assert np.asarray(Mx).shape[0] == R * n and set(np.unique(Mx)) <= {-1, 1}
+    assert len(obj.icm_cluster_sizes) > 0 and np.all(obj.icm_cluster_sizes >= 0)
+    assert np.asarray(Ex).shape == (R,) and np.all(np.isfinite(Ex))
+
 
 def test_houdayer_move_and_backbone_mask_on_long_chains(product, monkeypatch):
     """The iso-cluster kernels and the cluster-mask kernel with their work arrays in global memory: components against the
@@ -265,3 +285,23 @@ def test_houdayer_move_and_backbone_mask_on_long_chains(product, monkeypatch):
     b = run()
     for i, (x, y) in enumerate(zip(a, b)):
         assert np.array_equal(np.asarray(x), np.asarray(y)), i
+
+
+@pytest.mark.parametrize("rng", ["numpy", "philox"])
+def test_nmc_run_on_a_long_chain(product, rng):
+    """NMC.run at N = 26 000 (the reference's dense message arrays of N x N doubles would be 5.4 GB each there: no oracle run) --
+    the trace it returns is consistent: energies are those of its columns, the minimum is the minimum."""
+    import contextlib, io
+    n = 26_000
+    J, _ = big_instance(n, 23)
+    h = np.zeros(n)
+    csr = oracle.Csr(J)
+    obj = product.NMC(J, h.copy()) if rng == "numpy" else product.NMC(J, h.copy(), rng="philox", seed=3)
+    np.random.seed(2)
+    with contextlib.redirect_stdout(io.StringIO()):
+        M, E, emin = obj.run(6, 4, 1, 1, 1, 20, 3.0, 3.0, 0.05, 0.8, 0.9999, 0.97, 100, np.finfo(float).eps)
+    M, E = np.asarray(M), np.asarray(E).reshape(-1)
+    assert M.shape == (n, 3 * 4) and E.shape == (M.shape[1],) and set(np.unique(M)) <= {-1.0, 1.0}
+    for t in (0, 3, 4, 8, M.shape[1] - 1):
+        assert_energy(E[t], oracle.energy(csr, h, M[:, t]))
+    assert_energy(emin, E.min())
