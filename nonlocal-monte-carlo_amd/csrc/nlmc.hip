@@ -121,6 +121,8 @@ struct nlmc_ctx {
     bool seed_snap_on = false;
     DevBuf<uint8_t> cmask;        // [n_chains][n_pad] backbone mask of the last inference per chain
     DevBuf<uint8_t> cmask_scratch; // chains too long for LDS: the two membership arrays of k_cluster_mask per problem
+    DevBuf<int32_t> big_flag;     // ... "changed" words of the levelizer's relaxation passes
+    DevBuf<long long> big_esum;   // ... energy deltas of the running sweep per block row
     DevBuf<int32_t> nmc_status;   // sticky: a backbone inference diverged at its first lambda
     DevBuf<double> nmc_thr;       // thresholds of the cluster growth
     std::vector<double> nmc_thr_host, tab_host, lbp_eps_host, lbp_lams_host;   // contents of the device copies (uploads skipped when unchanged)
@@ -164,6 +166,7 @@ struct nlmc_ctx {
         void release() { order.release(); head32.release(); lvl_off.release(); nlev.release(); hi_max.release(); ellc64.release(); ell32.release(); ellv64.release(); headh64.release(); bkey.release(); bcur.release(); blvl.release(); }
     };
     Sched scratch, plan;
+    int n_cu = 0;                        // compute units of the device (asked once)
     bool big = false;                    // n > NLMC_LDS_N: every sweep runs the global-memory kernels of csrc/nlmc_big.h
     bool plan_big = false;               // the cached plan was built by k_levelize_big (its items are { k, row start })
     int plan_precision = 0;
@@ -379,13 +382,47 @@ int run_levelize(nlmc_ctx *c, int n_orders, const uint32_t *keys_in, int per_cha
     if (ell_mode < 0) {            // spins in global memory (csrc/nlmc_big.h); sc was reserved with reserve_big
         BigLevelizeArgs b{};
         b.g = c->g;
+        b.n_orders = n_orders;
         b.keys_in = keys_in;
         b.seed_lo = (uint32_t)seed; b.seed_hi = (uint32_t)(seed >> 32); b.sweep0 = sweep0;
         b.per_chain = per_chain; b.n_sweeps = n_sweeps; b.chain_base = c->chain_base;
         b.key = sc.bkey.p; b.lvl = sc.blvl.p; b.cur = sc.bcur.p;
         b.ord2 = sc.order.p; b.lvl_off = sc.lvl_off.p; b.nlev = sc.nlev.p; b.hi_max = sc.hi_max.p;
-        hipLaunchKernelGGL(k_levelize_big, dim3(n_orders), dim3(1024), 0, c->cur, b);
-        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, c->big_flag.reserve(NLMC_BIG_PASSES));
+        b.flag = c->big_flag.p;
+        // grid.y carries the order: batches of at most 65535 orders
+        const unsigned gx = (unsigned)((c->n + 255) / 256);
+        for (int ob = 0; ob < n_orders; ob += 65535) {
+            const int no = std::min(65535, n_orders - ob);
+            BigLevelizeArgs q = b;
+            const size_t n = (size_t)c->n;
+            q.n_orders = no;
+            if (q.keys_in) q.keys_in += (size_t)ob * n;
+            q.key = b.key ? b.key + (size_t)ob * n : nullptr; q.lvl += (size_t)ob * n; q.cur += (size_t)ob * (n + 2);
+            q.ord2 += (size_t)ob * n; q.lvl_off += (size_t)ob * (n + 1); q.nlev += ob; q.hi_max += ob;
+            // (Philox keys of per-chain orders are numbered over the whole call: the batch's first order id)
+            if (!q.keys_in && per_chain && n_orders > 65535) return fail(c, NLMC_ERR_UNSUPPORTED, "more than 65535 per-chain orders of a long chain in one window");
+            if (!q.keys_in) q.sweep0 = sweep0 + (uint32_t)ob;
+            hipLaunchKernelGGL(k_blv_init, dim3(gx, no), dim3(256), 0, c->cur, q);
+            HIP_TRY(c, hipGetLastError());
+            // passes until no spin waits for a neighbour's level any more (the depth of the schedule: ~20-40 for sparse graphs, n at worst)
+            for (long long done = 0; done <= (long long)c->n + NLMC_BIG_PASSES; done += NLMC_BIG_PASSES) {
+                int32_t fl[NLMC_BIG_PASSES];
+                HIP_TRY(c, hipMemsetAsync(q.flag, 0, sizeof(fl), c->cur));
+                for (int p = 0; p < NLMC_BIG_PASSES; ++p) hipLaunchKernelGGL(k_blv_pass, dim3(gx, no), dim3(256), 0, c->cur, q, p);
+                HIP_TRY(c, hipGetLastError());
+                HIP_TRY(c, hipMemcpyAsync(fl, q.flag, sizeof(fl), hipMemcpyDeviceToHost, c->cur));
+                HIP_TRY(c, hipStreamSynchronize(c->cur));
+                bool settled = false;
+                for (int p = 0; p < NLMC_BIG_PASSES; ++p) settled = settled || fl[p] == 0;
+                if (settled) break;
+            }
+            const unsigned gt = (unsigned)((c->n + NLMC_BIG_TILE - 1) / NLMC_BIG_TILE);
+            hipLaunchKernelGGL(k_blv_hist, dim3(gt, no), dim3(256), 0, c->cur, q);
+            hipLaunchKernelGGL(k_blv_scan, dim3(no), dim3(1024), 0, c->cur, q);
+            hipLaunchKernelGGL(k_blv_place, dim3(gt, no), dim3(256), 0, c->cur, q);
+            HIP_TRY(c, hipGetLastError());
+        }
         return NLMC_OK;
     }
     LevelizeArgs a{};
@@ -922,13 +959,43 @@ int run_sweeps(nlmc_ctx *c, bool stream_mode, int precision, int order_mode, int
         a.lds_u_stride = dbuf ? u_bytes : 0;
         a.lds_loff_stride = dbuf ? NLMC_LCAP * 4 : 0;
         a.lds_flags_off = lds_flags_off; a.lds_u_off = lds_u_off; a.lds_loff_off = lds_loff_off; a.lds_red_off = lds_red_off;
-        if (big && stream_mode)
-            hipLaunchKernelGGL(k_sweep_big<NLMC_BIG_STREAM>, dim3(R), dim3(nt), 0, c->cur, a);
-        else if (big && f64)
-            hipLaunchKernelGGL(k_sweep_big<NLMC_BIG_F64>, dim3(R), dim3(nt), 0, c->cur, a);
-        else if (big)
-            hipLaunchKernelGGL(k_sweep_big<NLMC_BIG_F32>, dim3(R), dim3(nt), 0, c->cur, a);
-        else if (stream_mode)
+        // chains too long for LDS (csrc/nlmc_big.h): enough of them to fill the chip -> one workgroup per chain for the whole
+        // window (its spins stay in that CU's L1 from level to level); few -> one launch per level over all chains, so that a
+        // single chain of a million spins still uses every CU (NLMC_BIG_PER_LEVEL = 0 / 1: test knob)
+        bool per_level = false;
+        if (big) {
+            if (c->n_cu == 0) HIP_TRY(c, hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
+            per_level = (long long)R * 8 <= c->n_cu;
+            if (const char *e = getenv("NLMC_BIG_PER_LEVEL")) per_level = atoi(e) != 0;
+            if (R > 65535) per_level = false;
+        }
+        if (big && !per_level) {
+            if (stream_mode) hipLaunchKernelGGL(k_sweep_big<NLMC_BIG_STREAM>, dim3(R), dim3(1024), 0, c->cur, a);
+            else if (f64) hipLaunchKernelGGL(k_sweep_big<NLMC_BIG_F64>, dim3(R), dim3(1024), 0, c->cur, a);
+            else hipLaunchKernelGGL(k_sweep_big<NLMC_BIG_F32>, dim3(R), dim3(1024), 0, c->cur, a);
+        } else if (big) {
+            // the numbers of levels come back first
+            const size_t n_ord = per_sweep_orders * (size_t)w;
+            std::vector<int32_t> nlev_h(n_ord);
+            HIP_TRY(c, hipMemcpyAsync(nlev_h.data(), a.nlev, sizeof(int32_t) * n_ord, hipMemcpyDeviceToHost, c->cur));
+            HIP_TRY(c, hipStreamSynchronize(c->cur));
+            HIP_TRY(c, c->big_esum.reserve((size_t)R));
+            HIP_TRY(c, hipMemsetAsync(c->big_esum.p, 0, sizeof(long long) * (size_t)R, c->cur));
+            const bool per_sweep_out = a.etrace || a.emin || a.strace;
+            const unsigned gx = (unsigned)std::max(1, std::min(256, (n / 16 + 255) / 256));
+            for (int t = 0; t < w; ++t) {
+                int nl = 0;
+                if (per_chain) for (size_t q = 0; q < per_sweep_orders; ++q) nl = std::max(nl, nlev_h[q * (size_t)w + t]);
+                else nl = nlev_h[(size_t)t];
+                for (int l = 0; l < nl; ++l) {
+                    if (stream_mode) hipLaunchKernelGGL(k_big_level<NLMC_BIG_STREAM>, dim3(gx, R), dim3(256), 0, c->cur, a, t, l, c->big_esum.p);
+                    else if (f64) hipLaunchKernelGGL(k_big_level<NLMC_BIG_F64>, dim3(gx, R), dim3(256), 0, c->cur, a, t, l, c->big_esum.p);
+                    else hipLaunchKernelGGL(k_big_level<NLMC_BIG_F32>, dim3(gx, R), dim3(256), 0, c->cur, a, t, l, c->big_esum.p);
+                }
+                if (per_sweep_out || t == w - 1) hipLaunchKernelGGL(k_big_sweep_end, dim3(R), dim3(1024), 0, c->cur, a, t, c->big_esum.p);
+                HIP_TRY(c, hipGetLastError());
+            }
+        } else if (stream_mode)
             hipLaunchKernelGGL(k_sweep_stream, dim3(R), dim3(nt), lds, c->cur, a);
         else if (f64 && c->f64_pack16 && c->has_diag)
             hipLaunchKernelGGL((k_sweep_philox<double, true, true>), dim3(R), dim3(nt), lds, c->cur, a);
@@ -1254,7 +1321,7 @@ void nlmc_destroy(nlmc_ctx *c)
     c->spins.release(); c->best.release(); c->flags.release(); c->efix.release(); c->emin.release(); c->etrace.release();
     c->argmin.release(); c->energy.release(); c->tab.release(); c->ustream.release(); c->etrace_d.release();
     c->keys.release(); c->perm_raw.release(); c->u_raw.release(); c->stream_bad.release(); c->strace.release(); c->cfg.release(); c->snap_g.release(); c->scratch.release(); c->plan.release();
-    c->slot_mark.release(); c->sub_list_buf.release(); c->cmask.release(); c->cmask_scratch.release(); c->nmc_status.release(); c->nmc_thr.release();
+    c->slot_mark.release(); c->sub_list_buf.release(); c->cmask.release(); c->cmask_scratch.release(); c->big_flag.release(); c->big_esum.release(); c->nmc_status.release(); c->nmc_thr.release();
     c->fz_glv.release(); c->fz_perm.release(); c->fz_adj.release(); c->fz_stats.release(); c->fz[0].release(); c->fz[1].release();
     c->lbp_src.release(); c->lbp_rev.release(); c->lbp_flag.release(); c->lbp_out_i.release(); c->lbp_tJ.release();
     c->lbp_eps.release(); c->lbp_ms.release(); c->lbp_lams.release(); c->lbp_w0.release(); c->lbp_w1.release();
@@ -1428,8 +1495,11 @@ int nlmc_sweep_stream(nlmc_ctx *c, int n_sweeps, const int32_t *perm, const doub
     HIP_TRY(c, hipMemcpyAsync(c->tab.p, tab.data(), sizeof(double) * tot, hipMemcpyHostToDevice, c->stream));
     if (c->big || (size_t)n * 4 > (size_t)150 * 1024) {       // (the seen-marks of k_stream_scatter live in LDS)
         HIP_TRY(c, hipMemsetAsync(c->keys.p, 0xFF, sizeof(uint32_t) * tot * n, c->stream));
-        hipLaunchKernelGGL(k_stream_scatter_big, dim3((unsigned)tot), dim3(1024), 0, c->stream, n, c->perm_raw.p, c->u_raw.p, c->keys.p,
-                           c->ustream.p, c->stream_bad.p);
+        for (size_t ob = 0; ob < tot; ob += 65535) {
+            const size_t no = std::min<size_t>(65535, tot - ob), sh = ob * (size_t)n;
+            hipLaunchKernelGGL(k_stream_scatter_big, dim3((unsigned)((n + 255) / 256), (unsigned)no), dim3(256), 0, c->stream, n, c->perm_raw.p + sh,
+                               c->u_raw.p + sh, c->keys.p + sh, c->ustream.p + sh, c->stream_bad.p);
+        }
     } else {
         { int rc = ensure_lds(c, 8, reinterpret_cast<const void *>(k_stream_scatter), (size_t)n * 4); if (rc) return rc; }
         hipLaunchKernelGGL(k_stream_scatter, dim3((unsigned)tot), dim3(256), (size_t)n * 4, c->stream, n, c->perm_raw.p, c->u_raw.p, c->keys.p,

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from conftest import load_product
 from helpers import make_instance, init_spins
 P = load_product()
-for N, R, S in ((30_000, 256, 20), (100_000, 256, 10), (1_000_000, 64, 4)):
+for N, R, S in ((30_000, 256, 20), (100_000, 256, 10), (1_000_000, 64, 4), (30_000, 1, 20), (100_000, 1, 10), (1_000_000, 1, 4)):
     J, h = make_instance(N)
     inst = P.Instance(J, h)
     with P.Engine(inst, None, R) as eng:

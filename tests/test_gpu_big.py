@@ -40,7 +40,8 @@ def big_instance(n, seed, gaussian=False, diag=False):
 
 
 @pytest.mark.parametrize("n,gaussian,diag", [(30_000, True, True), (70_000, False, False)])
-def test_stream_mode_of_long_chains_matches_the_oracle(product, n, gaussian, diag):
+def test_stream_mode_of_long_chains_matches_the_oracle(product, monkeypatch, n, gaussian, diag):
+    monkeypatch.setenv("NLMC_BIG_PER_LEVEL", "1" if diag else "0")      # (3 chains would take one launch per level by themselves)
     J, h = big_instance(n, 11, gaussian, diag)
     R, S = 3, 3
     csr = oracle.Csr(J)
@@ -70,7 +71,8 @@ def test_stream_mode_of_long_chains_matches_the_oracle(product, n, gaussian, dia
 
 @pytest.mark.parametrize("precision", ["f32", "f64"])
 @pytest.mark.parametrize("order", ["shared", "per_chain"])
-def test_philox_modes_of_long_chains_match_the_oracle(product, precision, order):
+def test_philox_modes_of_long_chains_match_the_oracle(product, monkeypatch, precision, order):
+    monkeypatch.setenv("NLMC_BIG_PER_LEVEL", "1" if precision == "f64" else "0")
     n = 30_000 if order == "shared" else 66_000
     J, h = big_instance(n, 3, gaussian=(precision == "f64"), diag=(order == "shared"))
     R, S = 3, 3
@@ -145,7 +147,10 @@ def test_global_memory_kernels_equal_the_lds_kernels_at_a_size_both_take(product
     monkeypatch.delenv("NLMC_FORCE_BIG", raising=False)
     a = run()
     monkeypatch.setenv("NLMC_FORCE_BIG", "1")
+    monkeypatch.setenv("NLMC_BIG_PER_LEVEL", "0")                 # one workgroup per chain
     b = run()
+    monkeypatch.setenv("NLMC_BIG_PER_LEVEL", "1")                 # one launch per level
+    b2 = run()
 
     def same(x, y):
         if isinstance(x, dict):
@@ -153,8 +158,8 @@ def test_global_memory_kernels_equal_the_lds_kernels_at_a_size_both_take(product
         if isinstance(x, (tuple, list)):
             return len(x) == len(y) and all(same(p, q) for p, q in zip(x, y))
         return np.array_equal(np.asarray(x), np.asarray(y))
-    for i, (x, y) in enumerate(zip(a, b)):
-        assert same(x, y), i
+    for i, (x, y, z) in enumerate(zip(a, b, b2)):
+        assert same(x, y) and same(x, z), i
 
 
 def test_drop_in_classes_on_a_long_chain(product):
