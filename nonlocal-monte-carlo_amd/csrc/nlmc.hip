@@ -406,17 +406,18 @@ int run_levelize(nlmc_ctx *c, int n_orders, const uint32_t *keys_in, int per_cha
             hipLaunchKernelGGL(k_blv_init, dim3(gx, no), dim3(256), 0, c->cur, q);
             HIP_TRY(c, hipGetLastError());
             // passes until no spin waits for a neighbour's level any more (the depth of the schedule: ~20-40 for sparse graphs, n at worst)
-            for (long long done = 0; done <= (long long)c->n + NLMC_BIG_PASSES; done += NLMC_BIG_PASSES) {
+            bool settled = false;
+            for (long long done = 0; !settled && done <= (long long)c->n + NLMC_BIG_PASSES; done += NLMC_BIG_PASSES) {
                 int32_t fl[NLMC_BIG_PASSES];
                 HIP_TRY(c, hipMemsetAsync(q.flag, 0, sizeof(fl), c->cur));
                 for (int p = 0; p < NLMC_BIG_PASSES; ++p) hipLaunchKernelGGL(k_blv_pass, dim3(gx, no), dim3(256), 0, c->cur, q, p);
                 HIP_TRY(c, hipGetLastError());
                 HIP_TRY(c, hipMemcpyAsync(fl, q.flag, sizeof(fl), hipMemcpyDeviceToHost, c->cur));
                 HIP_TRY(c, hipStreamSynchronize(c->cur));
-                bool settled = false;
                 for (int p = 0; p < NLMC_BIG_PASSES; ++p) settled = settled || fl[p] == 0;
-                if (settled) break;
             }
+            // (the order is total: n passes always suffice; never walk on with unset levels)
+            if (!settled) return fail(c, NLMC_ERR_STATE, "level schedule of a long chain did not settle");
             const unsigned gt = (unsigned)((c->n + NLMC_BIG_TILE - 1) / NLMC_BIG_TILE);
             hipLaunchKernelGGL(k_blv_hist, dim3(gt, no), dim3(256), 0, c->cur, q);
             hipLaunchKernelGGL(k_blv_scan, dim3(no), dim3(1024), 0, c->cur, q);
