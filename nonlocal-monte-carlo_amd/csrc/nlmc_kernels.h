@@ -478,8 +478,18 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
     // 32-bit mask per half and slot; up to three candidates per lane and slot, then whatever is left).  Early slots -- many
     // candidates per lane -- come out conflict-free, the last real entries of a row take what remains.
     __shared__ unsigned sh_bank[16][16];             // [wave][half * 8 + slot]
+    // Software pipeline over a thread's positions: item id -> row bounds -> row entries are three dependent reads (L2 hits, ~1 us
+    // each); the id of the position after next and the row bounds of the next one are fetched while the current one is packed, so
+    // that an iteration waits for its row entries only.
+    uint32_t it_a = tid < npos ? perm[tid] : 0xFFFFFFFFu, it_b = tid + nt < npos ? perm[tid + nt] : 0xFFFFFFFFu;
+    int rs_a = 0, re_a = 0;
+    if (it_a != 0xFFFFFFFFu) { rs_a = a.g.rowptr[it_a & 0xFFFFu]; re_a = a.g.rowptr[(it_a & 0xFFFFu) + 1]; }
     for (int pos = tid; pos < npos; pos += nt) {
-        const uint32_t it = perm[pos];
+        const uint32_t it = it_a;
+        const int rs_cur = rs_a, deg_cur = re_a - rs_a;
+        it_a = it_b;
+        if (it_a != 0xFFFFFFFFu) { rs_a = a.g.rowptr[it_a & 0xFFFFu]; re_a = a.g.rowptr[(it_a & 0xFFFFu) + 1]; }
+        it_b = pos + 2 * nt < npos ? perm[pos + 2 * nt] : 0xFFFFFFFFu;
         const uint32_t dpack = (uint32_t)a.k_dummy << 16;
         if (a.bank_aware && (tid & 63) < 16) sh_bank[tid >> 6][tid & 15] = 0u;       // (npos is a multiple of 64: whole waves iterate)
         if (it == 0xFFFFFFFFu) {
@@ -500,7 +510,7 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
         }
         const int second = (int)(it >> 31);
         const int k = (int)(it & 0xFFFFu), t = (int)((it >> 16) & 0x7FFFu);
-        const int rs = a.g.rowptr[k], deg = a.g.rowptr[k + 1] - rs;
+        const int rs = rs_cur, deg = deg_cur;
         const int thr = ((t % 3) * a.tab_words + k) << 16;
         const int e0 = second ? NLMC_FZ_W : 0, left = deg - e0;                 // this lane's entries: e0 .. e0 + 7
         EdgeQ ed[NLMC_FZ_W];
