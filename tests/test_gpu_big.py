@@ -310,3 +310,27 @@ def test_nmc_run_on_a_long_chain(product, rng):
     for t in (0, 3, 4, 8, M.shape[1] - 1):
         assert_energy(E[t], oracle.energy(csr, h, M[:, t]))
     assert_energy(emin, E.min())
+
+
+@pytest.mark.parametrize("per_level", ["0", "1"])
+def test_deepest_schedule_of_a_long_chain(product, monkeypatch, per_level):
+    """A ring visited in index order: every spin waits for its predecessor, the schedule has as many levels as spins (30 000: the
+    levelizer's passes, its histogram bins past the LDS ones, and a level per launch / per barrier with one spin in it)."""
+    monkeypatch.setenv("NLMC_BIG_PER_LEVEL", per_level)
+    n = 30_000
+    i = np.arange(n)
+    w = np.random.default_rng(2).choice([-1.0, 1.0], n)
+    J = sp.coo_matrix((np.concatenate([w, w]), (np.concatenate([i, (i + 1) % n]), np.concatenate([(i + 1) % n, i]))), shape=(n, n)).tocsr()
+    J.sort_indices()
+    h = np.zeros(n)
+    csr = oracle.Csr(J)
+    m0 = init_spins(1, n)
+    perm = np.arange(n, dtype=np.int32)[None, None, :]
+    u = np.random.default_rng(3).random((1, 1, n))
+    with product.Engine(J, h, 1) as eng:
+        eng.set_spins(m0)
+        o = eng.sweep_stream(perm, u, np.array([[0.8]]), record_stride=1, want_energy=True)
+        assert eng.last_schedule_stats()["levels"] == n
+    M, _ = oracle.sweeps_stream(csr, h, m0[0].astype(float), np.array([0.8]), perm[0], u[0])
+    assert np.array_equal(o["spins"][0], M)
+    assert_energy(o["energy"][0], [oracle.energy(csr, h, M[0])])
