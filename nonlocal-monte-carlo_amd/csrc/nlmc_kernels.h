@@ -477,7 +477,13 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
     // field is a sum, so a row's entries may stand in ANY order: slot by slot, the lanes of a half-wave claim banks (atomicOr on a
     // 32-bit mask per half and slot; up to three candidates per lane and slot, then whatever is left).  Early slots -- many
     // candidates per lane -- come out conflict-free, the last real entries of a row take what remains.
-    __shared__ unsigned sh_bank[16][16];             // [wave][half * 8 + slot]
+    // One claim word per (wave, half, bank): a lane claims bank b of the slot in hand with an exchange on word b -- different banks
+    // are different LDS banks, so the 32 lanes of a half proceed side by side and only true rivals queue (one mask word per half
+    // and slot, OR-ed by all 32 lanes, serialised every claim: 1.2 of the 1.85 M cycles of this loop at N = 10^4).  The word holds
+    // the number of the (iteration, slot) it was last claimed in, so nothing has to be cleared between slots.
+    __shared__ unsigned sh_claim[16][2][32];
+    sh_claim[tid >> 6][(tid >> 5) & 1][tid & 31] = 0u;
+    unsigned claim_gen = 0u;
     // Software pipeline over a thread's positions: item id -> row bounds -> row entries are three dependent reads (L2 hits, ~1 us
     // each); the id of the position after next and the row bounds of the next one are fetched while the current one is packed, so
     // that an iteration waits for its row entries only.
@@ -487,11 +493,11 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
     for (int pos = tid; pos < npos; pos += nt) {
         const uint32_t it = it_a;
         const int rs_cur = rs_a, deg_cur = re_a - rs_a;
+        claim_gen += NLMC_FZ_W;
         it_a = it_b;
         if (it_a != 0xFFFFFFFFu) { rs_a = a.g.rowptr[it_a & 0xFFFFu]; re_a = a.g.rowptr[(it_a & 0xFFFFu) + 1]; }
         it_b = pos + 2 * nt < npos ? perm[pos + 2 * nt] : 0xFFFFFFFFu;
         const uint32_t dpack = (uint32_t)a.k_dummy << 16;
-        if (a.bank_aware && (tid & 63) < 16) sh_bank[tid >> 6][tid & 15] = 0u;       // (npos is a multiple of 64: whole waves iterate)
         if (it == 0xFFFFFFFFu) {
             // (threshold word 3 tab_words: behind the three tables / snapshot slots, so that a dummy's threshold read and
             // snapshot write touch nothing that belongs to a spin)
@@ -521,12 +527,15 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
         if (a.bank_aware) {
             const int nreal = min(max(left, 0), NLMC_FZ_W);
             unsigned long long banks = 0ull;                   // 5 bits per entry
+            unsigned long long adr_lo = 0ull, adr_hi = 0ull;   // address format: the 16-bit LDS addresses of entries 0-3 | 4-7
 #pragma unroll
             for (int q = 0; q < NLMC_FZ_W; ++q) {
                 const unsigned ad = (unsigned)ed[q].col + ((a.fmt == NLMC_FMT_ADDR && ed[q].q < 0) ? (unsigned)a.neg_off : 0u);
                 banks |= (unsigned long long)((ad >> 2) & 31u) << (5 * q);
+                if (q < 4) adr_lo |= (unsigned long long)(ad & 0xFFFFu) << (16 * q);
+                else adr_hi |= (unsigned long long)(ad & 0xFFFFu) << (16 * (q - 4));
             }
-            unsigned *mask = &sh_bank[tid >> 6][((tid >> 5) & 1) * 8];
+            unsigned *claim = &sh_claim[tid >> 6][(tid >> 5) & 1][0];          // (npos is a multiple of 64: whole waves iterate)
             unsigned rem = (1u << nreal) - 1u, ordpk = 0u;     // entries not placed yet; 4 bits per slot: entry index, 8 = padding
             int spare = NLMC_FZ_W - nreal;                     // padding entries (they gather a byte that is always 0: one address for
                                                                // every lane, no conflict) -- a lane may spend one on a contested slot
@@ -534,6 +543,7 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
 #pragma unroll
             for (int q = 0; q < NLMC_FZ_W; ++q) {
                 unsigned chosen = 8u;
+                const unsigned gen = claim_gen + (unsigned)q + 1u;
                 if (rem) {
                     unsigned cand = rem;
                     bool got = false;
@@ -543,9 +553,8 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
                             // a candidate among the remaining ones, starting at a lane-dependent position
                             const unsigned r8 = ((cand | (cand << 8)) >> ((rot + (unsigned)q) & 7u)) & 0xFFu;
                             const unsigned e = ((unsigned)__builtin_ctz(r8) + ((rot + (unsigned)q) & 7u)) & 7u;
-                            const unsigned bit = 1u << (unsigned)((banks >> (5 * e)) & 31ull);
-                            const unsigned old = atomicOr(&mask[q], bit);
-                            if (!(old & bit)) { got = true; chosen = e; }
+                            const unsigned old = atomicExch(&claim[(unsigned)((banks >> (5 * e)) & 31ull)], gen);
+                            if (old != gen) { got = true; chosen = e; }
                             cand &= ~(1u << e);
                         }
                     }
@@ -556,6 +565,23 @@ __global__ __launch_bounds__(1024) void k_levelize_fused(FusedLevelizeArgs a)
                     }
                 }
                 ordpk |= chosen << (4 * q);
+            }
+            if (a.fmt == NLMC_FMT_ADDR) {
+                // (the address format -- what a +-J instance gets -- needs the 16-bit address of the chosen entry only: a 64-bit
+                // select and a shift per slot instead of the chain of selects over whole entries below, which was a third of this
+                // loop's instructions)
+                uint32_t pk[NLMC_FZ_W / 2] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int q = 0; q < NLMC_FZ_W; ++q) {
+                    const unsigned e = (ordpk >> (4 * q)) & 15u;
+                    const unsigned long long wsel = (e & 4u) ? adr_hi : adr_lo;
+                    const uint32_t v16 = e == 8u ? (uint32_t)a.k_zero : (uint32_t)(wsel >> (16u * (e & 3u))) & 0xFFFFu;
+                    pk[q / 2] |= v16 << (16 * (q & 1));
+                }
+                ell[pos] = make_int4((int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]);
+                head[pos] = second ? make_int2(k | 0x8000 | thr, hy)
+                                   : make_int2(k | (deg > 2 * NLMC_FZ_W ? 0x4000 : 0) | (deg > NLMC_FZ_W ? 0x8000 : 0) | thr, hy);
+                continue;
             }
             EdgeQ od[NLMC_FZ_W];
 #pragma unroll
