@@ -61,9 +61,16 @@ class ShardedTempering:
             self.lib_collective = agree_on_library_collectives(self.eng, torch, dist, device, want=self.n_pairs > 0)
         self._check_every = int(os.environ.get("NLMC_COMM_CHECK_EVERY", "256"))
         self._timeout_ms = int(float(os.environ.get("NLMC_COMM_TIMEOUT_S", "120")) * 1000)
+        # a gloo process group (rehearsals with several ranks on one GPU, which RCCL refuses): collectives on host tensors, the
+        # energies staged through the host every round
+        self._host_stage = (self.collective and not self.lib_collective and dist.get_backend() == "gloo"
+                            and str(device) != "cpu" and device is not None)
         if self.collective and not self.lib_collective:
             self.e_local = torch.empty(self.count, dtype=torch.float64, device=device)
             self.e_all = torch.empty(self.G, dtype=torch.float64, device=device)
+            if self._host_stage:
+                self.e_local_h = torch.empty(self.count, dtype=torch.float64)
+                self.e_all_h = torch.empty(self.G, dtype=torch.float64)
             # the sweep kernels write their chains' energies straight into the all-gather's send buffer
             self._sink = hasattr(self.eng, "set_energy_sink")
             if self._sink:
@@ -135,7 +142,12 @@ class ShardedTempering:
             elif self.collective:
                 if not self._sink or n_sweeps == 0:
                     self.eng.energy_dev(self.e_local.data_ptr())       # tracked energies -> device/host buffer
-                self.dist.all_gather_into_tensor(self.e_all, self.e_local)   # the ONE collective of the round
+                if self._host_stage:
+                    self.e_local_h.copy_(self.e_local)
+                    self.dist.all_gather_into_tensor(self.e_all_h, self.e_local_h)
+                    self.e_all.copy_(self.e_all_h)
+                else:
+                    self.dist.all_gather_into_tensor(self.e_all, self.e_local)   # the ONE collective of the round
                 log = self.eng.pt_swap_philox(self.rounds_done, self.seed, self.n_pairs,
                                               energies_all_dev=self.e_all.data_ptr(), want_log=want_log)
             else:
@@ -189,6 +201,8 @@ class ShardedTempering:
         if not self.collective:
             return loc
         dev = self.torch.device("cuda", self.torch.cuda.current_device()) if self.lib_collective else self.e_all.device
+        if self._host_stage:
+            dev = "cpu"
         t = self.torch.from_numpy(loc.astype(np.int8)).to(dev)
         out = self.torch.empty((self.G, loc.shape[1]), dtype=self.torch.int8, device=dev)
         self.dist.all_gather_into_tensor(out, t)
@@ -403,6 +417,8 @@ def agree_on_library_collectives(eng, torch, dist, device, want):
         except Exception as ex:  # noqa: BLE001
             print(f"[nlmc] librccl probe failed ({ex})", file=sys.stderr)
             ok = False
+    if dist.get_backend() == "gloo":
+        device = "cpu"                              # (the flags below are host tensors for a gloo group)
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) != 1:
@@ -631,7 +647,7 @@ class ShardedAsLocal:
 
     def gather(self, x):
         t, dist = self.st.torch, self.st.dist
-        dev = t.device("cuda", t.cuda.current_device())
+        dev = "cpu" if dist.get_backend() == "gloo" else t.device("cuda", t.cuda.current_device())
         loc = t.from_numpy(np.ascontiguousarray(x)).to(dev)
         out = t.empty((self.st.world * loc.shape[0],) + tuple(loc.shape[1:]), dtype=loc.dtype, device=dev)
         dist.all_gather_into_tensor(out, loc)

@@ -22,13 +22,33 @@ def main():
     torch.cuda.set_device(0)
     if backend == "gloo":
         dist.init_process_group("gloo", rank=rank, world_size=world)     # (two ranks on ONE GPU: RCCL refuses that, gloo does not care)
+    if mode == "bench":
+        # the bench workload's shape cut over the ranks: ShardedTempering as bench.py drives it (fp64 mode, fused windows, planned
+        # pair selections, one all-gather per round), a few rounds
+        from helpers import init_spins
+        N, G, S, rounds = 10_000, 256, 10, 6
+        J, h = make_instance(N)
+        inst = P.Instance(J, h)
+        betas = np.geomspace(0.05, 4.0, G)
+        dev = torch.device("cuda", 0)
+        st = P.distributed.ShardedTempering(lambda i, n, b, g: P.Engine(i, None, n, device=0, chain_base=b, n_chains_global=g), inst, betas,
+                                            G, 20250225, round(0.3 * G), torch=torch, dist=dist, device=dev, precision="f64")
+        st.set_spins(init_spins(G, N))
+        st.plan(rounds * S, rounds, chunk_rounds=4, lazy=True)
+        st.run_rounds(rounds, S)
+        np.savez(out + f".rank{rank}.npz", spins=st.eng.get_spins(), energy=st.eng.energy_tracked(), slots=st.eng.pt_slots(),
+                 base=st.base, count=st.count)
+        st.close()
+        dist.destroy_process_group()
+        print(json.dumps({"rank": rank, "ok": True}))
+        return
     N, R = 300, 6
     J, h = make_instance(N, seed=4)
     betas = np.geomspace(0.3, 2.5, R)
     doNMC = [False] * (R - 2) + [True, True] if mode == "nmc" else [False] * R
     obj = P.NPT(J.toarray(), h, rng="philox", seed=11)
     M, E = obj.run(betas, R, doNMC, num_sweeps_MCMC=60, num_sweeps_read=60, num_swap_attempts=6, num_swapping_pairs=2, num_cycles=1,
-                   num_restarts=2, global_beta=2.5, lambda_start=3.0, lambda_end=0.05, lambda_reduction_factor=0.8, threshold_initial=0.9999,
+                   num_restarts=(1 if mode == "cut" else 2), global_beta=2.5, lambda_start=3.0, lambda_end=0.05, lambda_reduction_factor=0.8, threshold_initial=0.9999,
                    threshold_cutoff=0.97)
     np.savez(out + f".rank{rank}.npz", M=M, E=E, restart_energies=obj.restart_energies, swap_accepted=obj.swap_accepted)
     if dist.is_initialized():

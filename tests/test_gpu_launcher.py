@@ -76,3 +76,42 @@ def test_one_rank_cut_ladder_driver_with_the_library_collective(product, tmp_pat
         raise
     assert np.array_equal(got[0]["M"], M) and np.array_equal(got[0]["E"], E)
     assert np.array_equal(got[0]["restart_energies"], RE) and np.array_equal(got[0]["swap_accepted"], acc)
+
+
+def test_two_ranks_cut_one_ladder(product, tmp_path):
+    """Two ranks (gloo group, both on the one GPU), ONE ladder of 6 temperatures: three chains per rank, the swap round decided on
+    every rank from the all-gathered energies (distributed.ShardedTempering with real engines on both sides; the collective itself
+    goes through the host here -- RCCL refuses two ranks on one GPU), label exchanges applied to the replicated slot table, the
+    last round's trace gathered: the same M, Energy and swap decisions as one process."""
+    N, R = 300, 6
+    J, h = make_instance(N, seed=4)
+    betas = np.geomspace(0.3, 2.5, R)
+    obj = product.NPT(J.toarray(), h, rng="philox", seed=11)
+    M, E = obj.run(betas, R, [False] * R, num_sweeps_MCMC=60, num_sweeps_read=60, num_swap_attempts=6, num_swapping_pairs=2, num_cycles=1)
+    got = launch(tmp_path, 2, "gloo", "cut")
+    for r in (0, 1):
+        assert np.array_equal(got[r]["M"], M) and np.array_equal(got[r]["E"], E)
+        assert np.array_equal(got[r]["swap_accepted"], obj.swap_accepted)
+
+
+def test_two_ranks_cut_the_bench_ladder(product, tmp_path):
+    """The bench workload's shape (N = 10^4, one ladder of 256 temperatures, fp64 mode on fused windows, 77 planned pairs per round)
+    cut over two ranks of 128 chains, driven like bench.py drives it: spins, tracked energies and the slot table after six rounds
+    equal one process holding all 256 chains."""
+    from helpers import init_spins
+    N, G, S, rounds = 10_000, 256, 10, 6
+    J, h = make_instance(N)
+    inst = product.Instance(J, h)
+    st = product.distributed.ShardedTempering(lambda i, n, b, g: product.Engine(i, None, n, chain_base=b, n_chains_global=g), inst,
+                                              np.geomspace(0.05, 4.0, G), G, 20250225, round(0.3 * G), precision="f64")
+    st.set_spins(init_spins(G, N))
+    st.plan(rounds * S, rounds, chunk_rounds=4, lazy=True)
+    st.run_rounds(rounds, S)
+    spins, energy, slots = st.eng.get_spins(), st.eng.energy_tracked(), st.eng.pt_slots()
+    st.close()
+    got = launch(tmp_path, 2, "gloo", "bench")
+    for r in (0, 1):
+        b, c = int(got[r]["base"]), int(got[r]["count"])
+        assert (b, c) == (128 * r, 128)
+        assert np.array_equal(got[r]["spins"], spins[b:b + c]) and np.array_equal(got[r]["energy"], energy[b:b + c])
+        assert np.array_equal(got[r]["slots"], slots)
