@@ -42,6 +42,26 @@ def main():
         dist.destroy_process_group()
         print(json.dumps({"rank": rank, "ok": True}))
         return
+    if mode == "apt":
+        # APT + iso-cluster moves, the temperature ladder cut into slot blocks over the ranks (SlotShardedAPT, gloo transport: the
+        # all-gather of the energies and the neighbour exchange of boundary configurations through torch.distributed on the host)
+        N, R, K, S, rounds, pairs = 600, 8, 6, 5, 6, 3
+        J, h = make_instance(N, seed=5)
+        inst = P.Instance(J, h)
+        rng = np.random.default_rng(11)
+        spins = (2 * rng.integers(0, 2, size=(K, R, N)) - 1).astype(np.int8)
+        apt = P.distributed.SlotShardedAPT(lambda i, n, b, g: P.Engine(i, None, n, device=0, chain_base=b, n_chains_global=g), inst,
+                                           np.geomspace(0.2, 2.5, R), K, 0xA5A50000, pairs, torch=torch, dist=dist, device="cpu", precision="f64")
+        apt.set_spins_by_slot(spins)
+        apt.plan(rounds, S, chunk_rounds=4)
+        logs = [apt.round(S, want_log=True, want_info=False)[0] for _ in range(rounds)]
+        cfg, en = apt.gather_by_slot()
+        apt.check()
+        np.savez(out + f".rank{rank}.npz", cfg=cfg, en=en, pairs=np.stack([l[0] for l in logs]), acc=np.stack([l[1] for l in logs]))
+        apt.close()
+        dist.destroy_process_group()
+        print(json.dumps({"rank": rank, "ok": True}))
+        return
     N, R = 300, 6
     J, h = make_instance(N, seed=4)
     betas = np.geomspace(0.3, 2.5, R)

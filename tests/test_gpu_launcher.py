@@ -115,3 +115,18 @@ def test_two_ranks_cut_the_bench_ladder(product, tmp_path):
         assert (b, c) == (128 * r, 128)
         assert np.array_equal(got[r]["spins"], spins[b:b + c]) and np.array_equal(got[r]["energy"], energy[b:b + c])
         assert np.array_equal(got[r]["slots"], slots)
+
+
+def test_two_ranks_share_the_apt_slot_blocks(product, tmp_path):
+    """Row e-2 with two PROCESSES (gloo group, both on the one GPU): 8 temperatures x 6 sub-replicas, four temperatures per rank,
+    Houdayer moves local, swaps across the block boundary exchange configurations between the processes -- states by (sub-replica,
+    slot), tracked energies and the swap log equal one context (tests/test_gpu_apt_sharded.py covers W contexts of ONE process)."""
+    from test_gpu_apt_sharded import drive, start_states
+    N, R, K, S, rounds, pairs = 600, 8, 6, 5, 6, 3
+    J, h = make_instance(N, seed=5)
+    ref = drive(product, product.Instance(J, h), np.geomspace(0.2, 2.5, R), K, start_states(K, R, N), 1, S, rounds, pairs, "f64", want_info=False)
+    got = launch(tmp_path, 2, "gloo", "apt")
+    assert ref[3].sum() > 0
+    for r in (0, 1):
+        assert np.array_equal(got[r]["cfg"], ref[0]) and np.array_equal(got[r]["en"], ref[1])
+        assert np.array_equal(got[r]["pairs"], ref[2]) and np.array_equal(got[r]["acc"], ref[3])
