@@ -283,6 +283,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    # NLMC_BENCH_BACKEND=gloo: REHEARSAL of the multi-rank code path on a box with fewer GPUs than ranks (RCCL refuses two ranks on
+    # one GPU): the ranks share the GPUs there are, the collectives go through the host.  Its numbers mean nothing; the line says so.
+    backend = os.environ.get("NLMC_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run (also with one rank)
@@ -294,8 +300,11 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            t = torch.zeros(1, device="cuda")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
+            t = torch.zeros(1, device=red_dev)
             dist.all_reduce(t)
             torch.cuda.synchronize()
         finally:
@@ -359,7 +368,7 @@ def main():
         tm = st.eng.timing_total()
         st.eng.timing_reset(False)
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         e_end = st.eng.energy()
@@ -505,6 +514,8 @@ def main():
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(use_f64=(first == "f64"))
         else:
             out["cpu_baseline"] = None
+        if backend != "nccl":
+            out["rehearsal"] = f"process group '{backend}', ranks share {torch.cuda.device_count()} GPU(s): code-path rehearsal, not a measurement"
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
