@@ -169,7 +169,7 @@ def self_launch(a, argv):
     return subprocess.call(cmd, env=env)
 
 
-C5_BETAS_PER_GPU, C5_SUBREPLICAS, C5_ROUNDS_PER_STEP = 32, 8, 1024
+C5_BETAS_PER_GPU, C5_SUBREPLICAS, C5_ROUNDS_PER_STEP = 32, 8, int(os.environ.get("NLMC_BENCH_C5_ROUNDS_PER_STEP", "1024"))
 
 
 def run_c5(a, P, inst, torch, dist, world, rank, local_rank):
@@ -183,7 +183,8 @@ def run_c5(a, P, inst, torch, dist, world, rank, local_rank):
     betas = np.geomspace(BETA_MIN, BETA_MAX, R)
     n_pairs = round(0.3 * R)
     stream = torch.cuda.current_stream().cuda_stream
-    dev = torch.device("cuda", local_rank)
+    gloo = os.environ.get("NLMC_BENCH_BACKEND", "nccl") != "nccl"          # rehearsal (see main): collectives on host tensors
+    dev = "cpu" if gloo else torch.device("cuda", local_rank)
 
     def mk(i, n, b, g, d=None):
         return P.Engine(i, None, n, device=local_rank, stream=stream, chain_base=b, n_chains_global=g)
@@ -211,7 +212,7 @@ def run_c5(a, P, inst, torch, dist, world, rank, local_rank):
         sync()
         dt = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         cfg, en = apt.gather_by_slot()
@@ -242,6 +243,8 @@ def run_c5(a, P, inst, torch, dist, world, rank, local_rank):
         if r2 is not None:
             out["second_leg"] = r2
         out["cpu_baseline"] = None
+        if gloo:
+            out["rehearsal"] = f"process group 'gloo', ranks share {torch.cuda.device_count()} GPU(s): code-path rehearsal, not a measurement"
         print(json.dumps(out), flush=True)
 
 
